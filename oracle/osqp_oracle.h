@@ -1,0 +1,180 @@
+/*
+ * oracle/osqp_oracle.h -- CPU ORACLE (TEST INFRASTRUCTURE, NOT PRODUCT CODE).
+ *
+ * Plain-C restatement of the single-instance CPU path of laperss/osqp-recursive-ldl
+ * (OSQP v0.6.0): KKT assembly, symmetric permutation, the QDLDL contract
+ * (etree / factor / solve), the `linsys_solver` backend (init / solve /
+ * update_rho_vec / update_matrices) and the ADMM loop around it.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use anything
+ * in this directory, and only as the checker / the CPU number reported beside the GPU one.
+ * The shipped library (osqp_recursive_ldl_amd/csrc) never links or calls it.
+ *
+ * PINNING STATUS
+ *   - pinned: form_KKT / update_KKT_* (tests/golden/update_matrices.json), init+solve incl. the
+ *     z-tilde epilogue (tests/golden/solve_linsys.json), ADMM known answers (basic_qp, basic_qp2,
+ *     unconstrained, update_matrices, non_cvx, primal_dual_infeasibility fixtures), all produced by
+ *     importing the reference's own Python generators (tests/golden/make_golden.py).
+ *   - NOT pinned by any reference fixture: L, D, Dinv, etree, Lnz (no reference test inspects
+ *     them; checked here by the identity P K P' = L D L' and an independent dense symbolic
+ *     factorisation), the fill-reducing permutation (the reference's vendored AMD needs the
+ *     cmake-generated osqp_configure.h and is therefore unbuildable here: "permutation parity
+ *     unpinned"), and the whole stage-recursive path ("parity unpinned", see rldl_oracle.c).
+ *   - QDLDL itself (github.com/oxfordcontrol/qdldl, ~v0.1.3 per reference CHANGELOG.md:19) is an
+ *     empty submodule in the reference; qdldl_oracle.c restates its published up-looking
+ *     algorithm against the call-site contract in lin_sys/direct/qdldl/qdldl_interface.c.
+ */
+#ifndef OSQP_ORACLE_H
+#define OSQP_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* reference include/glob_opts.h:74-85 with DLONG=ON, DFLOAT=OFF (CMakeLists.txt:79) */
+typedef long long orc_int;
+typedef double    orc_float;
+
+/* reference include/types.h:21-29 */
+typedef struct {
+  orc_int    nzmax, m, n;
+  orc_int   *p, *i;
+  orc_float *x;
+  orc_int    nz;
+} orc_csc;
+
+/* status / error values: reference include/constants.h:18-51 */
+#define ORC_SOLVED 1
+#define ORC_SOLVED_INACCURATE 2
+#define ORC_PRIMAL_INFEASIBLE_INACCURATE 3
+#define ORC_DUAL_INFEASIBLE_INACCURATE 4
+#define ORC_MAX_ITER_REACHED (-2)
+#define ORC_PRIMAL_INFEASIBLE (-3)
+#define ORC_DUAL_INFEASIBLE (-4)
+#define ORC_NON_CVX (-7)
+#define ORC_UNSOLVED (-10)
+#define ORC_LINSYS_SOLVER_INIT_ERROR 4
+#define ORC_NONCVX_ERROR 5
+#define ORC_INFTY 1e30
+#define ORC_NAN ((orc_float)0x7fc00000UL) /* sic: integer cast, constants.h:96 */
+
+/* ---- csc helpers (src/cs.c) ---- */
+orc_csc *orc_csc_spalloc(orc_int m, orc_int n, orc_int nzmax, int values, int triplet);
+void     orc_csc_spfree(orc_csc *A);
+orc_csc *orc_csc_from_arrays(orc_int m, orc_int n, const orc_int *p, const orc_int *i, const orc_float *x);
+orc_csc *orc_triplet_to_csc(const orc_csc *T, orc_int *TtoC);
+orc_int *orc_csc_pinv(const orc_int *p, orc_int n);
+orc_csc *orc_csc_symperm(const orc_csc *A, const orc_int *pinv, orc_int *AtoC, int values);
+
+/* ---- KKT (src/kkt.c) ---- */
+orc_csc *orc_form_KKT(const orc_csc *P, const orc_csc *A, orc_float param1, const orc_float *param2,
+                      orc_int *PtoKKT, orc_int *AtoKKT, orc_int **Pdiag_idx, orc_int *Pdiag_n,
+                      orc_int *param2toKKT);
+void orc_update_KKT_P(orc_csc *KKT, const orc_csc *P, const orc_int *PtoKKT, orc_float param1,
+                      const orc_int *Pdiag_idx, orc_int Pdiag_n);
+void orc_update_KKT_A(orc_csc *KKT, const orc_csc *A, const orc_int *AtoKKT);
+void orc_update_KKT_param2(orc_csc *KKT, const orc_float *param2, const orc_int *param2toKKT, orc_int m);
+
+/* ---- QDLDL contract (absent third-party; call sites qdldl_interface.c:59,74,553) ---- */
+orc_int orc_qdldl_etree(orc_int n, const orc_int *Ap, const orc_int *Ai, orc_int *work,
+                        orc_int *Lnz, orc_int *etree);
+orc_int orc_qdldl_factor(orc_int n, const orc_int *Ap, const orc_int *Ai, const orc_float *Ax,
+                         orc_int *Lp, orc_int *Li, orc_float *Lx, orc_float *D, orc_float *Dinv,
+                         const orc_int *Lnz, const orc_int *etree, orc_int *bwork, orc_int *iwork,
+                         orc_float *fwork);
+void orc_qdldl_Lsolve(orc_int n, const orc_int *Lp, const orc_int *Li, const orc_float *Lx, orc_float *x);
+void orc_qdldl_Ltsolve(orc_int n, const orc_int *Lp, const orc_int *Li, const orc_float *Lx, orc_float *x);
+void orc_qdldl_solve(orc_int n, const orc_int *Lp, const orc_int *Li, const orc_float *Lx,
+                     const orc_float *Dinv, orc_float *x);
+
+/* ---- ordering: simple exact minimum degree (the reference calls vendored AMD,
+ *      qdldl_interface.c:110-114; see PINNING STATUS) ---- */
+void orc_min_degree_order(orc_int n, const orc_int *Ap, const orc_int *Ai, orc_int *perm);
+
+/* ---- linsys backend (lin_sys/direct/qdldl/qdldl_interface.c) ---- */
+typedef struct {
+  orc_int    n, m, polish;
+  orc_float  sigma;
+  orc_csc   *L, *KKT;
+  orc_float *D, *Dinv, *bp, *sol, *rho_inv_vec, *fwork;
+  orc_int   *P, *etree, *Lnz, *iwork, *bwork;
+  orc_int   *PtoKKT, *AtoKKT, *rhotoKKT, *Pdiag_idx, Pdiag_n;
+} orc_linsys;
+
+/* perm_in == NULL -> orc_min_degree_order; otherwise that permutation is used (length n+m). */
+orc_int orc_linsys_init(orc_linsys **sp, const orc_csc *P, const orc_csc *A, orc_float sigma,
+                        const orc_float *rho_vec, orc_int polish, const orc_int *perm_in);
+orc_int orc_linsys_solve(orc_linsys *s, orc_float *b);
+orc_int orc_linsys_update_matrices(orc_linsys *s, const orc_csc *P, const orc_csc *A);
+orc_int orc_linsys_update_rho_vec(orc_linsys *s, const orc_float *rho_vec);
+void    orc_linsys_free(orc_linsys *s);
+
+/* ---- ADMM driver (src/osqp.c, src/auxil.c, src/proj.c, src/scaling.c) ---- */
+typedef struct {
+  orc_float rho, sigma, alpha, eps_abs, eps_rel, eps_prim_inf, eps_dual_inf;
+  orc_int   max_iter, check_termination, warm_start, scaling, scaled_termination;
+  orc_int   adaptive_rho, adaptive_rho_interval;
+  orc_float adaptive_rho_tolerance;
+} orc_settings;
+
+typedef struct {
+  orc_int   iter, status_val, rho_updates;
+  orc_float obj_val, pri_res, dua_res, rho_estimate;
+} orc_info;
+
+typedef struct {
+  orc_int      n, m;
+  orc_csc     *P, *A;              /* (scaled) problem data, private copies */
+  orc_float   *q, *l, *u;
+  orc_float   *rho_vec, *rho_inv_vec;
+  orc_int     *constr_type;
+  orc_float   *x, *y, *z, *xz_tilde, *x_prev, *z_prev;
+  orc_float   *Ax, *Px, *Aty, *delta_y, *Atdelta_y, *delta_x, *Pdelta_x, *Adelta_x;
+  orc_float   *D, *Dinv, *E, *Einv, c, cinv; /* scaling */
+  orc_float   *D_temp, *D_temp_A, *E_temp;
+  orc_float   *sol_x, *sol_y;
+  orc_settings settings;
+  orc_info     info;
+  orc_linsys  *linsys;
+  orc_int     *perm;               /* optional fixed permutation handed to the backend */
+} orc_workspace;
+
+void    orc_set_default_settings(orc_settings *s);
+orc_int orc_setup(orc_workspace **wp, const orc_csc *P, const orc_float *q, const orc_csc *A,
+                  const orc_float *l, const orc_float *u, const orc_settings *settings,
+                  const orc_int *perm_in);
+orc_int orc_solve(orc_workspace *w);
+orc_int orc_update_lin_cost(orc_workspace *w, const orc_float *q_new);
+orc_int orc_update_bounds(orc_workspace *w, const orc_float *l_new, const orc_float *u_new);
+orc_int orc_update_rho(orc_workspace *w, orc_float rho_new);
+orc_int orc_update_P_A(orc_workspace *w, const orc_float *Px_new, const orc_float *Ax_new);
+orc_int orc_warm_start(orc_workspace *w, const orc_float *x, const orc_float *y);
+void    orc_cleanup(orc_workspace *w);
+
+/* accessor helpers for ctypes */
+orc_float *orc_ws_x(orc_workspace *w);
+orc_float *orc_ws_y(orc_workspace *w);
+orc_float *orc_ws_z(orc_workspace *w);
+orc_float *orc_ws_sol_x(orc_workspace *w);
+orc_float *orc_ws_sol_y(orc_workspace *w);
+orc_info  *orc_ws_info(orc_workspace *w);
+orc_linsys *orc_ws_linsys(orc_workspace *w);
+orc_int    orc_linsys_nnzL(orc_linsys *s);
+void       orc_linsys_export(orc_linsys *s, orc_int *P, orc_int *etree, orc_int *Lnz, orc_int *Lp,
+                             orc_int *Li, orc_float *Lx, orc_float *D, orc_float *Dinv);
+orc_int    orc_linsys_nnzKKT(orc_linsys *s);
+void       orc_linsys_export_KKT(orc_linsys *s, orc_int *Kp, orc_int *Ki, orc_float *Kx);
+
+/* bounded CPU baseline: setup + solve `count` instances given as stacked value arrays sharing one
+ * pattern; returns elapsed seconds (CLOCK_MONOTONIC, like osqp_tic/toc src/util.c:317-337) */
+double orc_bench_shared_pattern(orc_int count, orc_int n, orc_int m, const orc_int *Pp, const orc_int *Pi,
+                                const orc_float *Px_all, const orc_int *Ap, const orc_int *Ai,
+                                const orc_float *Ax_all, const orc_float *q_all, const orc_float *l_all,
+                                const orc_float *u_all, const orc_settings *settings,
+                                const orc_int *perm_in, orc_float *x_out, orc_float *y_out,
+                                double *t_factor, double *t_solve);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,266 @@
+"""ctypes bindings for the CPU oracle (oracle/liboracle.so).
+
+Test infrastructure only: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg, never by the product package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB_PATH = os.path.join(ORACLE_DIR, "liboracle.so")
+
+c_int = C.c_longlong
+c_float = C.c_double
+IP = C.POINTER(c_int)
+FP = C.POINTER(c_float)
+
+
+class Csc(C.Structure):
+    _fields_ = [("nzmax", c_int), ("m", c_int), ("n", c_int), ("p", IP), ("i", IP), ("x", FP), ("nz", c_int)]
+
+
+class Settings(C.Structure):
+    _fields_ = [("rho", c_float), ("sigma", c_float), ("alpha", c_float), ("eps_abs", c_float),
+                ("eps_rel", c_float), ("eps_prim_inf", c_float), ("eps_dual_inf", c_float),
+                ("max_iter", c_int), ("check_termination", c_int), ("warm_start", c_int),
+                ("scaling", c_int), ("scaled_termination", c_int), ("adaptive_rho", c_int),
+                ("adaptive_rho_interval", c_int), ("adaptive_rho_tolerance", c_float)]
+
+
+class Info(C.Structure):
+    _fields_ = [("iter", c_int), ("status_val", c_int), ("rho_updates", c_int), ("obj_val", c_float),
+                ("pri_res", c_float), ("dua_res", c_float), ("rho_estimate", c_float)]
+
+
+def build(force=False):
+    if force or not os.path.exists(LIB_PATH) or any(
+            os.path.getmtime(os.path.join(ORACLE_DIR, f)) > os.path.getmtime(LIB_PATH)
+            for f in os.listdir(ORACLE_DIR) if f.endswith((".c", ".h"))):
+        subprocess.check_call(["make", "-s", "-C", ORACLE_DIR])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(LIB_PATH)
+        VP = C.c_void_p
+        L.orc_linsys_init.argtypes = [C.POINTER(VP), C.POINTER(Csc), C.POINTER(Csc), c_float, FP, c_int, IP]
+        L.orc_linsys_init.restype = c_int
+        L.orc_linsys_solve.argtypes = [VP, FP]
+        L.orc_linsys_solve.restype = c_int
+        L.orc_linsys_update_matrices.argtypes = [VP, C.POINTER(Csc), C.POINTER(Csc)]
+        L.orc_linsys_update_matrices.restype = c_int
+        L.orc_linsys_update_rho_vec.argtypes = [VP, FP]
+        L.orc_linsys_update_rho_vec.restype = c_int
+        L.orc_linsys_free.argtypes = [VP]
+        L.orc_linsys_nnzL.argtypes = [VP]
+        L.orc_linsys_nnzL.restype = c_int
+        L.orc_linsys_nnzKKT.argtypes = [VP]
+        L.orc_linsys_nnzKKT.restype = c_int
+        L.orc_linsys_export.argtypes = [VP, IP, IP, IP, IP, IP, FP, FP, FP]
+        L.orc_linsys_export_KKT.argtypes = [VP, IP, IP, FP]
+        L.orc_form_KKT.argtypes = [C.POINTER(Csc), C.POINTER(Csc), c_float, FP, IP, IP, C.POINTER(IP), IP, IP]
+        L.orc_form_KKT.restype = C.POINTER(Csc)
+        L.orc_update_KKT_P.argtypes = [C.POINTER(Csc), C.POINTER(Csc), IP, c_float, IP, c_int]
+        L.orc_update_KKT_A.argtypes = [C.POINTER(Csc), C.POINTER(Csc), IP]
+        L.orc_csc_spfree.argtypes = [C.POINTER(Csc)]
+        L.orc_qdldl_etree.argtypes = [c_int, IP, IP, IP, IP, IP]
+        L.orc_qdldl_etree.restype = c_int
+        L.orc_min_degree_order.argtypes = [c_int, IP, IP, IP]
+        L.orc_set_default_settings.argtypes = [C.POINTER(Settings)]
+        L.orc_setup.argtypes = [C.POINTER(VP), C.POINTER(Csc), FP, C.POINTER(Csc), FP, FP, C.POINTER(Settings), IP]
+        L.orc_setup.restype = c_int
+        L.orc_solve.argtypes = [VP]
+        L.orc_solve.restype = c_int
+        L.orc_cleanup.argtypes = [VP]
+        L.orc_update_lin_cost.argtypes = [VP, FP]
+        L.orc_update_bounds.argtypes = [VP, FP, FP]
+        L.orc_update_bounds.restype = c_int
+        L.orc_update_rho.argtypes = [VP, c_float]
+        L.orc_update_rho.restype = c_int
+        L.orc_update_P_A.argtypes = [VP, FP, FP]
+        L.orc_update_P_A.restype = c_int
+        L.orc_warm_start.argtypes = [VP, FP, FP]
+        for nm in ("orc_ws_x", "orc_ws_y", "orc_ws_z", "orc_ws_sol_x", "orc_ws_sol_y"):
+            getattr(L, nm).argtypes = [VP]
+            getattr(L, nm).restype = FP
+        L.orc_ws_info.argtypes = [VP]
+        L.orc_ws_info.restype = C.POINTER(Info)
+        L.orc_ws_linsys.argtypes = [VP]
+        L.orc_ws_linsys.restype = VP
+        L.orc_bench_shared_pattern.argtypes = [c_int, c_int, c_int, IP, IP, FP, IP, IP, FP, FP, FP, FP,
+                                               C.POINTER(Settings), IP, FP, FP, C.POINTER(C.c_double),
+                                               C.POINTER(C.c_double)]
+        L.orc_bench_shared_pattern.restype = C.c_double
+        for nm in ("orc_rldl_factor", ):
+            pass
+        _lib = L
+    return _lib
+
+
+def ip(a):
+    return a.ctypes.data_as(IP) if a is not None else None
+
+
+def fp(a):
+    return a.ctypes.data_as(FP) if a is not None else None
+
+
+class CscHolder:
+    """Keeps numpy arrays alive behind an orc_csc struct."""
+
+    def __init__(self, m, n, p, i, x):
+        self.p = np.ascontiguousarray(p, dtype=np.int64)
+        self.i = np.ascontiguousarray(i, dtype=np.int64)
+        self.x = np.ascontiguousarray(x, dtype=np.float64)
+        self.m, self.n = int(m), int(n)
+        self.s = Csc(len(self.x), self.m, self.n, ip(self.p), ip(self.i), fp(self.x), -1)
+
+    @classmethod
+    def from_scipy(cls, M):
+        from scipy import sparse
+        M = sparse.csc_matrix(M)
+        M.sort_indices()
+        return cls(M.shape[0], M.shape[1], M.indptr, M.indices, M.data)
+
+    @property
+    def ref(self):
+        return C.byref(self.s)
+
+
+def settings(**kw):
+    s = Settings()
+    lib().orc_set_default_settings(C.byref(s))
+    for k, v in kw.items():
+        if not hasattr(s, k):
+            raise KeyError(k)
+        setattr(s, k, v)
+    return s
+
+
+class OracleLinsys:
+    """init / solve / update_rho_vec / update_matrices of the reference's qdldl backend (CPU oracle)."""
+
+    def __init__(self, P, A, sigma, rho_vec, polish=0, perm=None):
+        self.Pc, self.Ac = CscHolder.from_scipy(P), CscHolder.from_scipy(A)
+        self.n, self.m = self.Pc.n, self.Ac.m
+        self.h = C.c_void_p()
+        rv = None if rho_vec is None else np.ascontiguousarray(rho_vec, dtype=np.float64)
+        pm = None if perm is None else np.ascontiguousarray(perm, dtype=np.int64)
+        self.status = lib().orc_linsys_init(C.byref(self.h), self.Pc.ref, self.Ac.ref, sigma, fp(rv), polish, ip(pm))
+
+    def solve(self, b):
+        b = np.array(b, dtype=np.float64, copy=True)
+        lib().orc_linsys_solve(self.h, fp(b))
+        return b
+
+    def update_rho_vec(self, rho_vec):
+        rv = np.ascontiguousarray(rho_vec, dtype=np.float64)
+        return lib().orc_linsys_update_rho_vec(self.h, fp(rv))
+
+    def update_matrices(self, P, A):
+        Pc, Ac = CscHolder.from_scipy(P), CscHolder.from_scipy(A)
+        return lib().orc_linsys_update_matrices(self.h, Pc.ref, Ac.ref)
+
+    def export(self):
+        N = self.n + self.m
+        nz = lib().orc_linsys_nnzL(self.h)
+        P = np.zeros(N, np.int64); et = np.zeros(N, np.int64); Lnz = np.zeros(N, np.int64)
+        Lp = np.zeros(N + 1, np.int64); Li = np.zeros(max(nz, 1), np.int64); Lx = np.zeros(max(nz, 1))
+        D = np.zeros(N); Dinv = np.zeros(N)
+        lib().orc_linsys_export(self.h, ip(P), ip(et), ip(Lnz), ip(Lp), ip(Li), fp(Lx), fp(D), fp(Dinv))
+        return dict(P=P, etree=et, Lnz=Lnz, Lp=Lp, Li=Li[:nz], Lx=Lx[:nz], D=D, Dinv=Dinv)
+
+    def export_KKT(self):
+        N = self.n + self.m
+        nz = lib().orc_linsys_nnzKKT(self.h)
+        Kp = np.zeros(N + 1, np.int64); Ki = np.zeros(nz, np.int64); Kx = np.zeros(nz)
+        lib().orc_linsys_export_KKT(self.h, ip(Kp), ip(Ki), fp(Kx))
+        return Kp, Ki, Kx
+
+    def free(self):
+        if self.h:
+            lib().orc_linsys_free(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class OracleOSQP:
+    """osqp_setup / osqp_solve / osqp_update_* on the CPU oracle."""
+
+    def __init__(self, P, q, A, l, u, perm=None, **kw):
+        self.Pc, self.Ac = CscHolder.from_scipy(P), CscHolder.from_scipy(A)
+        self.n, self.m = self.Pc.n, self.Ac.m
+        self.q = np.ascontiguousarray(q, dtype=np.float64)
+        self.l = np.ascontiguousarray(l, dtype=np.float64)
+        self.u = np.ascontiguousarray(u, dtype=np.float64)
+        self.st = settings(**kw)
+        pm = None if perm is None else np.ascontiguousarray(perm, dtype=np.int64)
+        self.h = C.c_void_p()
+        self.status = lib().orc_setup(C.byref(self.h), self.Pc.ref, fp(self.q), self.Ac.ref, fp(self.l),
+                                      fp(self.u), C.byref(self.st), ip(pm))
+
+    def _vec(self, fn, n):
+        return np.ctypeslib.as_array(fn(self.h), shape=(max(n, 1),))[:n].copy()
+
+    def solve(self):
+        flag = lib().orc_solve(self.h)
+        info = lib().orc_ws_info(self.h).contents
+        return dict(flag=flag, x=self._vec(lib().orc_ws_sol_x, self.n), y=self._vec(lib().orc_ws_sol_y, self.m),
+                    iter=info.iter, status=info.status_val, obj=info.obj_val, pri_res=info.pri_res,
+                    dua_res=info.dua_res, rho_updates=info.rho_updates,
+                    x_iter=self._vec(lib().orc_ws_x, self.n), y_iter=self._vec(lib().orc_ws_y, self.m),
+                    z_iter=self._vec(lib().orc_ws_z, self.m))
+
+    def update_lin_cost(self, q):
+        q = np.ascontiguousarray(q, dtype=np.float64)
+        lib().orc_update_lin_cost(self.h, fp(q))
+
+    def update_bounds(self, l, u):
+        l = np.ascontiguousarray(l, dtype=np.float64); u = np.ascontiguousarray(u, dtype=np.float64)
+        return lib().orc_update_bounds(self.h, fp(l), fp(u))
+
+    def update_rho(self, rho):
+        return lib().orc_update_rho(self.h, rho)
+
+    def update_P_A(self, Px=None, Ax=None):
+        Px = None if Px is None else np.ascontiguousarray(Px, dtype=np.float64)
+        Ax = None if Ax is None else np.ascontiguousarray(Ax, dtype=np.float64)
+        return lib().orc_update_P_A(self.h, fp(Px), fp(Ax))
+
+    def warm_start(self, x, y):
+        x = np.ascontiguousarray(x, dtype=np.float64); y = np.ascontiguousarray(y, dtype=np.float64)
+        lib().orc_warm_start(self.h, fp(x), fp(y))
+
+    def linsys_export(self):
+        ls = lib().orc_ws_linsys(self.h)
+        tmp = OracleLinsys.__new__(OracleLinsys)
+        tmp.h = C.c_void_p(ls); tmp.n, tmp.m = self.n, self.m
+        out = tmp.export()
+        tmp.h = C.c_void_p()
+        return out
+
+    def cleanup(self):
+        if self.h:
+            lib().orc_cleanup(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.cleanup()
+        except Exception:
+            pass

@@ -1,0 +1,276 @@
+"""CPU tests: pin the oracle (oracle/*.c) against the golden vectors produced by the reference's own
+Python generators (tests/golden/make_golden.py), and against algebraic identities for the
+quantities no reference test inspects (L, D, etree, Lnz).
+
+Reference suites mirrored:
+  tests/solve_linsys/test_solve_linsys.h:12-48       -> test_solve_linsys_*
+  tests/update_matrices/test_update_matrices.h:13-72  -> test_form_KKT
+  tests/update_matrices/test_update_matrices.h:74-313 -> test_update_matrices_solves
+  tests/basic_qp/test_basic_qp.h                      -> test_basic_qp_*
+  tests/basic_qp2/test_basic_qp2.h                    -> test_basic_qp2_*
+  tests/unconstrained/test_unconstrained.h            -> test_unconstrained
+  tests/non_cvx/test_non_cvx.h:31-36,53-58            -> test_non_cvx
+  tests/primal_dual_infeasibility/...                 -> test_primal_dual_infeasibility
+Tolerance: TESTS_TOL = 1e-4 (tests/minunit.h:13) for the reference's known answers.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+from scipy import sparse
+
+import oracle_bindings as ob
+from helpers import dense_from_L, dense_symbolic, full_kkt, load_golden, osqp_inf, random_qp
+
+TESTS_TOL = 1e-4
+
+
+def test_solve_linsys_golden():
+    d = load_golden("solve_linsys")["data"]
+    n, m = d["test_solve_KKT_n"], d["test_solve_KKT_m"]
+    rho_vec = np.full(m, d["test_solve_KKT_rho"])
+    s = ob.OracleLinsys(d["test_solve_KKT_Pu"], d["test_solve_KKT_A"], d["test_solve_KKT_sigma"], rho_vec)
+    assert s.status == 0
+    x = s.solve(d["test_solve_KKT_rhs"])
+    assert np.max(np.abs(x - d["test_solve_KKT_x"])) < TESTS_TOL
+    # tighter: the fixture is an exact scipy splu solve, the oracle should agree to ~1e-12
+    assert np.max(np.abs(x - d["test_solve_KKT_x"])) < 1e-10
+    # the fixture's dense KKT equals ours
+    K = full_kkt(d["test_solve_KKT_Pu"], d["test_solve_KKT_A"], d["test_solve_KKT_sigma"], rho_vec)
+    assert np.allclose(K, d["test_solve_KKT_KKT"].toarray(), atol=1e-14)
+
+
+def test_solve_linsys_polish_returns_raw_solution():
+    d = load_golden("solve_linsys")["data"]
+    P, A = d["test_solve_KKT_Pu"], d["test_solve_KKT_A"]
+    m = A.shape[0]
+    delta = 1e-6
+    s = ob.OracleLinsys(P, A, delta, None, polish=1)
+    rhs = d["test_solve_KKT_rhs"]
+    x = s.solve(rhs)
+    K = full_kkt(P, A, delta, np.full(m, 1.0 / delta))
+    assert np.allclose(K @ x, rhs, atol=1e-8)
+
+
+def test_form_KKT_golden():
+    d = load_golden("update_matrices")["data"]
+    n, m = d["test_form_KKT_n"], d["test_form_KKT_m"]
+    Pu, A = d["test_form_KKT_Pu"], d["test_form_KKT_A"]
+    Pc, Ac = ob.CscHolder.from_scipy(Pu), ob.CscHolder.from_scipy(A)
+    rho_inv = np.full(m, 1.0 / d["test_form_KKT_rho"])
+    PtoKKT = np.zeros(Pu.nnz, np.int64); AtoKKT = np.zeros(A.nnz, np.int64)
+    Pdiag = ob.IP(); Pdiag_n = ob.c_int(0)
+    K = ob.lib().orc_form_KKT(Pc.ref, Ac.ref, d["test_form_KKT_sigma"], ob.fp(rho_inv), ob.ip(PtoKKT),
+                              ob.ip(AtoKKT), C.byref(Pdiag), C.byref(Pdiag_n), None)
+    Kc = K.contents
+    N = n + m
+    nz = Kc.p[N]
+    Kp = np.array([Kc.p[i] for i in range(N + 1)]); Ki = np.array([Kc.i[i] for i in range(nz)])
+    Kx = np.array([Kc.x[i] for i in range(nz)])
+    ref = sparse.csc_matrix(d["test_form_KKT_KKTu"]); ref.sort_indices()
+    assert (Kp == ref.indptr).all() and (Ki == ref.indices).all()       # exact pattern
+    assert np.max(np.abs(Kx - ref.data)) < 1e-14                         # values
+    # update_KKT_P / update_KKT_A (test_update_matrices.h:52-60)
+    Pn, An = ob.CscHolder.from_scipy(d["test_form_KKT_Pu_new"]), ob.CscHolder.from_scipy(d["test_form_KKT_A_new"])
+    ob.lib().orc_update_KKT_P(K, Pn.ref, ob.ip(PtoKKT), d["test_form_KKT_sigma"], Pdiag, Pdiag_n)
+    ob.lib().orc_update_KKT_A(K, An.ref, ob.ip(AtoKKT))
+    Kx2 = np.array([Kc.x[i] for i in range(nz)])
+    ref2 = sparse.csc_matrix(d["test_form_KKT_KKTu_new"]); ref2.sort_indices()
+    assert (ref2.indices == ref.indices).all()
+    assert np.max(np.abs(Kx2 - ref2.data)) < 1e-14
+    ob.lib().orc_csc_spfree(K)
+
+
+def _solve_settings(**kw):
+    base = dict(eps_abs=1e-7, eps_rel=1e-7, max_iter=20000, check_termination=1, scaling=10, adaptive_rho=1)
+    base.update(kw)
+    return base
+
+
+def test_update_matrices_solves_golden():
+    d = load_golden("update_matrices")["data"]
+    args = (d["test_solve_Pu"], d["test_solve_q"], d["test_solve_A"], d["test_solve_l"], d["test_solve_u"])
+    for scaling in (0, 10):
+        w = ob.OracleOSQP(*args, **_solve_settings(scaling=scaling))
+        r = w.solve()
+        assert r["status"] == ob_status("solved")
+        assert np.max(np.abs(r["x"] - d["test_solve_x"])) < TESTS_TOL
+        assert np.max(np.abs(r["y"] - d["test_solve_y"])) < TESTS_TOL
+        assert abs(r["obj"] - d["test_solve_obj_value"]) < TESTS_TOL
+        # update P (test_update_matrices.h:130-160)
+        assert w.update_P_A(Px=sparse.csc_matrix(d["test_solve_Pu_new"]).data) == 0
+        r = w.solve()
+        assert np.max(np.abs(r["x"] - d["test_solve_P_new_x"])) < TESTS_TOL
+        assert abs(r["obj"] - d["test_solve_P_new_obj_value"]) < TESTS_TOL
+        w.cleanup()
+        # update A only
+        w = ob.OracleOSQP(*args, **_solve_settings(scaling=scaling))
+        assert w.update_P_A(Ax=sparse.csc_matrix(d["test_solve_A_new"]).data) == 0
+        r = w.solve()
+        assert np.max(np.abs(r["x"] - d["test_solve_A_new_x"])) < TESTS_TOL
+        assert abs(r["obj"] - d["test_solve_A_new_obj_value"]) < TESTS_TOL
+        # then P and A
+        assert w.update_P_A(Px=sparse.csc_matrix(d["test_solve_Pu_new"]).data,
+                            Ax=sparse.csc_matrix(d["test_solve_A_new"]).data) == 0
+        r = w.solve()
+        assert np.max(np.abs(r["x"] - d["test_solve_P_A_new_x"])) < TESTS_TOL
+        assert abs(r["obj"] - d["test_solve_P_A_new_obj_value"]) < TESTS_TOL
+        w.cleanup()
+
+
+def ob_status(name):
+    return {"solved": 1, "max_iter": -2, "primal_infeasible": -3, "dual_infeasible": -4, "non_cvx": -7}[name]
+
+
+def test_basic_qp_golden():
+    d = load_golden("basic_qp")
+    s = d["sols"]
+    w = ob.OracleOSQP(d["P"], d["q"], d["A"], osqp_inf(d["l"]), osqp_inf(d["u"]), **_solve_settings())
+    r = w.solve()
+    assert r["status"] == 1
+    assert np.max(np.abs(r["x"] - s["x_test"])) < TESTS_TOL
+    assert np.max(np.abs(r["y"] - s["y_test"])) < TESTS_TOL
+    assert abs(r["obj"] - s["obj_value_test"]) < TESTS_TOL
+    # bounds / cost updates keep solving (test_basic_qp.h:88-240): cross-check against a fresh setup
+    w.update_lin_cost(s["q_new"])
+    assert w.update_bounds(osqp_inf(s["l_new"]), osqp_inf(s["u_new"])) == 0
+    r2 = w.solve()
+    w2 = ob.OracleOSQP(d["P"], s["q_new"], d["A"], osqp_inf(s["l_new"]), osqp_inf(s["u_new"]), **_solve_settings())
+    r3 = w2.solve()
+    assert r2["status"] == r3["status"] == 1
+    assert np.max(np.abs(r2["x"] - r3["x"])) < TESTS_TOL
+    assert np.max(np.abs(r2["y"] - r3["y"])) < TESTS_TOL
+
+
+def test_basic_qp_update_rho_same_iterations():
+    """test_basic_qp.h:651-779: update_rho_vec must behave exactly like a fresh factorisation."""
+    d = load_golden("basic_qp")
+    kw = dict(rho=0.7, adaptive_rho=0, eps_abs=5e-5, eps_rel=5e-5, check_termination=1, scaling=10, max_iter=4000)
+    a = ob.OracleOSQP(d["P"], d["q"], d["A"], osqp_inf(d["l"]), osqp_inf(d["u"]), **kw)
+    ra = a.solve()
+    kw2 = dict(kw); kw2["rho"] = 0.1
+    b = ob.OracleOSQP(d["P"], d["q"], d["A"], osqp_inf(d["l"]), osqp_inf(d["u"]), warm_start=0, **kw2)
+    rb0 = b.solve()
+    assert b.update_rho(0.7) == 0
+    rb = b.solve()
+    assert ra["iter"] == rb["iter"]
+    assert rb0["iter"] != 0
+    assert np.max(np.abs(ra["x"] - rb["x"])) < 1e-9
+
+
+def test_basic_qp2_golden():
+    d = load_golden("basic_qp2")
+    s = d["sols"]
+    w = ob.OracleOSQP(d["P"], d["q"], d["A"], osqp_inf(d["l"]), osqp_inf(d["u"]),
+                      **_solve_settings(eps_abs=1e-9, eps_rel=1e-9, max_iter=200000))
+    r = w.solve()
+    assert r["status"] == 1
+    assert np.max(np.abs(r["x"] - s["x_test"])) < TESTS_TOL * 10
+    assert np.max(np.abs(r["y"] - s["y_test"])) < TESTS_TOL * 1000 * 1e-1
+    assert abs(r["obj"] - s["obj_value_test"]) / abs(s["obj_value_test"]) < TESTS_TOL
+    w.update_lin_cost(s["q_new"])
+    assert w.update_bounds(osqp_inf(d["l"]), osqp_inf(s["u_new"])) == 0
+    r = w.solve()
+    assert r["status"] == 1
+    assert np.max(np.abs(r["x"] - s["x_test_new"])) < TESTS_TOL * 10
+    assert abs(r["obj"] - s["obj_value_test_new"]) / abs(s["obj_value_test_new"]) < TESTS_TOL
+
+
+def test_unconstrained_golden():
+    d = load_golden("unconstrained")
+    s = d["sols"]
+    w = ob.OracleOSQP(d["P"], d["q"], d["A"], d["l"], d["u"], **_solve_settings())
+    r = w.solve()
+    assert r["status"] == 1
+    assert np.max(np.abs(r["x"] - s["x_test"])) < TESTS_TOL
+    assert abs(r["obj"] - s["obj_value_test"]) < TESTS_TOL
+
+
+def test_non_cvx_golden():
+    """test_non_cvx.h:31-36: setup must fail with OSQP_NONCVX_ERROR at sigma=1e-6; with sigma_new=5
+    setup succeeds and the solve diverges to OSQP_NON_CVX with obj_val == OSQP_NAN (:53-58)."""
+    d = load_golden("non_cvx")
+    w = ob.OracleOSQP(d["P"], d["q"], d["A"], osqp_inf(d["l"]), osqp_inf(d["u"]), sigma=1e-6)
+    assert w.status == 5
+    w = ob.OracleOSQP(d["P"], d["q"], d["A"], osqp_inf(d["l"]), osqp_inf(d["u"]),
+                      sigma=float(d["sols"]["sigma_new"]), adaptive_rho=1, max_iter=4000)
+    assert w.status == 0
+    r = w.solve()
+    assert r["status"] == -7
+    assert r["obj"] == float(0x7fc00000)
+
+
+def test_primal_dual_infeasibility_golden():
+    d = load_golden("primal_dual_infeasibility")["data"]
+    P, q = d["P"], d["q"]
+    cases = [("A12", "u1", 1, d["x1"], d["y1"], d["obj_value1"]), ("A12", "u2", -3, None, None, None),
+             ("A34", "u3", -4, None, None, None), ("A34", "u4", (-3, -4), None, None, None)]
+    for Ak, uk, status, x, y, obj in cases:
+        A = d[Ak]; u = osqp_inf(d[uk]); l = osqp_inf(d["l"])
+        # reference settings: scaling 0, max_iter 2000 (test_primal_dual_infeasibility.h:35-39); test 1 there
+        # relies on polish for 1e-4 accuracy, here tighter eps instead; test 4 accepts either certificate (:229-231)
+        w = ob.OracleOSQP(P, q, A, l, u, **_solve_settings(eps_abs=1e-6, eps_rel=1e-6, scaling=0, max_iter=2000,
+                                                            check_termination=25))
+        r = w.solve()
+        ok = status if isinstance(status, tuple) else (status,)
+        assert r["status"] in ok, (Ak, uk, r["status"])
+        if x is not None:
+            assert np.max(np.abs(r["x"] - x)) < TESTS_TOL
+            assert np.max(np.abs(r["y"] - y)) < TESTS_TOL
+            assert abs(r["obj"] - obj) < TESTS_TOL
+
+
+def test_lin_alg_golden_spmv():
+    """tests/lin_alg/test_lin_alg.h mat_vec / mat_tpose_vec: the oracle's residual SpMVs are pinned
+    indirectly through the ADMM tests; here we pin the fixture algebra itself so the GPU tests can
+    reuse it."""
+    d = load_golden("lin_alg")["data"]
+    A = d["test_mat_vec_A"]
+    assert np.allclose(A @ d["test_mat_vec_x"], d["test_mat_vec_Ax"], atol=1e-12)
+    assert np.allclose(A.T @ d["test_mat_vec_y"], d["test_mat_vec_ATy"], atol=1e-12)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_ldl_identity_and_symbolic(seed):
+    """Unpinned-by-reference quantities: check P K P' = L D L' and etree/Lnz against an
+    independent dense symbolic elimination."""
+    P, q, A, l, u = random_qp(seed, n=20, m=35, density=0.2)
+    n, m = 20, 35
+    rho = np.full(m, 0.1)
+    s = ob.OracleLinsys(P, A, 1e-6, rho)
+    assert s.status == 0
+    e = s.export()
+    N = n + m
+    K = full_kkt(P, A, 1e-6, rho)
+    perm = e["P"]
+    assert sorted(perm.tolist()) == list(range(N))
+    Kp = K[np.ix_(perm, perm)]
+    L = dense_from_L(e["Lp"], e["Li"], e["Lx"], N)
+    R = L @ np.diag(e["D"]) @ L.T
+    assert np.max(np.abs(R - Kp)) <= 1e-12 * max(1.0, np.max(np.abs(K)))
+    assert np.allclose(e["Dinv"], 1.0 / e["D"], rtol=1e-15)
+    assert (e["D"] > 0).sum() == n and (e["D"] < 0).sum() == m
+    et, Lnz, cols = dense_symbolic(np.triu(Kp != 0))
+    assert (et == e["etree"]).all()
+    assert (Lnz == e["Lnz"]).all()
+    for j in range(N):
+        assert e["Li"][e["Lp"][j]:e["Lp"][j + 1]].tolist() == cols[j]
+    # solve
+    b = np.random.default_rng(seed).standard_normal(N)
+    x = s.solve(b)
+    sol = np.linalg.solve(K, b)
+    expect = np.concatenate([sol[:n], b[n:] + sol[n:] / rho])
+    assert np.max(np.abs(x - expect)) < 1e-9
+    # update_rho_vec == fresh init
+    rho2 = np.full(m, 0.37)
+    assert s.update_rho_vec(rho2) == 0
+    s2 = ob.OracleLinsys(P, A, 1e-6, rho2, perm=perm)
+    assert np.max(np.abs(s.export()["Lx"] - s2.export()["Lx"])) == 0.0
+
+
+def test_etree_rejects_lower_entries():
+    Ap = np.array([0, 2, 3], np.int64); Ai = np.array([0, 1, 1], np.int64)  # entry (1,0) below diagonal
+    w = np.zeros(2, np.int64); Lnz = np.zeros(2, np.int64); et = np.zeros(2, np.int64)
+    assert ob.lib().orc_qdldl_etree(2, ob.ip(Ap), ob.ip(Ai), ob.ip(w), ob.ip(Lnz), ob.ip(et)) < 0
+    Ap = np.array([0, 1, 1], np.int64); Ai = np.array([0], np.int64)  # empty column
+    assert ob.lib().orc_qdldl_etree(2, ob.ip(Ap), ob.ip(Ai), ob.ip(w), ob.ip(Lnz), ob.ip(et)) < 0
