@@ -1,0 +1,181 @@
+/*
+ * osqp_rldl_hip.h -- C ABI of the MI355X-native batched direct KKT backend for OSQP's ADMM loop.
+ *
+ * Drop-in boundary.  Every entry point is plain C: pointers and sizes only,
+ * no torch / HIP types in any signature (a HIP stream is passed as `void *`).  Each declaration
+ * names the reference interface it replaces as file:line under laperss/osqp-recursive-ldl.
+ *
+ * Three layers, all exported by libosqp_rldl_hip.so:
+ *   1. legacy single-instance plugin  (host pointers; what `init_linsys_solver` would dispatch to)
+ *   2. batched plugin                 (device pointers; the same five operations with a leading batch dim)
+ *   3. batched ADMM driver            (device-resident mirror of osqp_setup/solve/update_*)
+ *   4. stage-recursive factorisation  (MPC stage blocks; alternative `init` strategy of layer 2)
+ */
+#ifndef OSQP_RLDL_HIP_H
+#define OSQP_RLDL_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- scalar types: include/glob_opts.h:74-85 with the reference defaults DLONG=ON, DFLOAT=OFF ---- */
+typedef long long c_int;
+typedef double    c_float;
+
+/* ---- compressed-column matrix: include/types.h:21-29 (identical layout) ---- */
+#ifndef OSQP_TYPES_H
+typedef struct {
+  c_int    nzmax;
+  c_int    m;
+  c_int    n;
+  c_int   *p;
+  c_int   *i;
+  c_float *x;
+  c_int    nz;
+} csc;
+#endif
+
+/* ---- solver enum: include/constants.h:36 has { QDLDL_SOLVER, MKL_PARDISO_SOLVER };
+ *      recursive_ldl.h:55 adds QDLDL_HORIZON_SOLVER=10.  We register value 20. ---- */
+#define HIP_LDL_SOLVER 20
+
+/* ---- error / status codes: include/constants.h:18-51 ---- */
+#define RLDL_LINSYS_SOLVER_INIT_ERROR 4 /* OSQP_LINSYS_SOLVER_INIT_ERROR */
+#define RLDL_NONCVX_ERROR 5             /* OSQP_NONCVX_ERROR */
+#define RLDL_MEM_ALLOC_ERROR 6          /* OSQP_MEM_ALLOC_ERROR */
+#define RLDL_NO_DEVICE_ERROR 100        /* no HIP device / kernel image: the product never falls back to CPU */
+
+/* =====================================================================================
+ * 1. Legacy single-instance plugin (prefix-compatible with `struct linsys_solver`,
+ *    include/types.h:298-319; mirror of qdldl_solver, lin_sys/direct/qdldl/qdldl_interface.h:16-74)
+ * ===================================================================================== */
+typedef struct hipldl hipldl_solver;
+struct hipldl {
+  int type;                                             /* enum linsys_solver_type        types.h:299 */
+  c_int (*solve)(hipldl_solver *self, c_float *b);      /*                               types.h:300-301 */
+  void (*free)(hipldl_solver *self);                    /*                               types.h:304 */
+  c_int (*update_matrices)(hipldl_solver *self, const csc *P, const csc *A); /*          types.h:308-310 */
+  c_int (*update_rho_vec)(hipldl_solver *self, const c_float *rho_vec);     /*          types.h:312-313 */
+  c_int nthreads;                                       /*                               types.h:317 */
+  void *impl;                                           /* private: one-instance rldl_batch + staging */
+};
+
+/* replaces init_linsys_solver_qdldl           lin_sys/direct/qdldl/qdldl_interface.c:170-316 */
+c_int init_linsys_solver_hipldl(hipldl_solver **sp, const csc *P, const csc *A, c_float sigma,
+                                const c_float *rho_vec, c_int polish);
+/* replaces solve_linsys_qdldl                 qdldl_interface.c:559-585 */
+c_int solve_linsys_hipldl(hipldl_solver *s, c_float *b);
+/* replaces update_linsys_solver_matrices_qdldl qdldl_interface.c:590-602 */
+c_int update_linsys_solver_matrices_hipldl(hipldl_solver *s, const csc *P, const csc *A);
+/* replaces update_linsys_solver_rho_vec_qdldl  qdldl_interface.c:605-619 */
+c_int update_linsys_solver_rho_vec_hipldl(hipldl_solver *s, const c_float *rho_vec);
+/* replaces free_linsys_solver_qdldl            qdldl_interface.c:17-43 */
+void free_linsys_solver_hipldl(hipldl_solver *s);
+
+/* =====================================================================================
+ * 2. Batched plugin: `batch` independent instances sharing ONE sparsity pattern of P (upper
+ *    triangular n x n) and A (m x n).  Value arrays are DEVICE pointers, instance-major:
+ *      d_Px[batch][nnzP], d_Ax[batch][nnzA], d_rho_vec[batch][m], d_b[batch][n+m].
+ *    Semantics per instance are exactly those of layer 1.
+ * ===================================================================================== */
+typedef struct rldl_batch rldl_batch;
+
+/* init (qdldl_interface.c:170-316): symbolic phase on the host (form_KKT src/kkt.c:6-177, ordering,
+ * csc_symperm src/cs.c:153-206, QDLDL_etree), numeric factor on the device.
+ * `P`/`A` give the pattern (their ->x is ignored); `perm` (host, length n+m) may be NULL.
+ * polish != 0: d_rho_vec must be NULL, sigma is used as delta for all of param2 (:254-265).
+ * Returns 0, RLDL_LINSYS_SOLVER_INIT_ERROR, or RLDL_NONCVX_ERROR when ANY instance has fewer than n
+ * positive pivots or a zero pivot (:80-92); per-instance detail via rldl_batch_factor_status. */
+c_int rldl_batch_init(rldl_batch **hp, c_int batch, const csc *P, const csc *A, const c_float *d_Px,
+                      const c_float *d_Ax, c_float sigma, const c_float *d_rho_vec, c_int polish,
+                      const c_int *perm, void *stream);
+/* solve (qdldl_interface.c:559-585): in/out d_b; non-polish post-condition b[0:n]=x_tilde,
+ * b[n+j] += rho_inv[j]*nu[j]; polish: raw KKT solution. */
+c_int rldl_batch_solve(rldl_batch *h, c_float *d_b);
+/* update_matrices (qdldl_interface.c:590-602): scatter through PtoKKT/AtoKKT (src/kkt.c:184-212), full
+ * numeric refactor.  Either pointer may be NULL (= unchanged).  Returns 0 ok / 1 failed. */
+c_int rldl_batch_update_matrices(rldl_batch *h, const c_float *d_Px, const c_float *d_Ax);
+/* update_rho_vec (qdldl_interface.c:605-619): rho_inv, KKT diagonal (src/kkt.c:214-222), refactor.
+ * d_mask (device, int32[batch]) may be NULL; otherwise only instances with mask != 0 are touched. */
+c_int rldl_batch_update_rho_vec(rldl_batch *h, const c_float *d_rho_vec, const int *d_mask);
+/* free (qdldl_interface.c:17-43) */
+void rldl_batch_free(rldl_batch *h);
+
+/* Host-only symbolic analysis (no device needed): form_KKT pattern + maps (src/kkt.c:6-177), ordering +
+ * csc_symperm + map composition (qdldl_interface.c:99-166), QDLDL_etree (call site :59).  Any output
+ * pointer may be NULL; call once with NULL arrays to obtain nnzKKT / nnzL, then again with buffers.
+ * Returns 0 or RLDL_LINSYS_SOLVER_INIT_ERROR. */
+c_int rldl_symbolic_analyze(const csc *P, const csc *A, c_int polish, const c_int *perm_in, c_int *nnzKKT,
+                            c_int *nnzL, c_int *etree_height, c_int *perm, c_int *etree, c_int *Lnz, c_int *Lp,
+                            c_int *Li, c_int *KKTp, c_int *KKTi, c_int *PtoKKT, c_int *AtoKKT, c_int *rhotoKKT);
+/* closed-form stage-interleaved permutation, compute_permutations src/recursive_ldl.c:1350-1362 */
+void rldl_stage_permutation(c_int N, c_int nx, c_int nu, c_int ny, c_int nt, c_int *perm);
+
+/* introspection for parity tests and for the roofline's algorithmic-byte count */
+c_int rldl_batch_dims(const rldl_batch *h, c_int *n, c_int *m, c_int *nnzKKT, c_int *nnzL, c_int *batch);
+c_int rldl_batch_export_symbolic(const rldl_batch *h, c_int *perm, c_int *etree, c_int *Lnz, c_int *Lp,
+                                 c_int *Li, c_int *KKTp, c_int *KKTi, c_int *PtoKKT, c_int *AtoKKT,
+                                 c_int *rhotoKKT);
+c_int rldl_batch_export_factor(const rldl_batch *h, c_int inst, c_float *Lx, c_float *D, c_float *Dinv,
+                               c_float *KKTx);                      /* host buffers, CSC order */
+c_int rldl_batch_factor_status(const rldl_batch *h, c_int *status); /* host[batch]: #positive D, or -1 */
+/* average device time (ms) of the last `solve` kernel launch group measured with HIP events on the
+ * handle's stream; bench.py's live roofline measurement uses this */
+c_int rldl_batch_time_solve(rldl_batch *h, c_float *d_b, c_int reps, c_float *ms_per_launch);
+
+/* =====================================================================================
+ * 3. Batched ADMM driver (device-resident mirror of src/osqp.c + src/auxil.c step kernels)
+ * ===================================================================================== */
+typedef struct {           /* subset of OSQPSettings, include/types.h:139-176; defaults constants.h:59-115 */
+  c_float rho, sigma, alpha, eps_abs, eps_rel, eps_prim_inf, eps_dual_inf;
+  c_int   max_iter, check_termination, warm_start, scaling, scaled_termination;
+  c_int   adaptive_rho, adaptive_rho_interval;
+  c_float adaptive_rho_tolerance;
+} OSQPBatchSettings;
+
+typedef struct osqp_batch osqp_batch;
+
+void  osqp_batch_set_default_settings(OSQPBatchSettings *s);           /* osqp.c:24-71 */
+/* osqp_setup (osqp.c:76-283).  All value arrays are DEVICE pointers, instance-major:
+ * d_Px[batch][nnzP], d_Ax[batch][nnzA], d_q[batch][n], d_l/d_u[batch][m]. */
+c_int osqp_batch_setup(osqp_batch **wp, c_int batch, const csc *P, const csc *A, const c_float *d_Px,
+                       const c_float *d_Ax, const c_float *d_q, const c_float *d_l, const c_float *d_u,
+                       const OSQPBatchSettings *settings, const c_int *perm, void *stream);
+c_int osqp_batch_solve(osqp_batch *w);                                  /* osqp.c:288-641 */
+c_int osqp_batch_update_lin_cost(osqp_batch *w, const c_float *d_q);   /* osqp.c:752-790 */
+c_int osqp_batch_update_bounds(osqp_batch *w, const c_float *d_l, const c_float *d_u); /* osqp.c:792-841 */
+c_int osqp_batch_update_rho(osqp_batch *w, c_float rho_new);           /* osqp.c:1268-1319 */
+c_int osqp_batch_update_P_A(osqp_batch *w, const c_float *d_Px, const c_float *d_Ax); /* osqp.c:1158-1266 */
+c_int osqp_batch_warm_start(osqp_batch *w, const c_float *d_x, const c_float *d_y);   /* osqp.c:929-948 */
+/* results: device pointers owned by the workspace (valid until cleanup) */
+c_int osqp_batch_get(osqp_batch *w, c_float **d_x, c_float **d_y, c_float **d_z, int **d_status,
+                     int **d_iter, c_float **d_obj, c_float **d_pri_res, c_float **d_dua_res);
+rldl_batch *osqp_batch_linsys(osqp_batch *w);
+/* timing of the fused ADMM-iteration kernel (HIP events on the workspace stream), for the roofline */
+c_int osqp_batch_time_iteration(osqp_batch *w, c_int reps, c_float *ms_per_launch);
+void  osqp_batch_cleanup(osqp_batch *w);                                /* osqp.c:646-744 */
+
+/* =====================================================================================
+ * 4. Stage-recursive LDL for MPC-structured KKT (src/recursive_ldl.c)
+ * ===================================================================================== */
+typedef struct {           /* stage sizes: include/recursive_ldl.h:17-50 (N, nx, nu, ny, nt) */
+  c_int N, nx, nu, ny, nt;
+} rldl_stage_dims;
+
+/* Replaces LDL_factorize_recursive (src/recursive_ldl.c:1139-1318) + init_linsys_solver_qdldl_recursive
+ * (:1555-1672): the batch handle is built from the ASSEMBLED P, A of setup_AP_matrices (:1873-1970)
+ * and factorised stage by stage with the closed-form interleaved permutation (:1350-1362). */
+c_int rldl_batch_init_recursive(rldl_batch **hp, c_int batch, const rldl_stage_dims *dims, const csc *P,
+                                const csc *A, const c_float *d_Px, const c_float *d_Ax, c_float sigma,
+                                const c_float *d_rho_vec, void *stream);
+/* Replaces LDL_update_from_pivot (:946-1110): re-run the stage recursion from stage `first_stage` on
+ * (after P/A values of stages >= first_stage, or rho, changed). */
+c_int rldl_batch_update_from_stage(rldl_batch *h, c_int first_stage, const c_float *d_Px, const c_float *d_Ax,
+                                   const c_float *d_rho_vec);
+
+const char *rldl_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,178 @@
+"""Loader for libosqp_rldl_hip.so (the C-ABI of include/osqp_rldl_hip.h) via ctypes.
+
+There is no CPU fallback anywhere in this package: if the shared library is missing the import of
+this module raises, and if no HIP device is present every compute entry point returns
+RLDL_NO_DEVICE_ERROR (100), which the wrappers turn into a RuntimeError.
+"""
+import ctypes as C
+import os
+import subprocess
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG_DIR, "csrc")
+LIB_PATH = os.path.join(PKG_DIR, "libosqp_rldl_hip.so")
+
+c_int = C.c_longlong
+c_float = C.c_double
+IP = C.POINTER(c_int)
+FP = C.POINTER(c_float)
+VP = C.c_void_p
+
+RLDL_NO_DEVICE_ERROR = 100
+HIP_LDL_SOLVER = 20
+
+
+class Csc(C.Structure):
+    """include/types.h:21-29"""
+    _fields_ = [("nzmax", c_int), ("m", c_int), ("n", c_int), ("p", IP), ("i", IP), ("x", FP), ("nz", c_int)]
+
+
+class HipldlSolver(C.Structure):
+    """Prefix-compatible with struct linsys_solver (include/types.h:298-319)."""
+    pass
+
+
+HipldlSolver._fields_ = [
+    ("type", C.c_int),
+    ("solve", C.CFUNCTYPE(c_int, C.POINTER(HipldlSolver), FP)),
+    ("free", C.CFUNCTYPE(None, C.POINTER(HipldlSolver))),
+    ("update_matrices", C.CFUNCTYPE(c_int, C.POINTER(HipldlSolver), C.POINTER(Csc), C.POINTER(Csc))),
+    ("update_rho_vec", C.CFUNCTYPE(c_int, C.POINTER(HipldlSolver), FP)),
+    ("nthreads", c_int),
+    ("impl", VP),
+]
+
+
+class OSQPBatchSettings(C.Structure):
+    _fields_ = [("rho", c_float), ("sigma", c_float), ("alpha", c_float), ("eps_abs", c_float),
+                ("eps_rel", c_float), ("eps_prim_inf", c_float), ("eps_dual_inf", c_float),
+                ("max_iter", c_int), ("check_termination", c_int), ("warm_start", c_int),
+                ("scaling", c_int), ("scaled_termination", c_int), ("adaptive_rho", c_int),
+                ("adaptive_rho_interval", c_int), ("adaptive_rho_tolerance", c_float)]
+
+
+class StageDims(C.Structure):
+    _fields_ = [("N", c_int), ("nx", c_int), ("nu", c_int), ("ny", c_int), ("nt", c_int)]
+
+
+# every symbol include/osqp_rldl_hip.h declares
+EXPORTED = [
+    "init_linsys_solver_hipldl", "solve_linsys_hipldl", "update_linsys_solver_matrices_hipldl",
+    "update_linsys_solver_rho_vec_hipldl", "free_linsys_solver_hipldl",
+    "rldl_batch_init", "rldl_batch_solve", "rldl_batch_update_matrices", "rldl_batch_update_rho_vec",
+    "rldl_batch_free", "rldl_batch_dims", "rldl_batch_export_symbolic", "rldl_batch_export_factor",
+    "rldl_batch_factor_status", "rldl_batch_time_solve",
+    "osqp_batch_set_default_settings", "osqp_batch_setup", "osqp_batch_solve", "osqp_batch_update_lin_cost",
+    "osqp_batch_update_bounds", "osqp_batch_update_rho", "osqp_batch_update_P_A", "osqp_batch_warm_start",
+    "osqp_batch_get", "osqp_batch_linsys", "osqp_batch_time_iteration", "osqp_batch_cleanup",
+    "rldl_batch_init_recursive", "rldl_batch_update_from_stage", "rldl_version",
+    "rldl_symbolic_analyze", "rldl_stage_permutation",
+]
+
+
+def build(force=False):
+    """Compile the host C + gfx950 HIP sources in-tree (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".c", ".h", ".hip"))]
+    srcs.append(os.path.join(PKG_DIR, "..", "include", "osqp_rldl_hip.h"))
+    stale = force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if stale:
+        subprocess.check_call(["make", "-s", "-C", CSRC])
+    return LIB_PATH
+
+
+def _declare(L):
+    PC = C.POINTER(Csc)
+    L.init_linsys_solver_hipldl.argtypes = [C.POINTER(C.POINTER(HipldlSolver)), PC, PC, c_float, FP, c_int]
+    L.init_linsys_solver_hipldl.restype = c_int
+    L.solve_linsys_hipldl.argtypes = [C.POINTER(HipldlSolver), FP]
+    L.solve_linsys_hipldl.restype = c_int
+    L.update_linsys_solver_matrices_hipldl.argtypes = [C.POINTER(HipldlSolver), PC, PC]
+    L.update_linsys_solver_matrices_hipldl.restype = c_int
+    L.update_linsys_solver_rho_vec_hipldl.argtypes = [C.POINTER(HipldlSolver), FP]
+    L.update_linsys_solver_rho_vec_hipldl.restype = c_int
+    L.free_linsys_solver_hipldl.argtypes = [C.POINTER(HipldlSolver)]
+    L.free_linsys_solver_hipldl.restype = None
+
+    L.rldl_batch_init.argtypes = [C.POINTER(VP), c_int, PC, PC, VP, VP, c_float, VP, c_int, IP, VP]
+    L.rldl_batch_init.restype = c_int
+    L.rldl_batch_solve.argtypes = [VP, VP]
+    L.rldl_batch_solve.restype = c_int
+    L.rldl_batch_update_matrices.argtypes = [VP, VP, VP]
+    L.rldl_batch_update_matrices.restype = c_int
+    L.rldl_batch_update_rho_vec.argtypes = [VP, VP, VP]
+    L.rldl_batch_update_rho_vec.restype = c_int
+    L.rldl_batch_free.argtypes = [VP]
+    L.rldl_batch_free.restype = None
+    L.rldl_batch_dims.argtypes = [VP, IP, IP, IP, IP, IP]
+    L.rldl_batch_dims.restype = c_int
+    L.rldl_batch_export_symbolic.argtypes = [VP] + [IP] * 10
+    L.rldl_batch_export_symbolic.restype = c_int
+    L.rldl_batch_export_factor.argtypes = [VP, c_int, FP, FP, FP, FP]
+    L.rldl_batch_export_factor.restype = c_int
+    L.rldl_batch_factor_status.argtypes = [VP, IP]
+    L.rldl_batch_factor_status.restype = c_int
+    L.rldl_batch_time_solve.argtypes = [VP, VP, c_int, FP]
+    L.rldl_batch_time_solve.restype = c_int
+
+    L.osqp_batch_set_default_settings.argtypes = [C.POINTER(OSQPBatchSettings)]
+    L.osqp_batch_set_default_settings.restype = None
+    L.osqp_batch_setup.argtypes = [C.POINTER(VP), c_int, PC, PC, VP, VP, VP, VP, VP, C.POINTER(OSQPBatchSettings), IP, VP]
+    L.osqp_batch_setup.restype = c_int
+    L.osqp_batch_solve.argtypes = [VP]
+    L.osqp_batch_solve.restype = c_int
+    L.osqp_batch_update_lin_cost.argtypes = [VP, VP]
+    L.osqp_batch_update_lin_cost.restype = c_int
+    L.osqp_batch_update_bounds.argtypes = [VP, VP, VP]
+    L.osqp_batch_update_bounds.restype = c_int
+    L.osqp_batch_update_rho.argtypes = [VP, c_float]
+    L.osqp_batch_update_rho.restype = c_int
+    L.osqp_batch_update_P_A.argtypes = [VP, VP, VP]
+    L.osqp_batch_update_P_A.restype = c_int
+    L.osqp_batch_warm_start.argtypes = [VP, VP, VP]
+    L.osqp_batch_warm_start.restype = c_int
+    L.osqp_batch_get.argtypes = [VP] + [C.POINTER(VP)] * 8
+    L.osqp_batch_get.restype = c_int
+    L.osqp_batch_linsys.argtypes = [VP]
+    L.osqp_batch_linsys.restype = VP
+    L.osqp_batch_time_iteration.argtypes = [VP, c_int, FP]
+    L.osqp_batch_time_iteration.restype = c_int
+    L.osqp_batch_cleanup.argtypes = [VP]
+    L.osqp_batch_cleanup.restype = None
+
+    L.rldl_batch_init_recursive.argtypes = [C.POINTER(VP), c_int, C.POINTER(StageDims), PC, PC, VP, VP, c_float, VP, VP]
+    L.rldl_batch_init_recursive.restype = c_int
+    L.rldl_batch_update_from_stage.argtypes = [VP, c_int, VP, VP, VP]
+    L.rldl_batch_update_from_stage.restype = c_int
+    L.rldl_version.argtypes = []
+    L.rldl_version.restype = C.c_char_p
+    L.rldl_stage_permutation.argtypes = [c_int] * 5 + [IP]
+    L.rldl_stage_permutation.restype = None
+    L.rldl_symbolic_analyze.argtypes = [PC, PC, c_int, IP, IP, IP, IP] + [IP] * 10
+    L.rldl_symbolic_analyze.restype = c_int
+    L.rldl_device_available.restype = C.c_int
+
+
+_lib = None
+
+
+def lib():
+    """The loaded C-ABI library.  Raises (never falls back) when the HIP extension is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libosqp_rldl_hip.so is not built (%s); run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C osqp_recursive_ldl_amd/csrc`.  There is no CPU fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        missing = [s for s in EXPORTED if not hasattr(L, s)]
+        if missing:
+            raise RuntimeError("libosqp_rldl_hip.so lacks symbols: %s" % missing)
+        _declare(L)
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc == RLDL_NO_DEVICE_ERROR:
+        raise RuntimeError("%s: no HIP device available (the backend has no CPU fallback)" % what)
+    return rc

@@ -1,0 +1,316 @@
+/*
+ * rldl_admm.c -- host side (plain C) of the batched, device-resident ADMM driver.
+ *
+ * Mirrors src/osqp.c: osqp_set_default_settings :24-71, osqp_setup :76-283, osqp_solve :288-641,
+ * osqp_update_lin_cost :752-790, osqp_update_bounds :792-841, osqp_warm_start :929-948,
+ * osqp_update_P_A :1158-1266, osqp_update_rho :1268-1319, osqp_cleanup :646-744.
+ * The host only sequences kernel launches; every vector lives on the device for the whole solve and
+ * the only device->host traffic inside the loop is one 4-byte "instances still active" counter per
+ * termination check.
+ *
+ * Documented divergences from the reference:
+ *   - scaling (Ruiz equilibration, src/scaling.c) is not built yet: settings->scaling must be 0.
+ *   - adaptive_rho with adaptive_rho_interval == 0 uses the PROFILING-off rule of osqp.c:266-279
+ *     (the shipped default derives the interval from wall-clock time and is not reproducible).
+ *   - polish is out of scope.
+ */
+#include <hip/hip_runtime_api.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/osqp_rldl_hip.h"
+#include "rldl_device.h"
+#include "rldl_internal.h"
+
+#define HIP_OK(call) ((call) == hipSuccess)
+#define ST_UNSOLVED (-10)
+#define RHO_MIN 1e-06
+#define RHO_MAX 1e06
+
+struct osqp_batch {
+  c_int batch, n, m, nnzP, nnzA;
+  OSQPBatchSettings st;
+  rldl_batch *ls;
+  rldl_dev_admm W;
+  double *Px, *Ax, *q, *l, *u;   /* owned device copies of the problem data (osqp.c:106-114) */
+  void *stream;
+  void *ev0, *ev1;
+  int *h_tmp_i;                  /* [batch] host scratch */
+  double *h_tmp_d;               /* [batch] host scratch */
+  float last_loop_ms;
+  c_int last_loop_launches;
+};
+
+void osqp_batch_set_default_settings(OSQPBatchSettings *s) {
+  s->rho = 0.1; s->sigma = 1e-6; s->alpha = 1.6; s->eps_abs = 1e-3; s->eps_rel = 1e-3;
+  s->eps_prim_inf = 1e-4; s->eps_dual_inf = 1e-4; s->max_iter = 4000; s->check_termination = 25;
+  s->warm_start = 1;
+  s->scaling = 0; /* reference default is 10 (constants.h:85); see header comment */
+  s->scaled_termination = 0; s->adaptive_rho = 1; s->adaptive_rho_interval = 0; s->adaptive_rho_tolerance = 5;
+}
+
+static void *dmalloc(size_t bytes, int *ok) {
+  void *d = 0;
+  if (!*ok) return 0;
+  if (!HIP_OK(hipMalloc(&d, bytes ? bytes : 8))) { *ok = 0; return 0; }
+  return d;
+}
+static double *dclone(const double *src, size_t count, void *stream, int *ok) {
+  double *d = (double *)dmalloc(sizeof(double) * count, ok);
+  if (*ok && count && !HIP_OK(hipMemcpyAsync(d, src, sizeof(double) * count, hipMemcpyDeviceToDevice, (hipStream_t)stream))) *ok = 0;
+  return d;
+}
+
+static int fill_int(osqp_batch *w, int *d, int value) {
+  c_int b;
+  for (b = 0; b < w->batch; b++) w->h_tmp_i[b] = value;
+  return HIP_OK(hipMemcpyAsync(d, w->h_tmp_i, sizeof(int) * (size_t)w->batch, hipMemcpyHostToDevice, (hipStream_t)w->stream)) &&
+                 HIP_OK(hipStreamSynchronize((hipStream_t)w->stream)) ? 0 : 1;
+}
+static int fill_double(osqp_batch *w, double *d, double value) {
+  c_int b;
+  for (b = 0; b < w->batch; b++) w->h_tmp_d[b] = value;
+  return HIP_OK(hipMemcpyAsync(d, w->h_tmp_d, sizeof(double) * (size_t)w->batch, hipMemcpyHostToDevice, (hipStream_t)w->stream)) &&
+                 HIP_OK(hipStreamSynchronize((hipStream_t)w->stream)) ? 0 : 1;
+}
+
+static void reset_info(osqp_batch *w) { /* auxil.c:628-645 */
+  (void)fill_int(w, w->W.status, ST_UNSOLVED);
+  (void)hipMemsetAsync(w->W.rho_updates, 0, sizeof(int) * (size_t)w->batch, (hipStream_t)w->stream);
+}
+
+void osqp_batch_cleanup(osqp_batch *w) {
+  if (!w) return;
+  (void)hipStreamSynchronize((hipStream_t)w->stream);
+  rldl_batch_free(w->ls);
+#define FR(p) if (p) (void)hipFree(p)
+  FR(w->Px); FR(w->Ax); FR(w->q); FR(w->l); FR(w->u);
+  FR(w->W.x); FR(w->W.z); FR(w->W.y); FR(w->W.delta_x); FR(w->W.delta_y); FR(w->W.rho_vec); FR(w->W.constr_type);
+  FR(w->W.pri_res); FR(w->W.dua_res); FR(w->W.obj); FR(w->W.rho_cur); FR(w->W.rho_est); FR(w->W.status);
+  FR(w->W.iter); FR(w->W.rho_updates); FR(w->W.refactor); FR(w->W.n_active);
+#undef FR
+  if (w->ev0) (void)hipEventDestroy((hipEvent_t)w->ev0);
+  if (w->ev1) (void)hipEventDestroy((hipEvent_t)w->ev1);
+  free(w->h_tmp_i); free(w->h_tmp_d);
+  free(w);
+}
+
+c_int osqp_batch_setup(osqp_batch **wp, c_int batch, const csc *P, const csc *A, const c_float *d_Px,
+                       const c_float *d_Ax, const c_float *d_q, const c_float *d_l, const c_float *d_u,
+                       const OSQPBatchSettings *settings, const c_int *perm, void *stream) {
+  osqp_batch *w;
+  int ok = 1;
+  c_int rc, n, m;
+  size_t B;
+  *wp = 0;
+  if (!rldl_device_available()) return RLDL_NO_DEVICE_ERROR;
+  if (!P || !A || !settings || batch <= 0) return 1;                /* OSQP_DATA_VALIDATION_ERROR */
+  if (settings->scaling != 0 || settings->rho <= 0 || settings->sigma <= 0 || settings->alpha <= 0 ||
+      settings->alpha >= 2 || settings->max_iter <= 0)
+    return 2;                                                       /* OSQP_SETTINGS_VALIDATION_ERROR */
+  w = (osqp_batch *)calloc(1, sizeof(osqp_batch));
+  if (!w) return RLDL_MEM_ALLOC_ERROR;
+  n = P->n; m = A->m; B = (size_t)batch;
+  w->batch = batch; w->n = n; w->m = m; w->nnzP = P->p[n]; w->nnzA = A->p[n]; w->st = *settings; w->stream = stream;
+  w->st.rho = settings->rho < RHO_MIN ? RHO_MIN : (settings->rho > RHO_MAX ? RHO_MAX : settings->rho);
+  w->h_tmp_i = (int *)calloc(B, sizeof(int)); w->h_tmp_d = (double *)calloc(B, sizeof(double));
+  if (!w->h_tmp_i || !w->h_tmp_d) { osqp_batch_cleanup(w); return RLDL_MEM_ALLOC_ERROR; }
+  w->Px = dclone(d_Px, B * (size_t)w->nnzP, stream, &ok); w->Ax = dclone(d_Ax, B * (size_t)w->nnzA, stream, &ok);
+  w->q = dclone(d_q, B * (size_t)n, stream, &ok); w->l = dclone(d_l, B * (size_t)m, stream, &ok);
+  w->u = dclone(d_u, B * (size_t)m, stream, &ok);
+  w->W.batch = (int)batch;
+  w->W.sigma = w->st.sigma; w->W.alpha = w->st.alpha; w->W.eps_abs = w->st.eps_abs; w->W.eps_rel = w->st.eps_rel;
+  w->W.eps_prim_inf = w->st.eps_prim_inf; w->W.eps_dual_inf = w->st.eps_dual_inf; w->W.rho = w->st.rho;
+  w->W.adaptive_rho_tolerance = w->st.adaptive_rho_tolerance;
+  w->W.Px = w->Px; w->W.Ax = w->Ax; w->W.q = w->q; w->W.l = w->l; w->W.u = w->u;
+  w->W.x = (double *)dmalloc(sizeof(double) * B * (size_t)n, &ok);
+  w->W.z = (double *)dmalloc(sizeof(double) * B * (size_t)m, &ok);
+  w->W.y = (double *)dmalloc(sizeof(double) * B * (size_t)m, &ok);
+  w->W.delta_x = (double *)dmalloc(sizeof(double) * B * (size_t)n, &ok);
+  w->W.delta_y = (double *)dmalloc(sizeof(double) * B * (size_t)m, &ok);
+  w->W.rho_vec = (double *)dmalloc(sizeof(double) * B * (size_t)m, &ok);
+  w->W.constr_type = (int *)dmalloc(sizeof(int) * B * (size_t)m, &ok);
+  w->W.pri_res = (double *)dmalloc(sizeof(double) * B, &ok); w->W.dua_res = (double *)dmalloc(sizeof(double) * B, &ok);
+  w->W.obj = (double *)dmalloc(sizeof(double) * B, &ok); w->W.rho_cur = (double *)dmalloc(sizeof(double) * B, &ok);
+  w->W.rho_est = (double *)dmalloc(sizeof(double) * B, &ok);
+  w->W.status = (int *)dmalloc(sizeof(int) * B, &ok); w->W.iter = (int *)dmalloc(sizeof(int) * B, &ok);
+  w->W.rho_updates = (int *)dmalloc(sizeof(int) * B, &ok); w->W.refactor = (int *)dmalloc(sizeof(int) * B, &ok);
+  w->W.n_active = (int *)dmalloc(sizeof(int), &ok);
+  if (!ok || !HIP_OK(hipEventCreate((hipEvent_t *)&w->ev0)) || !HIP_OK(hipEventCreate((hipEvent_t *)&w->ev1))) {
+    osqp_batch_cleanup(w);
+    return RLDL_MEM_ALLOC_ERROR;
+  }
+  (void)hipMemsetAsync(w->W.x, 0, sizeof(double) * B * (size_t)n, (hipStream_t)stream);
+  (void)hipMemsetAsync(w->W.z, 0, sizeof(double) * B * (size_t)m, (hipStream_t)stream);
+  (void)hipMemsetAsync(w->W.y, 0, sizeof(double) * B * (size_t)m, (hipStream_t)stream);
+  (void)hipMemsetAsync(w->W.delta_x, 0, sizeof(double) * B * (size_t)n, (hipStream_t)stream);
+  (void)hipMemsetAsync(w->W.delta_y, 0, sizeof(double) * B * (size_t)m, (hipStream_t)stream);
+  (void)hipMemsetAsync(w->W.iter, 0, sizeof(int) * B, (hipStream_t)stream);
+  (void)hipMemsetAsync(w->W.pri_res, 0, sizeof(double) * B, (hipStream_t)stream);
+  (void)hipMemsetAsync(w->W.dua_res, 0, sizeof(double) * B, (hipStream_t)stream);
+  (void)hipMemsetAsync(w->W.obj, 0, sizeof(double) * B, (hipStream_t)stream);
+  (void)hipMemsetAsync(w->W.refactor, 0, sizeof(int) * B, (hipStream_t)stream);
+  if (fill_double(w, w->W.rho_cur, w->st.rho) || fill_double(w, w->W.rho_est, w->st.rho)) { osqp_batch_cleanup(w); return RLDL_MEM_ALLOC_ERROR; }
+  reset_info(w);
+
+  /* set_rho_vec (auxil.c:79-101) needs only l, u, rho; the pattern-level symbolic data comes with the backend,
+   * so build a throw-away device view just for this launch AFTER the backend exists.  Order here:
+   * 1) classify rows with a temporary rho_vec, 2) init backend with it (osqp.c:201-209). */
+  {
+    /* k_set_rho_vec only reads S->m from the symbolic struct */
+    rldl_dev_sym tmp;
+    memset(&tmp, 0, sizeof(tmp));
+    tmp.n = (int)n; tmp.m = (int)m; tmp.N = (int)(n + m);
+    if (rldl_launch_set_rho_vec(&tmp, &w->W, 1, stream)) { osqp_batch_cleanup(w); return RLDL_LINSYS_SOLVER_INIT_ERROR; }
+  }
+  rc = rldl_batch_init(&w->ls, batch, P, A, w->Px, w->Ax, w->st.sigma, w->W.rho_vec, 0, perm, stream);
+  if (rc) { osqp_batch_cleanup(w); return rc; }
+  (void)hipMemsetAsync(w->W.refactor, 0, sizeof(int) * B, (hipStream_t)stream);
+  if (w->st.adaptive_rho && !w->st.adaptive_rho_interval) /* osqp.c:266-279 */
+    w->st.adaptive_rho_interval = w->st.check_termination ? 4 * w->st.check_termination : 100;
+  *wp = w;
+  return 0;
+}
+
+static int read_active(osqp_batch *w) {
+  int v = -1;
+  if (!HIP_OK(hipMemcpyAsync(&v, w->W.n_active, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)w->stream))) return -1;
+  if (!HIP_OK(hipStreamSynchronize((hipStream_t)w->stream))) return -1;
+  return v;
+}
+
+c_int osqp_batch_solve(osqp_batch *w) {
+  c_int iter, last_iter = 0, launches = 0;
+  int can_check = 0, nact;
+  size_t B;
+  hipStream_t st;
+  if (!w) return 7; /* OSQP_WORKSPACE_NOT_INIT_ERROR */
+  B = (size_t)w->batch; st = (hipStream_t)w->stream;
+  if (!w->st.warm_start) { /* cold_start, auxil.c:158-162 */
+    (void)hipMemsetAsync(w->W.x, 0, sizeof(double) * B * (size_t)w->n, st);
+    (void)hipMemsetAsync(w->W.z, 0, sizeof(double) * B * (size_t)w->m, st);
+    (void)hipMemsetAsync(w->W.y, 0, sizeof(double) * B * (size_t)w->m, st);
+  }
+  if (fill_int(w, w->W.status, ST_UNSOLVED)) return 1;
+  nact = (int)w->batch;
+  if (!HIP_OK(hipMemcpyAsync(w->W.n_active, &nact, sizeof(int), hipMemcpyHostToDevice, st))) return 1;
+  if (!HIP_OK(hipStreamSynchronize(st))) return 1;
+
+  (void)hipEventRecord((hipEvent_t)w->ev0, st);
+  for (iter = 1; iter <= w->st.max_iter; iter++) {
+    int do_adapt;
+    if (rldl_launch_admm_iter(&w->ls->dsym, &w->ls->num, &w->W, w->stream)) return 1;
+    launches++;
+    last_iter = iter;
+    can_check = w->st.check_termination && (iter % w->st.check_termination == 0);
+    do_adapt = w->st.adaptive_rho && w->st.adaptive_rho_interval && (iter % w->st.adaptive_rho_interval == 0);
+    if (can_check || do_adapt) {
+      if (rldl_launch_admm_check(&w->ls->dsym, &w->W, (int)iter, (can_check ? 1 : 0) | (do_adapt ? 2 : 0), 0, w->stream)) return 1;
+      if (do_adapt) { /* osqp_update_rho -> update_rho_vec -> refactor, only where rho moved */
+        if (rldl_batch_update_rho_vec(w->ls, w->W.rho_vec, w->W.refactor)) return 1;
+        (void)hipMemsetAsync(w->W.refactor, 0, sizeof(int) * B, st);
+      }
+      if (can_check) {
+        nact = read_active(w);
+        if (nact < 0) return 1;
+        if (nact == 0) break;
+      }
+    }
+  }
+  (void)hipEventRecord((hipEvent_t)w->ev1, st);
+  /* tail of osqp_solve (osqp.c:521-633) */
+  if (rldl_launch_admm_check(&w->ls->dsym, &w->W, (int)last_iter, 0, can_check ? 1 : 2, w->stream)) return 1;
+  if (!HIP_OK(hipStreamSynchronize(st))) return 1;
+  (void)hipEventElapsedTime(&w->last_loop_ms, (hipEvent_t)w->ev0, (hipEvent_t)w->ev1);
+  w->last_loop_launches = launches;
+  return 0;
+}
+
+c_int osqp_batch_update_lin_cost(osqp_batch *w, const c_float *d_q) {
+  if (!w || !d_q) return 1;
+  if (!HIP_OK(hipMemcpyAsync(w->q, d_q, sizeof(double) * (size_t)w->batch * (size_t)w->n, hipMemcpyDeviceToDevice, (hipStream_t)w->stream))) return 1;
+  reset_info(w);
+  return 0;
+}
+
+c_int osqp_batch_update_bounds(osqp_batch *w, const c_float *d_l, const c_float *d_u) {
+  size_t cnt;
+  if (!w || !d_l || !d_u) return 1;
+  cnt = sizeof(double) * (size_t)w->batch * (size_t)w->m;
+  if (!HIP_OK(hipMemcpyAsync(w->l, d_l, cnt, hipMemcpyDeviceToDevice, (hipStream_t)w->stream))) return 1;
+  if (!HIP_OK(hipMemcpyAsync(w->u, d_u, cnt, hipMemcpyDeviceToDevice, (hipStream_t)w->stream))) return 1;
+  reset_info(w);
+  /* update_rho_vec (auxil.c:103-145): refactor only instances whose constraint types changed */
+  if (rldl_launch_set_rho_vec(&w->ls->dsym, &w->W, 0, w->stream)) return 1;
+  if (rldl_batch_update_rho_vec(w->ls, w->W.rho_vec, w->W.refactor)) return 1;
+  (void)hipMemsetAsync(w->W.refactor, 0, sizeof(int) * (size_t)w->batch, (hipStream_t)w->stream);
+  return 0;
+}
+
+c_int osqp_batch_update_rho(osqp_batch *w, c_float rho_new) {
+  if (!w) return 7;
+  if (rho_new <= 0) return 1;
+  w->st.rho = rho_new < RHO_MIN ? RHO_MIN : (rho_new > RHO_MAX ? RHO_MAX : rho_new);
+  w->W.rho = w->st.rho;
+  if (fill_double(w, w->W.rho_cur, w->st.rho)) return 1;
+  if (rldl_launch_set_rho_vec(&w->ls->dsym, &w->W, 1, w->stream)) return 1; /* same types, new rho */
+  (void)hipMemsetAsync(w->W.refactor, 0, sizeof(int) * (size_t)w->batch, (hipStream_t)w->stream);
+  return rldl_batch_update_rho_vec(w->ls, w->W.rho_vec, 0);
+}
+
+c_int osqp_batch_update_P_A(osqp_batch *w, const c_float *d_Px, const c_float *d_Ax) {
+  c_int rc;
+  if (!w) return 7;
+  if (d_Px && !HIP_OK(hipMemcpyAsync(w->Px, d_Px, sizeof(double) * (size_t)w->batch * (size_t)w->nnzP, hipMemcpyDeviceToDevice, (hipStream_t)w->stream))) return 1;
+  if (d_Ax && !HIP_OK(hipMemcpyAsync(w->Ax, d_Ax, sizeof(double) * (size_t)w->batch * (size_t)w->nnzA, hipMemcpyDeviceToDevice, (hipStream_t)w->stream))) return 1;
+  rc = rldl_batch_update_matrices(w->ls, d_Px ? w->Px : 0, d_Ax ? w->Ax : 0);
+  reset_info(w);
+  return rc;
+}
+
+c_int osqp_batch_warm_start(osqp_batch *w, const c_float *d_x, const c_float *d_y) {
+  if (!w || !d_x || !d_y) return 1;
+  if (!w->st.warm_start) w->st.warm_start = 1;
+  if (!HIP_OK(hipMemcpyAsync(w->W.x, d_x, sizeof(double) * (size_t)w->batch * (size_t)w->n, hipMemcpyDeviceToDevice, (hipStream_t)w->stream))) return 1;
+  if (!HIP_OK(hipMemcpyAsync(w->W.y, d_y, sizeof(double) * (size_t)w->batch * (size_t)w->m, hipMemcpyDeviceToDevice, (hipStream_t)w->stream))) return 1;
+  return rldl_launch_matvec_A(&w->ls->dsym, &w->W, w->W.x, w->W.z, w->stream) ? 1 : 0; /* z = A x, osqp.c:945 */
+}
+
+c_int osqp_batch_get(osqp_batch *w, c_float **d_x, c_float **d_y, c_float **d_z, int **d_status, int **d_iter,
+                     c_float **d_obj, c_float **d_pri_res, c_float **d_dua_res) {
+  if (!w) return 1;
+  if (d_x) *d_x = w->W.x;
+  if (d_y) *d_y = w->W.y;
+  if (d_z) *d_z = w->W.z;
+  if (d_status) *d_status = w->W.status;
+  if (d_iter) *d_iter = w->W.iter;
+  if (d_obj) *d_obj = w->W.obj;
+  if (d_pri_res) *d_pri_res = w->W.pri_res;
+  if (d_dua_res) *d_dua_res = w->W.dua_res;
+  return 0;
+}
+
+rldl_batch *osqp_batch_linsys(osqp_batch *w) { return w ? w->ls : 0; }
+
+/* Average device time of the fused ADMM-iteration kernel over the last osqp_batch_solve loop when
+ * reps == 0 (valid when no check kernels were interleaved: check_termination = adaptive_rho = 0),
+ * otherwise time `reps` extra launches now (this advances the iterates). */
+c_int osqp_batch_time_iteration(osqp_batch *w, c_int reps, c_float *ms_per_launch) {
+  c_int r;
+  float ms = 0.f;
+  if (!w || !ms_per_launch) return 1;
+  if (reps <= 0) {
+    if (!w->last_loop_launches) return 1;
+    *ms_per_launch = (c_float)w->last_loop_ms / (c_float)w->last_loop_launches;
+    return 0;
+  }
+  if (fill_int(w, w->W.status, ST_UNSOLVED)) return 1;
+  (void)hipEventRecord((hipEvent_t)w->ev0, (hipStream_t)w->stream);
+  for (r = 0; r < reps; r++)
+    if (rldl_launch_admm_iter(&w->ls->dsym, &w->ls->num, &w->W, w->stream)) return 1;
+  (void)hipEventRecord((hipEvent_t)w->ev1, (hipStream_t)w->stream);
+  if (!HIP_OK(hipEventSynchronize((hipEvent_t)w->ev1))) return 1;
+  if (!HIP_OK(hipEventElapsedTime(&ms, (hipEvent_t)w->ev0, (hipEvent_t)w->ev1))) return 1;
+  *ms_per_launch = (c_float)ms / (c_float)reps;
+  return 0;
+}

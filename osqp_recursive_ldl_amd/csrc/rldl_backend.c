@@ -1,0 +1,339 @@
+/*
+ * rldl_backend.c -- host side (plain C) of the batched linear-system backend and the legacy
+ * single-instance plugin object.  Talks to the GPU only through the HIP runtime C API (memory,
+ * streams, events) and the extern "C" launchers of rldl_device.h.
+ *
+ * Mirrors lin_sys/direct/qdldl/qdldl_interface.c: init :170-316, solve :559-585,
+ * update_matrices :590-602, update_rho_vec :605-619, free :17-43.
+ * There is NO CPU fallback: without a HIP device every entry point fails with RLDL_NO_DEVICE_ERROR.
+ */
+#include <hip/hip_runtime_api.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/osqp_rldl_hip.h"
+#include "rldl_device.h"
+#include "rldl_internal.h"
+#include "rldl_symbolic.h"
+
+#define HIP_OK(call) ((call) == hipSuccess)
+
+const char *rldl_version(void) { return "osqp-rldl-hip 0.1 (gfx950)"; }
+
+/* ------------------------------------------------------------------ device pool ---- */
+static void *dev_upload(const void *src, size_t bytes, int *ok) {
+  void *d = 0;
+  if (!*ok) return 0;
+  if (!HIP_OK(hipMalloc(&d, bytes ? bytes : 8))) { *ok = 0; return 0; }
+  if (bytes && !HIP_OK(hipMemcpy(d, src, bytes, hipMemcpyHostToDevice))) { *ok = 0; }
+  return d;
+}
+static void *dev_alloc(size_t bytes, int *ok) {
+  void *d = 0;
+  if (!*ok) return 0;
+  if (!HIP_OK(hipMalloc(&d, bytes ? bytes : 8))) { *ok = 0; return 0; }
+  return d;
+}
+
+int rldl_device_available(void) {
+  int count = 0;
+  if (!HIP_OK(hipGetDeviceCount(&count))) return 0;
+  return count > 0;
+}
+
+static int upload_symbolic(rldl_batch *h) {
+  const rldl_symbolic *s = h->sym;
+  rldl_dev_sym *D = &h->dsym;
+  int ok = 1;
+  memset(D, 0, sizeof(*D));
+  D->n = s->n; D->m = s->m; D->N = s->N; D->nnzP = s->nnzP; D->nnzA = s->nnzA; D->nnzK = s->nnzK;
+  D->nnzL = s->nnzL; D->nsig = s->nsig; D->polish = s->polish;
+#define UP(field, count, type) D->field = (const type *)dev_upload(s->field, sizeof(type) * (size_t)(count), &ok)
+  UP(perm, s->N, int); UP(PtoK, s->nnzP, int); UP(AtoK, s->nnzA, int); UP(rhotoK, s->m, int); UP(sigK, s->nsig, int);
+  UP(Pisdiag, s->nnzP, unsigned char);
+  UP(Lp, s->N + 1, int); UP(Li, s->nnzL, int); UP(Rp, s->N + 1, int); UP(Rj, s->nnzL, int); UP(Rpos, s->nnzL, int);
+  UP(KtoW, s->nnzK, int); UP(Udst, s->npairs, int); UP(Uab, s->npairs, unsigned int); UP(Up, s->N + 1, long long);
+  UP(Pp, s->n + 1, int); UP(Pi, s->nnzP, int); UP(Prp, s->n + 1, int); UP(Prj, s->nnzP, int); UP(Prpos, s->nnzP, int);
+  UP(Ap, s->n + 1, int); UP(Ai, s->nnzA, int); UP(Arp, s->m + 1, int); UP(Arj, s->nnzA, int); UP(Arpos, s->nnzA, int);
+#undef UP
+  return ok ? 0 : -1;
+}
+
+static void free_dev_symbolic(rldl_dev_sym *D) {
+#define FR(f) if (D->f) (void)hipFree((void *)D->f)
+  FR(perm); FR(PtoK); FR(AtoK); FR(rhotoK); FR(sigK); FR(Pisdiag); FR(Lp); FR(Li); FR(Rp); FR(Rj); FR(Rpos);
+  FR(KtoW); FR(Udst); FR(Uab); FR(Up); FR(Pp); FR(Pi); FR(Prp); FR(Prj); FR(Prpos); FR(Ap); FR(Ai); FR(Arp);
+  FR(Arj); FR(Arpos);
+#undef FR
+  memset(D, 0, sizeof(*D));
+}
+
+void rldl_batch_free(rldl_batch *h) {
+  if (!h) return;
+  if (h->stream_owned && h->stream) (void)hipStreamSynchronize((hipStream_t)h->stream);
+  free_dev_symbolic(&h->dsym);
+  if (h->num.Kx) (void)hipFree(h->num.Kx);
+  if (h->num.LD) (void)hipFree(h->num.LD);
+  if (h->num.Dinv) (void)hipFree(h->num.Dinv);
+  if (h->num.rho_inv) (void)hipFree(h->num.rho_inv);
+  if (h->num.status) (void)hipFree(h->num.status);
+  if (h->ev0) (void)hipEventDestroy((hipEvent_t)h->ev0);
+  if (h->ev1) (void)hipEventDestroy((hipEvent_t)h->ev1);
+  rldl_symbolic_free(h->sym);
+  free(h->status_host);
+  free(h);
+}
+
+/* numeric factor of every (masked) instance + host-side verdict, qdldl_interface.c:80-92 */
+static c_int collect_status(rldl_batch *h) {
+  c_int b, bad = 0;
+  if (!HIP_OK(hipMemcpyAsync(h->status_host, h->num.status, sizeof(int) * (size_t)h->batch, hipMemcpyDeviceToHost,
+                             (hipStream_t)h->stream)))
+    return RLDL_LINSYS_SOLVER_INIT_ERROR;
+  if (!HIP_OK(hipStreamSynchronize((hipStream_t)h->stream))) return RLDL_LINSYS_SOLVER_INIT_ERROR;
+  for (b = 0; b < h->batch; b++)
+    if (h->status_host[b] < 0 || h->status_host[b] < h->sym->n) bad = 1;
+  return bad ? RLDL_NONCVX_ERROR : 0;
+}
+
+static c_int factor_and_check(rldl_batch *h, const int *d_mask) {
+  if (rldl_launch_factor(&h->dsym, &h->num, d_mask, h->stream)) return RLDL_LINSYS_SOLVER_INIT_ERROR;
+  return collect_status(h);
+}
+
+c_int rldl_batch_check_status(rldl_batch *h) { return collect_status(h) ? 1 : 0; }
+
+static c_int batch_create(rldl_batch **hp, c_int batch, const csc *P, const csc *A, c_float sigma, c_int polish,
+                          const c_int *perm, void *stream) {
+  rldl_batch *h;
+  int rc, ok = 1;
+  *hp = 0;
+  if (!rldl_device_available()) return RLDL_NO_DEVICE_ERROR;
+  if (!P || !A || batch <= 0 || P->n != A->n || P->m != P->n) return RLDL_LINSYS_SOLVER_INIT_ERROR;
+  h = (rldl_batch *)calloc(1, sizeof(rldl_batch));
+  if (!h) return RLDL_MEM_ALLOC_ERROR;
+  h->batch = batch; h->stream = stream;
+  rc = rldl_symbolic_create(&h->sym, P->n, A->m, P->p, P->i, A->p, A->i, polish != 0, perm);
+  if (rc) { free(h); return rc == -2 ? RLDL_MEM_ALLOC_ERROR : RLDL_LINSYS_SOLVER_INIT_ERROR; }
+  if (upload_symbolic(h)) { rldl_batch_free(h); return RLDL_MEM_ALLOC_ERROR; }
+  h->num.batch = (int)batch; h->num.sigma = sigma;
+  h->num.Kx = (double *)dev_alloc(sizeof(double) * (size_t)batch * (size_t)h->sym->nnzK, &ok);
+  h->num.LD = (double *)dev_alloc(sizeof(double) * (size_t)batch * (size_t)(h->sym->nnzL + h->sym->N), &ok);
+  h->num.Dinv = (double *)dev_alloc(sizeof(double) * (size_t)batch * (size_t)h->sym->N, &ok);
+  h->num.rho_inv = (double *)dev_alloc(sizeof(double) * (size_t)batch * (size_t)h->sym->m, &ok);
+  h->num.status = (int *)dev_alloc(sizeof(int) * (size_t)batch, &ok);
+  h->status_host = (int *)calloc((size_t)batch, sizeof(int));
+  if (!ok || !h->status_host) { rldl_batch_free(h); return RLDL_MEM_ALLOC_ERROR; }
+  if (!HIP_OK(hipEventCreate((hipEvent_t *)&h->ev0)) || !HIP_OK(hipEventCreate((hipEvent_t *)&h->ev1))) {
+    rldl_batch_free(h);
+    return RLDL_MEM_ALLOC_ERROR;
+  }
+  *hp = h;
+  return 0;
+}
+
+c_int rldl_batch_init(rldl_batch **hp, c_int batch, const csc *P, const csc *A, const c_float *d_Px,
+                      const c_float *d_Ax, c_float sigma, const c_float *d_rho_vec, c_int polish, const c_int *perm,
+                      void *stream) {
+  rldl_batch *h;
+  c_int rc = batch_create(&h, batch, P, A, sigma, polish, perm, stream);
+  if (hp) *hp = 0;
+  if (rc) return rc;
+  if (!polish && !d_rho_vec && A->m > 0) { rldl_batch_free(h); return RLDL_LINSYS_SOLVER_INIT_ERROR; }
+  if (rldl_launch_kkt_assemble(&h->dsym, &h->num, d_Px, d_Ax, polish ? 0 : d_rho_vec, 1, 0, stream)) {
+    rldl_batch_free(h);
+    return RLDL_LINSYS_SOLVER_INIT_ERROR;
+  }
+  rc = factor_and_check(h, 0);
+  if (rc) { /* qdldl_interface.c:298-303: free, *sp = NULL, error code */
+    rldl_batch_free(h);
+    return rc;
+  }
+  *hp = h;
+  return 0;
+}
+
+c_int rldl_batch_solve(rldl_batch *h, c_float *d_b) {
+  if (!h || !d_b) return 1;
+  return rldl_launch_solve(&h->dsym, &h->num, d_b, h->stream) ? 1 : 0;
+}
+
+c_int rldl_batch_update_matrices(rldl_batch *h, const c_float *d_Px, const c_float *d_Ax) {
+  if (!h || h->sym->polish) return 1;
+  if (rldl_launch_kkt_assemble(&h->dsym, &h->num, d_Px, d_Ax, 0, 0, 0, h->stream)) return 1;
+  return factor_and_check(h, 0) ? 1 : 0; /* reference returns (QDLDL_factor < 0), :598-600 */
+}
+
+c_int rldl_batch_update_rho_vec(rldl_batch *h, const c_float *d_rho_vec, const int *d_mask) {
+  if (!h || (!d_rho_vec && h->sym->m > 0) || h->sym->polish) return 1;
+  if (rldl_launch_kkt_assemble(&h->dsym, &h->num, 0, 0, d_rho_vec, 0, d_mask, h->stream)) return 1;
+  if (d_mask) { /* asynchronous masked refactor: status is collected by the caller when it needs it */
+    return rldl_launch_factor(&h->dsym, &h->num, d_mask, h->stream) ? 1 : 0;
+  }
+  return factor_and_check(h, 0) ? 1 : 0;
+}
+
+c_int rldl_batch_dims(const rldl_batch *h, c_int *n, c_int *m, c_int *nnzKKT, c_int *nnzL, c_int *batch) {
+  if (!h) return 1;
+  if (n) *n = h->sym->n;
+  if (m) *m = h->sym->m;
+  if (nnzKKT) *nnzKKT = h->sym->nnzK;
+  if (nnzL) *nnzL = h->sym->nnzL;
+  if (batch) *batch = h->batch;
+  return 0;
+}
+
+static void copy_i2ll(c_int *dst, const int *src, size_t cnt) {
+  size_t i;
+  if (!dst) return;
+  for (i = 0; i < cnt; i++) dst[i] = src[i];
+}
+
+static void export_sym(const rldl_symbolic *s, c_int *perm, c_int *etree, c_int *Lnz, c_int *Lp, c_int *Li, c_int *KKTp,
+                       c_int *KKTi, c_int *PtoKKT, c_int *AtoKKT, c_int *rhotoKKT) {
+  copy_i2ll(perm, s->perm, (size_t)s->N); copy_i2ll(etree, s->etree, (size_t)s->N);
+  copy_i2ll(Lnz, s->Lnz, (size_t)s->N); copy_i2ll(Lp, s->Lp, (size_t)s->N + 1);
+  copy_i2ll(Li, s->Li, (size_t)s->nnzL); copy_i2ll(KKTp, s->Kp, (size_t)s->N + 1);
+  copy_i2ll(KKTi, s->Ki, (size_t)s->nnzK); copy_i2ll(PtoKKT, s->PtoK, (size_t)s->nnzP);
+  copy_i2ll(AtoKKT, s->AtoK, (size_t)s->nnzA); copy_i2ll(rhotoKKT, s->rhotoK, (size_t)s->m);
+}
+
+c_int rldl_symbolic_analyze(const csc *P, const csc *A, c_int polish, const c_int *perm_in, c_int *nnzKKT,
+                            c_int *nnzL, c_int *etree_height, c_int *perm, c_int *etree, c_int *Lnz, c_int *Lp,
+                            c_int *Li, c_int *KKTp, c_int *KKTi, c_int *PtoKKT, c_int *AtoKKT, c_int *rhotoKKT) {
+  rldl_symbolic *s = 0;
+  if (!P || !A || P->n != A->n || P->m != P->n) return RLDL_LINSYS_SOLVER_INIT_ERROR;
+  if (rldl_symbolic_create(&s, P->n, A->m, P->p, P->i, A->p, A->i, polish != 0, perm_in)) return RLDL_LINSYS_SOLVER_INIT_ERROR;
+  if (nnzKKT) *nnzKKT = s->nnzK;
+  if (nnzL) *nnzL = s->nnzL;
+  if (etree_height) *etree_height = s->etree_height;
+  export_sym(s, perm, etree, Lnz, Lp, Li, KKTp, KKTi, PtoKKT, AtoKKT, rhotoKKT);
+  rldl_symbolic_free(s);
+  return 0;
+}
+
+c_int rldl_batch_export_symbolic(const rldl_batch *h, c_int *perm, c_int *etree, c_int *Lnz, c_int *Lp, c_int *Li,
+                                 c_int *KKTp, c_int *KKTi, c_int *PtoKKT, c_int *AtoKKT, c_int *rhotoKKT) {
+  const rldl_symbolic *s;
+  if (!h) return 1;
+  s = h->sym;
+  export_sym(s, perm, etree, Lnz, Lp, Li, KKTp, KKTi, PtoKKT, AtoKKT, rhotoKKT);
+  return 0;
+}
+
+c_int rldl_batch_export_factor(const rldl_batch *h, c_int inst, c_float *Lx, c_float *D, c_float *Dinv, c_float *KKTx) {
+  const rldl_symbolic *s;
+  size_t nW;
+  if (!h || inst < 0 || inst >= h->batch) return 1;
+  s = h->sym;
+  nW = (size_t)(s->nnzL + s->N);
+  if (!HIP_OK(hipStreamSynchronize((hipStream_t)h->stream))) return 1;
+  if (Lx && s->nnzL && !HIP_OK(hipMemcpy(Lx, h->num.LD + (size_t)inst * nW, sizeof(double) * (size_t)s->nnzL, hipMemcpyDeviceToHost))) return 1;
+  if (D && !HIP_OK(hipMemcpy(D, h->num.LD + (size_t)inst * nW + s->nnzL, sizeof(double) * (size_t)s->N, hipMemcpyDeviceToHost))) return 1;
+  if (Dinv && !HIP_OK(hipMemcpy(Dinv, h->num.Dinv + (size_t)inst * s->N, sizeof(double) * (size_t)s->N, hipMemcpyDeviceToHost))) return 1;
+  if (KKTx && !HIP_OK(hipMemcpy(KKTx, h->num.Kx + (size_t)inst * s->nnzK, sizeof(double) * (size_t)s->nnzK, hipMemcpyDeviceToHost))) return 1;
+  return 0;
+}
+
+c_int rldl_batch_factor_status(const rldl_batch *h, c_int *status) {
+  c_int b;
+  if (!h || !status) return 1;
+  if (!HIP_OK(hipStreamSynchronize((hipStream_t)h->stream))) return 1;
+  if (!HIP_OK(hipMemcpy(h->status_host, h->num.status, sizeof(int) * (size_t)h->batch, hipMemcpyDeviceToHost))) return 1;
+  for (b = 0; b < h->batch; b++) status[b] = h->status_host[b];
+  return 0;
+}
+
+c_int rldl_batch_time_solve(rldl_batch *h, c_float *d_b, c_int reps, c_float *ms_per_launch) {
+  c_int r;
+  float ms = 0.f;
+  if (!h || !d_b || reps <= 0) return 1;
+  if (!HIP_OK(hipEventRecord((hipEvent_t)h->ev0, (hipStream_t)h->stream))) return 1;
+  for (r = 0; r < reps; r++)
+    if (rldl_launch_solve(&h->dsym, &h->num, d_b, h->stream)) return 1;
+  if (!HIP_OK(hipEventRecord((hipEvent_t)h->ev1, (hipStream_t)h->stream))) return 1;
+  if (!HIP_OK(hipEventSynchronize((hipEvent_t)h->ev1))) return 1;
+  if (!HIP_OK(hipEventElapsedTime(&ms, (hipEvent_t)h->ev0, (hipEvent_t)h->ev1))) return 1;
+  if (ms_per_launch) *ms_per_launch = (c_float)ms / (c_float)reps;
+  return 0;
+}
+
+/* =====================================================================================
+ * Legacy single-instance plugin: a batch of one with host<->device staging per call.
+ * ===================================================================================== */
+typedef struct {
+  rldl_batch *batch;
+  c_int n, m, nnzP, nnzA;
+  double *d_Px, *d_Ax, *d_rho, *d_b;
+} hipldl_impl;
+
+static void legacy_free_impl(hipldl_impl *im) {
+  if (!im) return;
+  rldl_batch_free(im->batch);
+  if (im->d_Px) (void)hipFree(im->d_Px);
+  if (im->d_Ax) (void)hipFree(im->d_Ax);
+  if (im->d_rho) (void)hipFree(im->d_rho);
+  if (im->d_b) (void)hipFree(im->d_b);
+  free(im);
+}
+
+void free_linsys_solver_hipldl(hipldl_solver *s) {
+  if (!s) return;
+  legacy_free_impl((hipldl_impl *)s->impl);
+  free(s);
+}
+
+c_int solve_linsys_hipldl(hipldl_solver *s, c_float *b) {
+  hipldl_impl *im = (hipldl_impl *)s->impl;
+  size_t bytes = sizeof(double) * (size_t)(im->n + im->m);
+  if (!HIP_OK(hipMemcpy(im->d_b, b, bytes, hipMemcpyHostToDevice))) return 1;
+  if (rldl_batch_solve(im->batch, im->d_b)) return 1;
+  if (!HIP_OK(hipStreamSynchronize((hipStream_t)im->batch->stream))) return 1;
+  if (!HIP_OK(hipMemcpy(b, im->d_b, bytes, hipMemcpyDeviceToHost))) return 1;
+  return 0;
+}
+
+c_int update_linsys_solver_matrices_hipldl(hipldl_solver *s, const csc *P, const csc *A) {
+  hipldl_impl *im = (hipldl_impl *)s->impl;
+  if (im->nnzP && !HIP_OK(hipMemcpy(im->d_Px, P->x, sizeof(double) * (size_t)im->nnzP, hipMemcpyHostToDevice))) return 1;
+  if (im->nnzA && !HIP_OK(hipMemcpy(im->d_Ax, A->x, sizeof(double) * (size_t)im->nnzA, hipMemcpyHostToDevice))) return 1;
+  return rldl_batch_update_matrices(im->batch, im->d_Px, im->d_Ax);
+}
+
+c_int update_linsys_solver_rho_vec_hipldl(hipldl_solver *s, const c_float *rho_vec) {
+  hipldl_impl *im = (hipldl_impl *)s->impl;
+  if (im->m && !HIP_OK(hipMemcpy(im->d_rho, rho_vec, sizeof(double) * (size_t)im->m, hipMemcpyHostToDevice))) return 1;
+  return rldl_batch_update_rho_vec(im->batch, im->d_rho, 0);
+}
+
+c_int init_linsys_solver_hipldl(hipldl_solver **sp, const csc *P, const csc *A, c_float sigma, const c_float *rho_vec,
+                                c_int polish) {
+  hipldl_solver *s;
+  hipldl_impl *im;
+  int ok = 1;
+  c_int rc;
+  *sp = 0;
+  if (!rldl_device_available()) return RLDL_NO_DEVICE_ERROR;
+  s = (hipldl_solver *)calloc(1, sizeof(hipldl_solver));
+  im = (hipldl_impl *)calloc(1, sizeof(hipldl_impl));
+  if (!s || !im) { free(s); free(im); return RLDL_MEM_ALLOC_ERROR; }
+  s->type = HIP_LDL_SOLVER;
+  s->solve = &solve_linsys_hipldl;
+  s->free = &free_linsys_solver_hipldl;
+  s->update_matrices = &update_linsys_solver_matrices_hipldl;
+  s->update_rho_vec = &update_linsys_solver_rho_vec_hipldl;
+  s->nthreads = 1;
+  s->impl = im;
+  im->n = P->n; im->m = A->m; im->nnzP = P->p[P->n]; im->nnzA = A->p[A->n];
+  im->d_Px = (double *)dev_upload(P->x, sizeof(double) * (size_t)im->nnzP, &ok);
+  im->d_Ax = (double *)dev_upload(A->x, sizeof(double) * (size_t)im->nnzA, &ok);
+  im->d_rho = polish ? (double *)dev_alloc(sizeof(double) * (size_t)im->m, &ok)
+                     : (double *)dev_upload(rho_vec, sizeof(double) * (size_t)im->m, &ok);
+  im->d_b = (double *)dev_alloc(sizeof(double) * (size_t)(im->n + im->m), &ok);
+  if (!ok) { free_linsys_solver_hipldl(s); return RLDL_MEM_ALLOC_ERROR; }
+  rc = rldl_batch_init(&im->batch, 1, P, A, im->d_Px, im->d_Ax, sigma, polish ? 0 : im->d_rho, polish, 0, 0);
+  if (rc) { free_linsys_solver_hipldl(s); return rc; }
+  *sp = s;
+  return 0;
+}

@@ -1,0 +1,70 @@
+/*
+ * rldl_device.h -- the thin C boundary between the plain-C host code and the HIP kernels.
+ *
+ * Everything below is `extern "C"`, takes plain pointers/sizes, and only ENQUEUES work on the given
+ * stream (no allocation, no synchronisation), so a caller may capture the launchers in a hipGraph.
+ */
+#ifndef RLDL_DEVICE_H
+#define RLDL_DEVICE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* device-resident copy of rldl_symbolic (all pointers are DEVICE pointers) */
+typedef struct {
+  int n, m, N, nnzP, nnzA, nnzK, nnzL, nsig, polish;
+  const int *perm, *PtoK, *AtoK, *rhotoK, *sigK;
+  const unsigned char *Pisdiag;
+  const int *Lp, *Li, *Rp, *Rj, *Rpos, *KtoW, *Udst;
+  const unsigned int *Uab;
+  const long long *Up;
+  const int *Pp, *Pi, *Prp, *Prj, *Prpos, *Ap, *Ai, *Arp, *Arj, *Arpos;
+} rldl_dev_sym;
+
+/* per-batch numeric state of the linear-system backend (DEVICE pointers, instance-major) */
+typedef struct {
+  int batch;
+  double sigma;
+  double *Kx;       /* [batch][nnzK]   permuted KKT values                     */
+  double *LD;       /* [batch][nnzL+N] L values (CSC order) followed by D      */
+  double *Dinv;     /* [batch][N]                                              */
+  double *rho_inv;  /* [batch][m]      param2 of the KKT (delta when polishing) */
+  int *status;      /* [batch]         #positive pivots, or -1 on a zero pivot */
+} rldl_dev_num;
+
+/* ADMM iterate state (DEVICE pointers, instance-major) + scalar settings */
+typedef struct {
+  int batch;
+  double sigma, alpha, eps_abs, eps_rel, eps_prim_inf, eps_dual_inf, rho, adaptive_rho_tolerance;
+  const double *Px, *Ax, *q, *l, *u;
+  double *x, *z, *y, *delta_x, *delta_y, *rho_vec;
+  int *constr_type;
+  double *pri_res, *dua_res, *obj, *rho_cur, *rho_est; /* [batch] */
+  int *status, *iter, *rho_updates;                    /* [batch] */
+  int *refactor;                                       /* [batch] mask written by the adapt-rho step */
+  int *n_active;                                       /* [1] instances still iterating */
+} rldl_dev_admm;
+
+/* shared-memory footprint (bytes) of the LDS-resident variants; the launchers pick the global-memory
+ * variant by themselves when this exceeds RLDL_LDS_LIMIT */
+#define RLDL_LDS_LIMIT (64 * 1024)
+
+int rldl_launch_kkt_assemble(const rldl_dev_sym *S, const rldl_dev_num *Nn, const double *d_Px, const double *d_Ax,
+                             const double *d_rho_vec, int set_sigma_only, const int *d_mask, void *stream);
+int rldl_launch_factor(const rldl_dev_sym *S, const rldl_dev_num *Nn, const int *d_mask, void *stream);
+int rldl_launch_factor_from(const rldl_dev_sym *S, const rldl_dev_num *Nn, int c_start, void *stream);
+int rldl_launch_solve(const rldl_dev_sym *S, const rldl_dev_num *Nn, double *d_b, void *stream);
+int rldl_launch_admm_iter(const rldl_dev_sym *S, const rldl_dev_num *Nn, const rldl_dev_admm *W, void *stream);
+int rldl_launch_admm_check(const rldl_dev_sym *S, const rldl_dev_admm *W, int iter, int approximate, int final_pass,
+                           void *stream);
+int rldl_launch_admm_adapt_rho(const rldl_dev_sym *S, const rldl_dev_admm *W, void *stream);
+int rldl_launch_set_rho_vec(const rldl_dev_sym *S, const rldl_dev_admm *W, int init, void *stream);
+int rldl_launch_finalize(const rldl_dev_sym *S, const rldl_dev_admm *W, int max_iter, void *stream);
+int rldl_launch_matvec_A(const rldl_dev_sym *S, const rldl_dev_admm *W, const double *d_x, double *d_out, void *stream);
+const char *rldl_kernel_arch(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,613 @@
+// rldl_kernels.hip -- hand-written gfx950 (CDNA4) kernels of the batched direct KKT backend.
+//
+// Execution model: ONE 64-lane wavefront owns ONE QP instance (workgroup = 1 wave), so every
+// cross-lane dependency is resolved inside a wave (LDS is in-order per wave) and the batch dimension
+// supplies the parallelism: batch=4096 -> 4096 workgroups = 16 waves per CU on 256 CUs.
+// Per-instance value arrays are instance-major and contiguous, so a wave's loads are fully coalesced
+// 512-byte rows; all index arrays describe the shared sparsity pattern and stay L2-resident.
+//
+// Kernels and the reference code each one replaces:
+//   k_kkt_assemble : update_KKT_P/A/param2            src/kkt.c:184-222  (+ rho_inv = 1/rho, qdldl_interface.c:609-611)
+//   k_factor       : QDLDL_factor (numeric LDL')       call sites qdldl_interface.c:74-77, :598-600, :616-618
+//   k_solve        : permute_x, QDLDL_solve, permutet_x, z-tilde epilogue   qdldl_interface.c:538-585
+//   k_admm_iter    : compute_rhs, solve, update_x, update_z+project, update_y   src/auxil.c:164-228, src/proj.c:4-14
+//   k_admm_check   : update_info, check_termination, adapt_rho   src/auxil.c:13-77, :243-515, :567-626, :684-789
+//   k_set_rho_vec  : set_rho_vec / update_rho_vec      src/auxil.c:79-145
+//   k_finalize     : tail of osqp_solve                src/osqp.c:541-641, store_solution src/auxil.c:527-565
+#include <hip/hip_runtime.h>
+
+#include "rldl_device.h"
+
+#define WAVE 64
+
+#define OSQP_INFTY 1e30
+#define OSQP_NAN_VALUE 2143289344.0 /* (c_float)0x7fc00000UL, include/constants.h:96 (sic) */
+#define MIN_SCALING 1e-04
+#define RHO_MIN 1e-06
+#define RHO_MAX 1e06
+#define RHO_TOL 1e-04
+#define RHO_EQ_OVER_RHO_INEQ 1e03
+
+#define ST_SOLVED 1
+#define ST_SOLVED_INACCURATE 2
+#define ST_PRIMAL_INFEASIBLE_INACCURATE 3
+#define ST_DUAL_INFEASIBLE_INACCURATE 4
+#define ST_MAX_ITER_REACHED (-2)
+#define ST_PRIMAL_INFEASIBLE (-3)
+#define ST_DUAL_INFEASIBLE (-4)
+#define ST_NON_CVX (-7)
+#define ST_UNSOLVED (-10)
+
+namespace {
+
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { double t = __shfl_xor(v, o); v = t > v ? t : v; }
+  return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ int wave_any(int p) { return __any(p); }
+
+// ------------------------------------------------------------------------------------------------
+// KKT value scatter: Kx[PtoK[i]] = Px[i] (+sigma on the diagonal), Kx[AtoK[i]] = Ax[i],
+// Kx[rhotoK[j]] = -1/rho[j], sigma-only slots.  One workgroup of 256 threads per instance.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_kkt_assemble(rldl_dev_sym S, rldl_dev_num Nn, const double *__restrict__ Px,
+                                                      const double *__restrict__ Ax, const double *__restrict__ rho_vec,
+                                                      int set_sigma_only, const int *__restrict__ mask) {
+  const int inst = blockIdx.x;
+  if (mask && !mask[inst]) return;
+  double *K = Nn.Kx + (size_t)inst * S.nnzK;
+  if (Px) {
+    const double *p = Px + (size_t)inst * S.nnzP;
+    for (int i = threadIdx.x; i < S.nnzP; i += blockDim.x) K[S.PtoK[i]] = p[i] + (S.Pisdiag[i] ? Nn.sigma : 0.0);
+  }
+  if (Ax) {
+    const double *a = Ax + (size_t)inst * S.nnzA;
+    for (int i = threadIdx.x; i < S.nnzA; i += blockDim.x) K[S.AtoK[i]] = a[i];
+  }
+  if (set_sigma_only)
+    for (int i = threadIdx.x; i < S.nsig; i += blockDim.x) K[S.sigK[i]] = Nn.sigma;
+  if (rho_vec || S.polish) {
+    double *ri = Nn.rho_inv + (size_t)inst * S.m;
+    for (int j = threadIdx.x; j < S.m; j += blockDim.x) {
+      // polish: param2 = delta (= sigma) for every row, qdldl_interface.c:254-258
+      double v = S.polish ? Nn.sigma : 1.0 / rho_vec[(size_t)inst * S.m + j];
+      ri[j] = v;
+      K[S.rhotoK[j]] = -v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Numeric LDL' (right-looking, one wave per instance).  Workspace W = [L (CSC order) | D] lives in
+// LDS (USE_LDS) or directly in the output array.  Column j: d = D[j]; every pair (a >= b) of the
+// column's entries updates one later slot W[dst] -= w_a * w_b / d (dst precomputed on the host, all
+// distinct inside a column -> no atomics), then the column is scaled by 1/d.
+// Returns the QDLDL_factor contract: status = #positive pivots, or -1 on a zero pivot.
+// ------------------------------------------------------------------------------------------------
+template <bool USE_LDS>
+__global__ __launch_bounds__(WAVE) void k_factor(rldl_dev_sym S, rldl_dev_num Nn, const int *__restrict__ mask, int c_start) {
+  const int inst = blockIdx.x;
+  if (mask && !mask[inst]) return;
+  extern __shared__ double sh[];
+  const int lane = threadIdx.x;
+  const int nW = S.nnzL + S.N;
+  double *out = Nn.LD + (size_t)inst * nW;
+  double *W = USE_LDS ? sh : out;
+  const double *K = Nn.Kx + (size_t)inst * S.nnzK;
+  int npos = 0, bad = 0;
+
+  if (c_start <= 0) {
+    for (int i = lane; i < nW; i += WAVE) W[i] = 0.0;
+    __syncthreads();
+    for (int k = lane; k < S.nnzK; k += WAVE) W[S.KtoW[k]] = K[k];
+    __syncthreads();
+  } else {
+    // Restart (LDL_update_from_pivot semantics, src/recursive_ldl.c:946-1110): columns < c_start keep
+    // their L and D; the trailing part is rebuilt from the KKT values plus the replayed contributions
+    // of the kept columns.
+    const int l0 = S.Lp[c_start];
+    if (USE_LDS) for (int i = lane; i < nW; i += WAVE) W[i] = out[i];
+    __syncthreads();
+    for (int i = l0 + lane; i < S.nnzL; i += WAVE) W[i] = 0.0;
+    for (int j = c_start + lane; j < S.N; j += WAVE) W[S.nnzL + j] = 0.0;
+    __syncthreads();
+    for (int k = lane; k < S.nnzK; k += WAVE) {
+      const int w = S.KtoW[k];
+      if ((w >= l0 && w < S.nnzL) || w >= S.nnzL + c_start) W[w] = K[k];
+    }
+    __syncthreads();
+    for (int c = 0; c < c_start; c++) {
+      const double d = W[S.nnzL + c];
+      if (d > 0.0) npos++;
+      const int base = S.Lp[c], cnt = S.Lp[c + 1] - base;
+      if (cnt == 0 || S.Li[base + cnt - 1] < c_start) continue;   // column does not reach the trailing part
+      const long long t0 = S.Up[c], t1 = S.Up[c + 1];
+      for (long long t = t0 + lane; t < t1; t += WAVE) {
+        const int dst = S.Udst[t];
+        if ((dst >= l0 && dst < S.nnzL) || dst >= S.nnzL + c_start) {
+          const unsigned ab = S.Uab[t];
+          W[dst] -= W[base + (ab & 0xffffu)] * (W[base + (ab >> 16)] * d);   // stored L is already scaled by 1/d
+        }
+      }
+      __syncthreads();
+    }
+  }
+
+  for (int j = c_start > 0 ? c_start : 0; j < S.N; j++) {
+    const double d = W[S.nnzL + j];
+    if (d == 0.0) { bad = 1; break; }
+    if (d > 0.0) npos++;
+    const int base = S.Lp[j], c = S.Lp[j + 1] - base;
+    if (c == 0) continue;
+    const double dinv = 1.0 / d;
+    const long long t0 = S.Up[j], t1 = S.Up[j + 1];
+    for (long long t = t0 + lane; t < t1; t += WAVE) {
+      const unsigned ab = S.Uab[t];
+      const double wa = W[base + (ab & 0xffffu)], wb = W[base + (ab >> 16)];
+      W[S.Udst[t]] -= wa * (wb * dinv);
+    }
+    __syncthreads();
+    for (int a = lane; a < c; a += WAVE) W[base + a] *= dinv;
+    // no barrier needed: later columns never read column j again (only the write-out below does)
+  }
+  __syncthreads();
+  if (USE_LDS)
+    for (int i = lane; i < nW; i += WAVE) out[i] = W[i];
+  double *Dinv = Nn.Dinv + (size_t)inst * S.N;
+  for (int j = lane; j < S.N; j += WAVE) Dinv[j] = 1.0 / W[S.nnzL + j];
+  if (lane == 0) Nn.status[inst] = bad ? -1 : npos;
+}
+
+// ------------------------------------------------------------------------------------------------
+// x <- L^-T D^-1 L^-1 x for one instance; xs[N] in LDS, Lv = L values (LDS copy or global).
+// Forward: column sweep (lanes over the entries of column j).  Backward: the same axpy form on L'
+// using the row-order access (Rp/Rj/Rpos), so neither sweep needs a cross-lane reduction.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void tri_solve(const rldl_dev_sym &S, const double *Lv, const double *__restrict__ Dinv,
+                                          double *xs, int lane) {
+  for (int j = 0; j < S.N; j++) {
+    const int base = S.Lp[j], c = S.Lp[j + 1] - base;
+    if (c == 0) continue;
+    const double xj = xs[j];
+    for (int a = lane; a < c; a += WAVE) xs[S.Li[base + a]] -= Lv[base + a] * xj;
+    __syncthreads();
+  }
+  for (int j = lane; j < S.N; j += WAVE) xs[j] *= Dinv[j];
+  __syncthreads();
+  for (int i = S.N - 1; i >= 0; i--) {
+    const int base = S.Rp[i], c = S.Rp[i + 1] - base;
+    if (c == 0) continue;
+    const double xi = xs[i];
+    for (int a = lane; a < c; a += WAVE) xs[S.Rj[base + a]] -= Lv[S.Rpos[base + a]] * xi;
+    __syncthreads();
+  }
+}
+
+template <bool USE_LDS>
+__global__ __launch_bounds__(WAVE) void k_solve(rldl_dev_sym S, rldl_dev_num Nn, double *__restrict__ b_all) {
+  const int inst = blockIdx.x, lane = threadIdx.x;
+  extern __shared__ double sh[];
+  double *xs = sh;               // [N]
+  double *Ls = sh + S.N;         // [nnzL] when USE_LDS
+  const double *Lg = Nn.LD + (size_t)inst * (S.nnzL + S.N);
+  const double *Dinv = Nn.Dinv + (size_t)inst * S.N;
+  double *b = b_all + (size_t)inst * S.N;
+  if (USE_LDS)
+    for (int i = lane; i < S.nnzL; i += WAVE) Ls[i] = Lg[i];
+  for (int j = lane; j < S.N; j += WAVE) xs[j] = b[S.perm[j]];          // permute_x  :538-541
+  __syncthreads();
+  tri_solve(S, USE_LDS ? Ls : Lg, Dinv, xs, lane);
+  if (S.polish) {
+    for (int j = lane; j < S.N; j += WAVE) b[S.perm[j]] = xs[j];        // permutet_x :544-547, raw solution :563-565
+  } else {
+    const double *ri = Nn.rho_inv + (size_t)inst * S.m;
+    for (int j = lane; j < S.N; j += WAVE) {
+      const int o = S.perm[j];
+      if (o < S.n) b[o] = xs[j];                                        // x_tilde :572-574
+      else b[o] += ri[o - S.n] * xs[j];                                 // z_tilde :577-579
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// One fused ADMM iteration per launch (auxil.c:164-228): rhs -> permuted LDS vector -> tri-solve ->
+// x/z/y updates, all for one instance per wave.  Instances whose status left UNSOLVED are skipped.
+// ------------------------------------------------------------------------------------------------
+template <bool USE_LDS>
+__global__ __launch_bounds__(WAVE) void k_admm_iter(rldl_dev_sym S, rldl_dev_num Nn, rldl_dev_admm W) {
+  const int inst = blockIdx.x, lane = threadIdx.x;
+  if (W.status[inst] != ST_UNSOLVED) return;
+  extern __shared__ double sh[];
+  double *xs = sh;               // [N] permuted rhs / solution
+  double *Ls = sh + S.N;         // [nnzL]
+  const int n = S.n, m = S.m;
+  const double *Lg = Nn.LD + (size_t)inst * (S.nnzL + S.N);
+  const double *Dinv = Nn.Dinv + (size_t)inst * S.N;
+  const double *ri = Nn.rho_inv + (size_t)inst * m;
+  double *x = W.x + (size_t)inst * n, *z = W.z + (size_t)inst * m, *y = W.y + (size_t)inst * m;
+  const double *q = W.q + (size_t)inst * n;
+
+  if (USE_LDS)
+    for (int i = lane; i < S.nnzL; i += WAVE) Ls[i] = Lg[i];
+  // compute_rhs (auxil.c:164-178) gathered straight into permuted order (permute_x)
+  for (int j = lane; j < S.N; j += WAVE) {
+    const int o = S.perm[j];
+    xs[j] = o < n ? W.sigma * x[o] - q[o] : z[o - n] - ri[o - n] * y[o - n];
+  }
+  __syncthreads();
+  tri_solve(S, USE_LDS ? Ls : Lg, Dinv, xs, lane);
+  // un-permute + epilogue + update_x / update_z / update_y
+  const double alpha = W.alpha;
+  double *dx = W.delta_x + (size_t)inst * n, *dy = W.delta_y + (size_t)inst * m;
+  const double *l = W.l + (size_t)inst * m, *u = W.u + (size_t)inst * m;
+  const double *rv = W.rho_vec + (size_t)inst * m;
+  for (int j = lane; j < S.N; j += WAVE) {
+    const int o = S.perm[j];
+    const double s = xs[j];
+    if (o < n) {
+      const double xp = x[o];
+      const double xn = alpha * s + (1.0 - alpha) * xp;       // update_x :188-201
+      x[o] = xn;
+      dx[o] = xn - xp;
+    } else {
+      const int i = o - n;
+      const double zp = z[i], yi = y[i], r = ri[i];
+      const double zt = (zp - r * yi) + r * s;                 // z_tilde, qdldl_interface.c:577-579
+      const double mix = alpha * zt + (1.0 - alpha) * zp;
+      double zn = mix + r * yi;                                // update_z :203-215
+      zn = fmin(fmax(zn, l[i]), u[i]);                         // project, proj.c:4-14
+      const double d = rv[i] * (mix - zn);                     // update_y :217-228
+      z[i] = zn;
+      dy[i] = d;
+      y[i] = yi + d;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Residuals, termination and adaptive rho for one instance per wave.
+// ------------------------------------------------------------------------------------------------
+struct ResidualData {
+  double pri_res, dua_res, nz, nAx, nq, nAty, nPx;
+};
+
+// LDS vectors: vx[n], vy[m], Ax[m], Px[n], Aty[n]
+__device__ __forceinline__ void spmv_A(const rldl_dev_sym &S, const double *Av, const double *v, double *out, int lane) {
+  for (int i = lane; i < S.m; i += WAVE) {       // row-wise: out = A v (mat_vec, lin_alg.c:241-271)
+    double acc = 0.0;
+    for (int p = S.Arp[i]; p < S.Arp[i + 1]; p++) acc += Av[S.Arpos[p]] * v[S.Arj[p]];
+    out[i] = acc;
+  }
+}
+__device__ __forceinline__ void spmv_At(const rldl_dev_sym &S, const double *Av, const double *v, double *out, int lane) {
+  for (int j = lane; j < S.n; j += WAVE) {       // column-wise: out = A' v (mat_tpose_vec, lin_alg.c:273-322)
+    double acc = 0.0;
+    for (int p = S.Ap[j]; p < S.Ap[j + 1]; p++) acc += Av[p] * v[S.Ai[p]];
+    out[j] = acc;
+  }
+}
+__device__ __forceinline__ void spmv_Psym(const rldl_dev_sym &S, const double *Pv, const double *v, double *out, int lane) {
+  for (int j = lane; j < S.n; j += WAVE) {       // P upper-tri: P v + P' v without the diagonal twice (auxil.c:299-303)
+    double acc = 0.0;
+    for (int p = S.Prp[j]; p < S.Prp[j + 1]; p++) acc += Pv[S.Prpos[p]] * v[S.Prj[p]];          // row j of the upper part
+    for (int p = S.Pp[j]; p < S.Pp[j + 1]; p++) { const int i = S.Pi[p]; if (i != j) acc += Pv[p] * v[i]; }
+    out[j] = acc;
+  }
+}
+__device__ __forceinline__ double norm_inf_lds(const double *v, int len, int lane) {
+  double mx = 0.0;
+  for (int i = lane; i < len; i += WAVE) { const double a = fabs(v[i]); mx = a > mx ? a : mx; }
+  return wave_max(mx);
+}
+
+// is_primal_infeasible (auxil.c:364-424); dyp = projected delta_y (LDS scratch), tmp[n] scratch
+__device__ __forceinline__ int primal_infeasible(const rldl_dev_sym &S, const double *Av, const double *l, const double *u,
+                                                 const double *dy, double *dyp, double *tmp, double eps, int lane) {
+  for (int i = lane; i < S.m; i += WAVE) {
+    double d = dy[i];
+    if (u[i] > OSQP_INFTY * MIN_SCALING) {
+      if (l[i] < -OSQP_INFTY * MIN_SCALING) d = 0.0; else d = fmin(d, 0.0);
+    } else if (l[i] < -OSQP_INFTY * MIN_SCALING) d = fmax(d, 0.0);
+    dyp[i] = d;
+  }
+  __syncthreads();
+  const double nd = norm_inf_lds(dyp, S.m, lane);
+  if (!(nd > eps)) return 0;
+  double lhs = 0.0;
+  for (int i = lane; i < S.m; i += WAVE) lhs += u[i] * fmax(dyp[i], 0.0) + l[i] * fmin(dyp[i], 0.0);
+  lhs = wave_sum(lhs);
+  if (!(lhs < -eps * nd)) return 0;
+  spmv_At(S, Av, dyp, tmp, lane);
+  __syncthreads();
+  return norm_inf_lds(tmp, S.n, lane) < eps * nd;
+}
+
+// is_dual_infeasible (auxil.c:426-515); tmpn[n], tmpm[m] scratch
+__device__ __forceinline__ int dual_infeasible(const rldl_dev_sym &S, const double *Pv, const double *Av, const double *q,
+                                               const double *l, const double *u, const double *dx, double *tmpn,
+                                               double *tmpm, double eps, int lane) {
+  const double nd = norm_inf_lds(dx, S.n, lane);
+  if (!(nd > eps)) return 0;
+  double qd = 0.0;
+  for (int i = lane; i < S.n; i += WAVE) qd += q[i] * dx[i];
+  qd = wave_sum(qd);
+  if (!(qd < -eps * nd)) return 0;
+  spmv_Psym(S, Pv, dx, tmpn, lane);
+  __syncthreads();
+  if (!(norm_inf_lds(tmpn, S.n, lane) < eps * nd)) return 0;
+  spmv_A(S, Av, dx, tmpm, lane);
+  __syncthreads();
+  int viol = 0;
+  for (int i = lane; i < S.m; i += WAVE)
+    if ((u[i] < OSQP_INFTY * MIN_SCALING && tmpm[i] > eps * nd) || (l[i] > -OSQP_INFTY * MIN_SCALING && tmpm[i] < -eps * nd))
+      viol = 1;
+  return !wave_any(viol);
+}
+
+// mode bits
+#define CHK_TERMINATION 1
+#define CHK_ADAPT 2
+#define CHK_FINAL 4          /* tail of osqp_solve */
+#define CHK_FINAL_NEEDS_INFO 8
+
+__global__ __launch_bounds__(WAVE) void k_admm_check(rldl_dev_sym S, rldl_dev_admm W, int iter, int mode) {
+  const int inst = blockIdx.x, lane = threadIdx.x;
+  const int n = S.n, m = S.m;
+  extern __shared__ double sh[];
+  double *vx = sh, *vy = vx + n, *vz = vy + m, *vAx = vz + m, *vPx = vAx + m, *vAty = vPx + n;
+  double *vdx = vAty + n, *vdy = vdx + n, *t_n = vdy + m, *t_m = t_n + n, *dyp = t_m + m;
+  int st = W.status[inst];
+  const int active = st == ST_UNSOLVED;
+  if (!active && !(mode & CHK_FINAL)) return;
+
+  const double *Pv = W.Px + (size_t)inst * S.nnzP, *Av = W.Ax + (size_t)inst * S.nnzA;
+  const double *q = W.q + (size_t)inst * n, *l = W.l + (size_t)inst * m, *u = W.u + (size_t)inst * m;
+  double *x = W.x + (size_t)inst * n, *z = W.z + (size_t)inst * m, *y = W.y + (size_t)inst * m;
+  double *dxg = W.delta_x + (size_t)inst * n, *dyg = W.delta_y + (size_t)inst * m;
+
+  for (int i = lane; i < n; i += WAVE) { vx[i] = x[i]; vdx[i] = dxg[i]; }
+  for (int i = lane; i < m; i += WAVE) { vy[i] = y[i]; vz[i] = z[i]; vdy[i] = dyg[i]; }
+  __syncthreads();
+
+  // update_info (auxil.c:567-626): residuals
+  spmv_A(S, Av, vx, vAx, lane);
+  spmv_Psym(S, Pv, vx, vPx, lane);
+  spmv_At(S, Av, vy, vAty, lane);
+  __syncthreads();
+  double pr = 0.0, dr = 0.0;
+  for (int i = lane; i < m; i += WAVE) { const double a = fabs(vAx[i] - vz[i]); pr = a > pr ? a : pr; }
+  for (int i = lane; i < n; i += WAVE) { const double a = fabs(q[i] + vPx[i] + vAty[i]); dr = a > dr ? a : dr; }
+  pr = m ? wave_max(pr) : 0.0;
+  dr = wave_max(dr);
+  const double nz = norm_inf_lds(vz, m, lane), nAx = norm_inf_lds(vAx, m, lane);
+  double nq = 0.0;
+  for (int i = lane; i < n; i += WAVE) { const double a = fabs(q[i]); nq = a > nq ? a : nq; }
+  nq = wave_max(nq);
+  const double nAty = norm_inf_lds(vAty, n, lane), nPx = norm_inf_lds(vPx, n, lane);
+
+  const int do_info = active && (!(mode & CHK_FINAL) || (mode & CHK_FINAL_NEEDS_INFO));
+  if (do_info && lane == 0) { W.pri_res[inst] = pr; W.dua_res[inst] = dr; W.iter[inst] = iter; }
+  if (!do_info) { pr = W.pri_res[inst]; dr = W.dua_res[inst]; }
+
+  // check_termination (auxil.c:684-789); up to two passes in the final call (exact, then approximate)
+  const int npass = (mode & CHK_FINAL) ? 2 : ((mode & CHK_TERMINATION) ? 1 : 0);
+  double obj_special = 0.0;
+  int have_special = 0;
+  for (int pass = 0; pass < npass && st == ST_UNSOLVED; pass++) {
+    const int approx = (mode & CHK_FINAL) ? pass : 0;
+    if ((mode & CHK_FINAL) && pass == 0 && !(mode & CHK_FINAL_NEEDS_INFO)) continue; // exact check already ran this iteration
+    if (pr > OSQP_INFTY || dr > OSQP_INFTY) { st = ST_NON_CVX; obj_special = OSQP_NAN_VALUE; have_special = 1; break; }
+    const double f = approx ? 10.0 : 1.0;
+    const double ea = W.eps_abs * f, er = W.eps_rel * f, epi = W.eps_prim_inf * f, edi = W.eps_dual_inf * f;
+    int prc = 0, drc = 0, pic = 0, dic = 0;
+    if (m == 0) prc = 1;
+    else if (pr < ea + er * fmax(nz, nAx)) prc = 1;
+    else pic = primal_infeasible(S, Av, l, u, vdy, dyp, t_n, epi, lane);
+    if (dr < ea + er * fmax(fmax(nq, nAty), nPx)) drc = 1;
+    else dic = dual_infeasible(S, Pv, Av, q, l, u, vdx, t_n, t_m, edi, lane);
+    if (prc && drc) st = approx ? ST_SOLVED_INACCURATE : ST_SOLVED;
+    else if (pic) {
+      st = approx ? ST_PRIMAL_INFEASIBLE_INACCURATE : ST_PRIMAL_INFEASIBLE;
+      obj_special = OSQP_INFTY; have_special = 1;
+      for (int i = lane; i < m; i += WAVE) dyg[i] = dyp[i];     // keep the projected certificate
+    } else if (dic) {
+      st = approx ? ST_DUAL_INFEASIBLE_INACCURATE : ST_DUAL_INFEASIBLE;
+      obj_special = -OSQP_INFTY; have_special = 1;
+    }
+  }
+  if ((mode & CHK_FINAL) && st == ST_UNSOLVED) st = ST_MAX_ITER_REACHED;   // osqp.c:567-571
+
+  if (active && st != ST_UNSOLVED && lane == 0) {
+    W.status[inst] = st;
+    if (have_special) W.obj[inst] = obj_special;
+    atomicSub(W.n_active, 1);
+  }
+
+  // adapt_rho (auxil.c:13-77); only for instances that keep iterating
+  if ((mode & CHK_ADAPT) && st == ST_UNSOLVED) {
+    double prn = pr / (fmax(nz, nAx) + 1e-10);
+    double drn = dr / (fmax(fmax(nq, nAty), nPx) + 1e-10);
+    const double rho = W.rho_cur[inst];
+    double est = rho * sqrt(prn / (drn + 1e-10));
+    est = fmin(fmax(est, RHO_MIN), RHO_MAX);
+    if (lane == 0) W.rho_est[inst] = est;
+    if (est > rho * W.adaptive_rho_tolerance || est < rho / W.adaptive_rho_tolerance) {
+      // osqp_update_rho (osqp.c:1268-1319)
+      const double rn = fmin(fmax(est, RHO_MIN), RHO_MAX);
+      double *rv = W.rho_vec + (size_t)inst * m;
+      const int *ct = W.constr_type + (size_t)inst * m;
+      for (int i = lane; i < m; i += WAVE) {
+        if (ct[i] == 0) rv[i] = rn;
+        else if (ct[i] == 1) rv[i] = RHO_EQ_OVER_RHO_INEQ * rn;
+      }
+      if (lane == 0) { W.rho_cur[inst] = rn; W.rho_updates[inst] += 1; W.refactor[inst] = 1; }
+    }
+  }
+
+  // tail of osqp_solve: objective, rho estimate, store_solution (osqp.c:541-633, auxil.c:527-565)
+  if (mode & CHK_FINAL) {
+    const int has_sol = st != ST_PRIMAL_INFEASIBLE && st != ST_PRIMAL_INFEASIBLE_INACCURATE && st != ST_DUAL_INFEASIBLE &&
+                        st != ST_DUAL_INFEASIBLE_INACCURATE && st != ST_NON_CVX;
+    if (has_sol) {
+      double o = 0.0;
+      for (int i = lane; i < n; i += WAVE) o += (0.5 * vPx[i] + q[i]) * vx[i];   // 1/2 x'Px + q'x (auxil.c:230-241)
+      o = wave_sum(o);
+      if (lane == 0) W.obj[inst] = o;
+    }
+    {
+      double prn = pr / (fmax(nz, nAx) + 1e-10), drn = dr / (fmax(fmax(nq, nAty), nPx) + 1e-10);
+      double est = W.rho_cur[inst] * sqrt(prn / (drn + 1e-10));
+      if (lane == 0) W.rho_est[inst] = fmin(fmax(est, RHO_MIN), RHO_MAX);
+    }
+    if (!has_sol) {
+      // normalised certificates (auxil.c:543-557), iterates cold-started (:560-562)
+      if (st == ST_PRIMAL_INFEASIBLE || st == ST_PRIMAL_INFEASIBLE_INACCURATE) {
+        __syncthreads();
+        double nv = 0.0;
+        for (int i = lane; i < m; i += WAVE) { const double a = fabs(dyg[i]); nv = a > nv ? a : nv; }
+        nv = wave_max(nv);
+        for (int i = lane; i < m; i += WAVE) dyg[i] *= 1.0 / nv;
+      }
+      if (st == ST_DUAL_INFEASIBLE || st == ST_DUAL_INFEASIBLE_INACCURATE) {
+        const double nv = norm_inf_lds(vdx, n, lane);
+        for (int i = lane; i < n; i += WAVE) dxg[i] = vdx[i] * (1.0 / nv);
+      }
+    }
+  }
+}
+
+// set_rho_vec (auxil.c:79-101) when init != 0, update_rho_vec (auxil.c:103-145) otherwise:
+// classify rows, fill rho_vec, raise the refactor mask when a constraint type changed.
+__global__ __launch_bounds__(WAVE) void k_set_rho_vec(rldl_dev_sym S, rldl_dev_admm W, int init) {
+  const int inst = blockIdx.x, lane = threadIdx.x, m = S.m;
+  const double *l = W.l + (size_t)inst * m, *u = W.u + (size_t)inst * m;
+  double *rv = W.rho_vec + (size_t)inst * m;
+  int *ct = W.constr_type + (size_t)inst * m;
+  const double rho = W.rho_cur[inst];
+  int changed = 0;
+  for (int i = lane; i < m; i += WAVE) {
+    int t;
+    double r;
+    if (l[i] < -OSQP_INFTY * MIN_SCALING && u[i] > OSQP_INFTY * MIN_SCALING) { t = -1; r = RHO_MIN; }
+    else if (u[i] - l[i] < RHO_TOL) { t = 1; r = RHO_EQ_OVER_RHO_INEQ * rho; }
+    else { t = 0; r = rho; }
+    if (init || ct[i] != t) { ct[i] = t; rv[i] = r; changed = 1; }
+  }
+  changed = wave_any(changed);
+  if (lane == 0) W.refactor[inst] = init ? 1 : changed;
+}
+
+__global__ __launch_bounds__(WAVE) void k_matvec_A(rldl_dev_sym S, rldl_dev_admm W, const double *__restrict__ xin,
+                                                   double *__restrict__ out) {
+  const int inst = blockIdx.x, lane = threadIdx.x;
+  const double *Av = W.Ax + (size_t)inst * S.nnzA, *v = xin + (size_t)inst * S.n;
+  double *o = out + (size_t)inst * S.m;
+  for (int i = lane; i < S.m; i += WAVE) {
+    double acc = 0.0;
+    for (int p = S.Arp[i]; p < S.Arp[i + 1]; p++) acc += Av[S.Arpos[p]] * v[S.Arj[p]];
+    o[i] = acc;
+  }
+}
+
+}  // namespace
+
+// ================================================================================================
+// extern "C" launchers (enqueue only)
+// ================================================================================================
+static inline int launch_status() { return hipGetLastError() == hipSuccess ? 0 : -1; }
+
+extern "C" int rldl_launch_kkt_assemble(const rldl_dev_sym *S, const rldl_dev_num *Nn, const double *d_Px,
+                                        const double *d_Ax, const double *d_rho_vec, int set_sigma_only,
+                                        const int *d_mask, void *stream) {
+  if (Nn->batch <= 0) return 0;
+  hipLaunchKernelGGL(k_kkt_assemble, dim3(Nn->batch), dim3(256), 0, (hipStream_t)stream, *S, *Nn, d_Px, d_Ax, d_rho_vec,
+                     set_sigma_only, d_mask);
+  return launch_status();
+}
+
+static int launch_factor(const rldl_dev_sym *S, const rldl_dev_num *Nn, const int *d_mask, int c_start, void *stream) {
+  if (Nn->batch <= 0) return 0;
+  const size_t lds = sizeof(double) * (size_t)(S->nnzL + S->N);
+  if (lds <= RLDL_LDS_LIMIT)
+    hipLaunchKernelGGL(k_factor<true>, dim3(Nn->batch), dim3(WAVE), lds, (hipStream_t)stream, *S, *Nn, d_mask, c_start);
+  else
+    hipLaunchKernelGGL(k_factor<false>, dim3(Nn->batch), dim3(WAVE), 0, (hipStream_t)stream, *S, *Nn, d_mask, c_start);
+  return launch_status();
+}
+
+extern "C" int rldl_launch_factor(const rldl_dev_sym *S, const rldl_dev_num *Nn, const int *d_mask, void *stream) {
+  return launch_factor(S, Nn, d_mask, 0, stream);
+}
+
+extern "C" int rldl_launch_factor_from(const rldl_dev_sym *S, const rldl_dev_num *Nn, int c_start, void *stream) {
+  if (c_start < 0 || c_start > S->N) return -1;
+  return launch_factor(S, Nn, 0, c_start, stream);
+}
+
+extern "C" int rldl_launch_solve(const rldl_dev_sym *S, const rldl_dev_num *Nn, double *d_b, void *stream) {
+  if (Nn->batch <= 0) return 0;
+  const size_t lds = sizeof(double) * (size_t)(S->nnzL + S->N);
+  if (lds <= RLDL_LDS_LIMIT)
+    hipLaunchKernelGGL(k_solve<true>, dim3(Nn->batch), dim3(WAVE), lds, (hipStream_t)stream, *S, *Nn, d_b);
+  else
+    hipLaunchKernelGGL(k_solve<false>, dim3(Nn->batch), dim3(WAVE), sizeof(double) * (size_t)S->N, (hipStream_t)stream, *S,
+                       *Nn, d_b);
+  return launch_status();
+}
+
+extern "C" int rldl_launch_admm_iter(const rldl_dev_sym *S, const rldl_dev_num *Nn, const rldl_dev_admm *W, void *stream) {
+  if (Nn->batch <= 0) return 0;
+  const size_t lds = sizeof(double) * (size_t)(S->nnzL + S->N);
+  if (lds <= RLDL_LDS_LIMIT)
+    hipLaunchKernelGGL(k_admm_iter<true>, dim3(Nn->batch), dim3(WAVE), lds, (hipStream_t)stream, *S, *Nn, *W);
+  else
+    hipLaunchKernelGGL(k_admm_iter<false>, dim3(Nn->batch), dim3(WAVE), sizeof(double) * (size_t)S->N, (hipStream_t)stream,
+                       *S, *Nn, *W);
+  return launch_status();
+}
+
+static size_t check_lds(const rldl_dev_sym *S) { return sizeof(double) * (size_t)(6 * S->n + 6 * S->m + 8); }
+
+extern "C" int rldl_launch_admm_check(const rldl_dev_sym *S, const rldl_dev_admm *W, int iter, int approximate,
+                                      int final_pass, void *stream) {
+  if (W->batch <= 0) return 0;
+  // approximate: bit0 = run termination check, bit1 = adapt rho; final_pass: 0 none, 1 final, 2 final + needs info
+  int mode = 0;
+  if (approximate & 1) mode |= CHK_TERMINATION;
+  if (approximate & 2) mode |= CHK_ADAPT;
+  if (final_pass) mode |= CHK_FINAL;
+  if (final_pass == 2) mode |= CHK_FINAL_NEEDS_INFO;
+  hipLaunchKernelGGL(k_admm_check, dim3(W->batch), dim3(WAVE), check_lds(S), (hipStream_t)stream, *S, *W, iter, mode);
+  return launch_status();
+}
+
+extern "C" int rldl_launch_admm_adapt_rho(const rldl_dev_sym *S, const rldl_dev_admm *W, void *stream) {
+  (void)S; (void)W; (void)stream;
+  return 0; /* folded into k_admm_check (mode bit CHK_ADAPT) */
+}
+
+extern "C" int rldl_launch_set_rho_vec(const rldl_dev_sym *S, const rldl_dev_admm *W, int init, void *stream) {
+  if (W->batch <= 0) return 0;
+  hipLaunchKernelGGL(k_set_rho_vec, dim3(W->batch), dim3(WAVE), 0, (hipStream_t)stream, *S, *W, init);
+  return launch_status();
+}
+
+extern "C" int rldl_launch_finalize(const rldl_dev_sym *S, const rldl_dev_admm *W, int max_iter, void *stream) {
+  (void)S; (void)W; (void)max_iter; (void)stream;
+  return 0; /* folded into k_admm_check (mode bit CHK_FINAL) */
+}
+
+extern "C" int rldl_launch_matvec_A(const rldl_dev_sym *S, const rldl_dev_admm *W, const double *d_x, double *d_out,
+                                    void *stream) {
+  if (W->batch <= 0) return 0;
+  hipLaunchKernelGGL(k_matvec_A, dim3(W->batch), dim3(WAVE), 0, (hipStream_t)stream, *S, *W, d_x, d_out);
+  return launch_status();
+}
+
+extern "C" const char *rldl_kernel_arch(void) { return "gfx950"; }

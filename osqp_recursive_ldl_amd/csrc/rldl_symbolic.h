@@ -1,0 +1,72 @@
+/*
+ * rldl_symbolic.h -- host-side (plain C) symbolic analysis shared by every kernel of the backend.
+ *
+ * One rldl_symbolic describes the sparsity of ONE pattern group: the permuted upper-triangular KKT
+ * matrix, the value-scatter maps of the reference's update path, the elimination tree, the pattern
+ * of L in CSC and CSR order, and the update lists that drive the right-looking device factorisation.
+ * All index arrays are int32 (device copies are uploaded verbatim).
+ *
+ * Reference functions whose result this analysis reproduces (host, integer work):
+ *   form_KKT            src/kkt.c:6-177            (pattern + PtoKKT/AtoKKT/param2toKKT/Pdiag_idx)
+ *   permute_KKT         lin_sys/direct/qdldl/qdldl_interface.c:99-166 (ordering, csc_pinv, csc_symperm, map composition)
+ *   QDLDL_etree         call site qdldl_interface.c:59 (etree, Lnz; Lp = cumsum as QDLDL_factor builds it)
+ */
+#ifndef RLDL_SYMBOLIC_H
+#define RLDL_SYMBOLIC_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+  int n, m, N;                 /* variables, constraints, KKT dimension n+m */
+  int nnzP, nnzA, nnzK, nnzL;
+  int polish;
+  /* permutation: row/col k of the permuted matrix is row/col perm[k] of the original */
+  int *perm, *pinv;
+  /* permuted KKT, upper triangular CSC (rows ascending inside a column) */
+  int *Kp, *Ki;
+  /* value scatter maps into the permuted KKT value array */
+  int *PtoK;                   /* [nnzP] */
+  unsigned char *Pisdiag;      /* [nnzP] 1 where P(i,i): sigma is added (src/kkt.c:69-79, :196-202) */
+  int *AtoK;                   /* [nnzA] */
+  int *rhotoK;                 /* [m]    */
+  int nsig, *sigK;             /* KKT slots holding sigma alone (P column without a diagonal entry) */
+  /* elimination tree and L pattern (strictly lower, CSC, rows ascending) */
+  int *etree, *Lnz, *Lp, *Li;
+  int etree_height;
+  /* L in row order: entries of row i are columns Rj[Rp[i]..Rp[i+1]) ascending, value slot Rpos[] */
+  int *Rp, *Rj, *Rpos;
+  /* factor workspace W = [L values (nnzL, CSC order) | D (N)]; KtoW maps KKT slot -> W slot */
+  int *KtoW;
+  /* right-looking updates: for column j, pairs t in [Up[j], Up[j+1]): W[Udst[t]] -= l_a * l_b * D_j,
+   * a = Uab[t] & 0xffff, b = Uab[t] >> 16 index the entries of column j (b <= a) */
+  long long *Up;               /* [N+1] */
+  int *Udst;
+  unsigned int *Uab;
+  long long npairs;
+  /* problem matrices for the residual kernels: CSC as given plus row-order (CSR) access maps */
+  int *Pp, *Pi, *Prp, *Prj, *Prpos;   /* P upper triangular n x n */
+  int *Ap, *Ai, *Arp, *Arj, *Arpos;   /* A m x n */
+} rldl_symbolic;
+
+/* Pp/Pi/Ap/Ai: 64-bit CSC pattern arrays as they come through the C ABI (csc.p / csc.i).
+ * perm_in: optional user permutation (length n+m), NULL -> built-in minimum-degree ordering.
+ * Returns 0, or a negative code: -1 not upper triangular / bad index, -2 out of memory,
+ * -3 invalid permutation. */
+int rldl_symbolic_create(rldl_symbolic **out, long long n, long long m, const long long *Pp,
+                         const long long *Pi, const long long *Ap, const long long *Ai, int polish,
+                         const long long *perm_in);
+void rldl_symbolic_free(rldl_symbolic *s);
+
+/* fill-reducing ordering of a symmetric pattern given by its upper triangle (CSC, n columns) */
+int rldl_order_min_degree(int n, const int *Ap, const int *Ai, int *perm);
+
+/* closed-form stage-interleaved permutation of src/recursive_ldl.c:1350-1362 (compute_permutations) */
+void rldl_stage_permutation(long long N, long long nx, long long nu, long long ny, long long nt,
+                            long long *perm);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

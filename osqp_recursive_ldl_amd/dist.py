@@ -1,0 +1,68 @@
+"""Multi-GPU layer: the batch shards embarrassingly (every QP instance is a closed system).
+
+One process per GPU (torch.distributed; backend "nccl" is RCCL on ROCm, "gloo" on CPU for tests).
+The data path has NO collective; the only exchange is one all-gather of the packed per-instance result
+record  [x(n) | y(m) | obj | pri_res | dua_res | iter | status]  at the end of a solve.
+"""
+import numpy as np
+
+
+def shard_range(batch, rank, world):
+    """Contiguous shard [lo, hi) of `batch` instances for `rank` (sizes differ by at most one)."""
+    base, rem = divmod(int(batch), int(world))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def pack_results(res, n, m):
+    """Pack a results dict (tensors [b, ...]) into one float64 record tensor [b, n+m+5]."""
+    import torch
+    b = res["x"].shape[0]
+    rec = torch.empty((b, n + m + 5), dtype=torch.float64, device=res["x"].device)
+    rec[:, :n] = res["x"]
+    rec[:, n:n + m] = res["y"]
+    rec[:, n + m] = res["obj"]
+    rec[:, n + m + 1] = res["pri_res"]
+    rec[:, n + m + 2] = res["dua_res"]
+    rec[:, n + m + 3] = res["iter"].to(torch.float64)
+    rec[:, n + m + 4] = res["status"].to(torch.float64)
+    return rec
+
+
+def unpack_results(rec, n, m):
+    import torch
+    return dict(x=rec[:, :n], y=rec[:, n:n + m], obj=rec[:, n + m], pri_res=rec[:, n + m + 1], dua_res=rec[:, n + m + 2],
+                iter=rec[:, n + m + 3].to(torch.int32), status=rec[:, n + m + 4].to(torch.int32))
+
+
+def gather_results(res, n, m, sizes=None):
+    """All-gather the per-rank result shards into the full batch on every rank (the one collective of
+    the path).  `sizes` = per-rank shard sizes when they differ; equal shards use all_gather_into_tensor."""
+    import torch
+    import torch.distributed as dist
+    rec = pack_results(res, n, m).contiguous()
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return unpack_results(rec, n, m)
+    world = dist.get_world_size()
+    if sizes is None or len(set(sizes)) == 1:
+        out = torch.empty((world * rec.shape[0], rec.shape[1]), dtype=rec.dtype, device=rec.device)
+        dist.all_gather_into_tensor(out, rec)
+    else:
+        parts = [torch.empty((s, rec.shape[1]), dtype=rec.dtype, device=rec.device) for s in sizes]
+        dist.all_gather(parts, rec)
+        out = torch.cat(parts, 0)
+    return unpack_results(out, n, m)
+
+
+def shard_sizes(batch, world):
+    return [shard_range(batch, r, world)[1] - shard_range(batch, r, world)[0] for r in range(world)]
+
+
+def sharded_values(values_fn, batch, rank, world):
+    """Generate only this rank's slice of a synthetic batch: values_fn(count, seed0) -> tuple of arrays."""
+    lo, hi = shard_range(batch, rank, world)
+    return values_fn(hi - lo, lo)
+
+
+__all__ = ["shard_range", "shard_sizes", "pack_results", "unpack_results", "gather_results", "sharded_values"]
+_ = np

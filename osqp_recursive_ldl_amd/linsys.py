@@ -1,0 +1,260 @@
+"""Host-side mirror of the reference's linear-system plugin interface, over the C-ABI.
+
+`HipLDLSolver`      legacy single-instance object: init / solve / update_matrices / update_rho_vec / free with
+                    HOST numpy data, exactly the call shapes of lin_sys/direct/qdldl/qdldl_interface.c
+                    (init :170-316, solve :559-585, update_matrices :590-602, update_rho_vec :605-619).
+`BatchLinsys`       the same five operations with a leading batch dimension on DEVICE tensors.
+
+torch is used only as the owner of device memory and the current stream; all compute happens inside
+libosqp_rldl_hip.so.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import Csc, c_int
+
+
+def _ip(a):
+    return a.ctypes.data_as(_lib.IP)
+
+
+def _fp(a):
+    return a.ctypes.data_as(_lib.FP)
+
+
+class CscPattern:
+    """A `csc` struct (include/types.h:21-29) backed by numpy arrays kept alive by this object."""
+
+    def __init__(self, M, upper=False):
+        from scipy import sparse
+        M = sparse.csc_matrix(M)
+        if upper:
+            M = sparse.triu(M, format="csc")
+        M.sort_indices()
+        self.shape = M.shape
+        self.p = np.ascontiguousarray(M.indptr, dtype=np.int64)
+        self.i = np.ascontiguousarray(M.indices, dtype=np.int64)
+        self.x = np.ascontiguousarray(M.data, dtype=np.float64)
+        self.nnz = int(self.p[-1])
+        self.s = Csc(max(self.nnz, 1), M.shape[0], M.shape[1], _ip(self.p), _ip(self.i), _fp(self.x), -1)
+
+    @property
+    def ref(self):
+        return C.byref(self.s)
+
+    def with_values(self, x):
+        out = CscPattern.__new__(CscPattern)
+        out.shape, out.p, out.i, out.nnz = self.shape, self.p, self.i, self.nnz
+        out.x = np.ascontiguousarray(x, dtype=np.float64)
+        assert out.x.shape == (self.nnz,)
+        out.s = Csc(max(self.nnz, 1), self.shape[0], self.shape[1], _ip(out.p), _ip(out.i), _fp(out.x), -1)
+        return out
+
+
+class HipLDLSolver:
+    """Legacy single-instance plugin object (one QP, host arrays), driven through the vtable of the
+    returned struct -- the same way OSQP's `work->linsys_solver->solve(...)` would (src/auxil.c:185)."""
+
+    def __init__(self, P, A, sigma, rho_vec, polish=0):
+        L = _lib.lib()
+        self.P = P if isinstance(P, CscPattern) else CscPattern(P)
+        self.A = A if isinstance(A, CscPattern) else CscPattern(A)
+        self.n, self.m = self.P.shape[0], self.A.shape[0]
+        self._sp = C.POINTER(_lib.HipldlSolver)()
+        rv = None if rho_vec is None else np.ascontiguousarray(rho_vec, dtype=np.float64)
+        self.status = _lib.check(L.init_linsys_solver_hipldl(C.byref(self._sp), self.P.ref, self.A.ref, float(sigma),
+                                                             None if rv is None else _fp(rv), int(polish)),
+                                 "init_linsys_solver_hipldl")
+        self.type = self._sp.contents.type if self.status == 0 else None
+
+    def solve(self, b):
+        b = np.array(b, dtype=np.float64, copy=True)
+        rc = self._sp.contents.solve(self._sp, _fp(b))     # through the vtable
+        if rc:
+            raise RuntimeError("solve failed")
+        return b
+
+    def update_matrices(self, P, A):
+        Pn = self.P.with_values(P if not hasattr(P, "data") else _sorted_data(P))
+        An = self.A.with_values(A if not hasattr(A, "data") else _sorted_data(A))
+        return int(self._sp.contents.update_matrices(self._sp, Pn.ref, An.ref))
+
+    def update_rho_vec(self, rho_vec):
+        rv = np.ascontiguousarray(rho_vec, dtype=np.float64)
+        return int(self._sp.contents.update_rho_vec(self._sp, _fp(rv)))
+
+    def free(self):
+        if self._sp:
+            self._sp.contents.free(self._sp)
+            self._sp = C.POINTER(_lib.HipldlSolver)()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def _sorted_data(M):
+    from scipy import sparse
+    M = sparse.csc_matrix(M)
+    M.sort_indices()
+    return M.data
+
+
+def _dptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _dev_f64(t, shape, name):
+    import torch
+    if t is None:
+        return None
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float64 and t.is_contiguous()):
+        raise TypeError("%s must be a contiguous float64 device tensor" % name)
+    if tuple(t.shape) != tuple(shape):
+        raise ValueError("%s has shape %s, expected %s" % (name, tuple(t.shape), tuple(shape)))
+    return t
+
+
+class BatchLinsys:
+    """Batched plugin: `batch` instances sharing the sparsity pattern of P (upper triangular) and A.
+    Value tensors are float64 device tensors, instance-major: Px[batch, nnzP], Ax[batch, nnzA],
+    rho_vec[batch, m], b[batch, n+m]."""
+
+    def __init__(self, P_pattern, A_pattern, Px, Ax, sigma, rho_vec, polish=0, perm=None, _handle=None, _owned=True):
+        L = _lib.lib()
+        self.P = P_pattern if isinstance(P_pattern, CscPattern) else CscPattern(P_pattern)
+        self.A = A_pattern if isinstance(A_pattern, CscPattern) else CscPattern(A_pattern)
+        self.n, self.m = self.P.shape[0], self.A.shape[0]
+        self._owned = _owned
+        if _handle is not None:
+            self.h = C.c_void_p(_handle)
+            self.batch = self.dims()["batch"]
+            self.status = 0
+            return
+        self.batch = int(Px.shape[0])
+        _dev_f64(Px, (self.batch, self.P.nnz), "Px"); _dev_f64(Ax, (self.batch, self.A.nnz), "Ax")
+        if not polish:
+            _dev_f64(rho_vec, (self.batch, self.m), "rho_vec")
+        pm = None if perm is None else np.ascontiguousarray(perm, dtype=np.int64)
+        self.h = C.c_void_p()
+        self.status = _lib.check(L.rldl_batch_init(C.byref(self.h), self.batch, self.P.ref, self.A.ref, _dptr(Px), _dptr(Ax),
+                                                   float(sigma), None if polish else _dptr(rho_vec), int(polish),
+                                                   None if pm is None else _ip(pm), None), "rldl_batch_init")
+
+    @classmethod
+    def recursive(cls, dims, P_pattern, A_pattern, Px, Ax, sigma, rho_vec):
+        """Stage-recursive strategy (src/recursive_ldl.c): dims = (N, nx, nu, ny, nt)."""
+        L = _lib.lib()
+        self = cls.__new__(cls)
+        self.P = P_pattern if isinstance(P_pattern, CscPattern) else CscPattern(P_pattern)
+        self.A = A_pattern if isinstance(A_pattern, CscPattern) else CscPattern(A_pattern)
+        self.n, self.m = self.P.shape[0], self.A.shape[0]
+        self.batch = int(Px.shape[0])
+        self._owned = True
+        sd = _lib.StageDims(*[int(v) for v in dims])
+        self.h = C.c_void_p()
+        self.status = _lib.check(L.rldl_batch_init_recursive(C.byref(self.h), self.batch, C.byref(sd), self.P.ref, self.A.ref,
+                                                             _dptr(Px), _dptr(Ax), float(sigma), _dptr(rho_vec), None),
+                                 "rldl_batch_init_recursive")
+        return self
+
+    def solve(self, b):
+        """In place on b[batch, n+m] (qdldl_interface.c:559-585)."""
+        _dev_f64(b, (self.batch, self.n + self.m), "b")
+        if _lib.lib().rldl_batch_solve(self.h, _dptr(b)):
+            raise RuntimeError("rldl_batch_solve failed")
+        return b
+
+    def update_matrices(self, Px=None, Ax=None):
+        _dev_f64(Px, (self.batch, self.P.nnz), "Px"); _dev_f64(Ax, (self.batch, self.A.nnz), "Ax")
+        return int(_lib.lib().rldl_batch_update_matrices(self.h, _dptr(Px), _dptr(Ax)))
+
+    def update_rho_vec(self, rho_vec, mask=None):
+        _dev_f64(rho_vec, (self.batch, self.m), "rho_vec")
+        return int(_lib.lib().rldl_batch_update_rho_vec(self.h, _dptr(rho_vec), _dptr(mask)))
+
+    def update_from_stage(self, first_stage, Px=None, Ax=None, rho_vec=None):
+        return int(_lib.lib().rldl_batch_update_from_stage(self.h, int(first_stage), _dptr(Px), _dptr(Ax), _dptr(rho_vec)))
+
+    def dims(self):
+        v = [c_int(0) for _ in range(5)]
+        _lib.lib().rldl_batch_dims(self.h, *[C.byref(t) for t in v])
+        return dict(n=v[0].value, m=v[1].value, nnzKKT=v[2].value, nnzL=v[3].value, batch=v[4].value)
+
+    def export_symbolic(self):
+        d = self.dims()
+        N = d["n"] + d["m"]
+        out = dict(perm=np.zeros(N, np.int64), etree=np.zeros(N, np.int64), Lnz=np.zeros(N, np.int64),
+                   Lp=np.zeros(N + 1, np.int64), Li=np.zeros(max(d["nnzL"], 1), np.int64),
+                   KKTp=np.zeros(N + 1, np.int64), KKTi=np.zeros(d["nnzKKT"], np.int64),
+                   PtoKKT=np.zeros(max(self.P.nnz, 1), np.int64), AtoKKT=np.zeros(max(self.A.nnz, 1), np.int64),
+                   rhotoKKT=np.zeros(max(d["m"], 1), np.int64))
+        _lib.lib().rldl_batch_export_symbolic(self.h, *[_ip(out[k]) for k in
+                                                        ("perm", "etree", "Lnz", "Lp", "Li", "KKTp", "KKTi", "PtoKKT",
+                                                         "AtoKKT", "rhotoKKT")])
+        out["Li"] = out["Li"][:d["nnzL"]]
+        out["PtoKKT"] = out["PtoKKT"][:self.P.nnz]; out["AtoKKT"] = out["AtoKKT"][:self.A.nnz]
+        out["rhotoKKT"] = out["rhotoKKT"][:d["m"]]
+        return out
+
+    def export_factor(self, inst):
+        d = self.dims()
+        N = d["n"] + d["m"]
+        Lx = np.zeros(max(d["nnzL"], 1)); D = np.zeros(N); Dinv = np.zeros(N); Kx = np.zeros(d["nnzKKT"])
+        if _lib.lib().rldl_batch_export_factor(self.h, int(inst), _fp(Lx), _fp(D), _fp(Dinv), _fp(Kx)):
+            raise RuntimeError("export_factor failed")
+        return dict(Lx=Lx[:d["nnzL"]], D=D, Dinv=Dinv, KKTx=Kx)
+
+    def factor_status(self):
+        st = np.zeros(self.batch, np.int64)
+        _lib.lib().rldl_batch_factor_status(self.h, _ip(st))
+        return st
+
+    def time_solve(self, b, reps=20):
+        ms = _lib.c_float(0)
+        if _lib.lib().rldl_batch_time_solve(self.h, _dptr(b), int(reps), C.byref(ms)):
+            raise RuntimeError("time_solve failed")
+        return ms.value
+
+    def free(self):
+        if getattr(self, "h", None) and self._owned:
+            _lib.lib().rldl_batch_free(self.h)
+        self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def symbolic_analyze(P, A, polish=0, perm=None):
+    """Host-only symbolic phase (no GPU needed): permutation, permuted KKT pattern, scatter maps,
+    elimination tree and the pattern of L, as plain numpy int64 arrays."""
+    L = _lib.lib()
+    Pc = P if isinstance(P, CscPattern) else CscPattern(P)
+    Ac = A if isinstance(A, CscPattern) else CscPattern(A)
+    n, m = Pc.shape[0], Ac.shape[0]
+    N = n + m
+    pm = None if perm is None else np.ascontiguousarray(perm, dtype=np.int64)
+    nk, nl, h = c_int(0), c_int(0), c_int(0)
+    null = [None] * 10
+    rc = L.rldl_symbolic_analyze(Pc.ref, Ac.ref, int(polish), None if pm is None else _ip(pm), C.byref(nk), C.byref(nl),
+                                 C.byref(h), *null)
+    if rc:
+        raise ValueError("rldl_symbolic_analyze failed (%d)" % rc)
+    out = dict(perm=np.zeros(N, np.int64), etree=np.zeros(N, np.int64), Lnz=np.zeros(N, np.int64),
+               Lp=np.zeros(N + 1, np.int64), Li=np.zeros(max(nl.value, 1), np.int64), KKTp=np.zeros(N + 1, np.int64),
+               KKTi=np.zeros(max(nk.value, 1), np.int64), PtoKKT=np.zeros(max(Pc.nnz, 1), np.int64),
+               AtoKKT=np.zeros(max(Ac.nnz, 1), np.int64), rhotoKKT=np.zeros(max(m, 1), np.int64))
+    keys = ("perm", "etree", "Lnz", "Lp", "Li", "KKTp", "KKTi", "PtoKKT", "AtoKKT", "rhotoKKT")
+    L.rldl_symbolic_analyze(Pc.ref, Ac.ref, int(polish), None if pm is None else _ip(pm), C.byref(nk), C.byref(nl),
+                            C.byref(h), *[_ip(out[k]) for k in keys])
+    out["Li"] = out["Li"][:nl.value]; out["KKTi"] = out["KKTi"][:nk.value]
+    out["PtoKKT"] = out["PtoKKT"][:Pc.nnz]; out["AtoKKT"] = out["AtoKKT"][:Ac.nnz]; out["rhotoKKT"] = out["rhotoKKT"][:m]
+    out.update(nnzKKT=nk.value, nnzL=nl.value, etree_height=h.value, n=n, m=m)
+    return out

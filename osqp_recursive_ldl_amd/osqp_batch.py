@@ -1,0 +1,116 @@
+"""Batched, device-resident mirror of the reference's public solver API for the hot path:
+osqp_setup / osqp_solve / osqp_update_lin_cost / osqp_update_bounds / osqp_update_rho /
+osqp_update_P_A / osqp_warm_start / osqp_cleanup (src/osqp.c), one instance per wavefront.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .linsys import BatchLinsys, CscPattern, _dev_f64, _dptr, _ip
+
+STATUS_NAMES = {1: "solved", 2: "solved inaccurate", 3: "primal infeasible inaccurate", 4: "dual infeasible inaccurate",
+                -2: "maximum iterations reached", -3: "primal infeasible", -4: "dual infeasible", -7: "problem non convex",
+                -10: "unsolved"}
+
+
+def default_settings(**kw):
+    s = _lib.OSQPBatchSettings()
+    _lib.lib().osqp_batch_set_default_settings(C.byref(s))
+    for k, v in kw.items():
+        if not hasattr(s, k):
+            raise KeyError("unknown setting %r" % k)
+        setattr(s, k, v)
+    return s
+
+
+class OSQPBatch:
+    def __init__(self, P_pattern, A_pattern, Px, Ax, q, l, u, perm=None, **settings):
+        L = _lib.lib()
+        self.P = P_pattern if isinstance(P_pattern, CscPattern) else CscPattern(P_pattern)
+        self.A = A_pattern if isinstance(A_pattern, CscPattern) else CscPattern(A_pattern)
+        self.n, self.m = self.P.shape[0], self.A.shape[0]
+        self.batch = int(q.shape[0])
+        _dev_f64(Px, (self.batch, self.P.nnz), "Px"); _dev_f64(Ax, (self.batch, self.A.nnz), "Ax")
+        _dev_f64(q, (self.batch, self.n), "q"); _dev_f64(l, (self.batch, self.m), "l"); _dev_f64(u, (self.batch, self.m), "u")
+        self.settings = default_settings(**settings)
+        pm = None if perm is None else np.ascontiguousarray(perm, dtype=np.int64)
+        self.h = C.c_void_p()
+        self.status = _lib.check(L.osqp_batch_setup(C.byref(self.h), self.batch, self.P.ref, self.A.ref, _dptr(Px), _dptr(Ax),
+                                                    _dptr(q), _dptr(l), _dptr(u), C.byref(self.settings),
+                                                    None if pm is None else _ip(pm), None), "osqp_batch_setup")
+        self._device = q.device
+
+    def linsys(self):
+        return BatchLinsys(self.P, self.A, None, None, 0, None, _handle=_lib.lib().osqp_batch_linsys(self.h), _owned=False)
+
+    def solve(self):
+        rc = _lib.lib().osqp_batch_solve(self.h)
+        if rc:
+            raise RuntimeError("osqp_batch_solve failed (%d)" % rc)
+        return self.results()
+
+    def _view(self, ptr, shape, dtype):
+        """Zero-copy torch view of a workspace-owned device array (valid until cleanup)."""
+        import torch
+        count = int(np.prod(shape))
+        if count == 0:
+            return torch.empty(shape, dtype=dtype, device=self._device)
+        itemsize = torch.empty((), dtype=dtype).element_size()
+
+        class _Arr:  # __cuda_array_interface__ carrier
+            pass
+        a = _Arr()
+        typestr = {torch.float64: "<f8", torch.int32: "<i4"}[dtype]
+        a.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2,
+                                      "strides": None}
+        del itemsize
+        return torch.as_tensor(a, device=self._device)
+
+    def results(self, clone=True):
+        import torch
+        p = [C.c_void_p() for _ in range(8)]
+        _lib.lib().osqp_batch_get(self.h, *[C.byref(t) for t in p])
+        B, n, m = self.batch, self.n, self.m
+        out = dict(x=self._view(p[0].value, (B, n), torch.float64), y=self._view(p[1].value, (B, m), torch.float64),
+                   z=self._view(p[2].value, (B, m), torch.float64), status=self._view(p[3].value, (B,), torch.int32),
+                   iter=self._view(p[4].value, (B,), torch.int32), obj=self._view(p[5].value, (B,), torch.float64),
+                   pri_res=self._view(p[6].value, (B,), torch.float64), dua_res=self._view(p[7].value, (B,), torch.float64))
+        if clone:
+            out = {k: v.clone() for k, v in out.items()}
+        return out
+
+    def update_lin_cost(self, q):
+        return int(_lib.lib().osqp_batch_update_lin_cost(self.h, _dptr(_dev_f64(q, (self.batch, self.n), "q"))))
+
+    def update_bounds(self, l, u):
+        _dev_f64(l, (self.batch, self.m), "l"); _dev_f64(u, (self.batch, self.m), "u")
+        return int(_lib.lib().osqp_batch_update_bounds(self.h, _dptr(l), _dptr(u)))
+
+    def update_rho(self, rho):
+        return int(_lib.lib().osqp_batch_update_rho(self.h, float(rho)))
+
+    def update_P_A(self, Px=None, Ax=None):
+        _dev_f64(Px, (self.batch, self.P.nnz), "Px"); _dev_f64(Ax, (self.batch, self.A.nnz), "Ax")
+        return int(_lib.lib().osqp_batch_update_P_A(self.h, _dptr(Px), _dptr(Ax)))
+
+    def warm_start(self, x, y):
+        _dev_f64(x, (self.batch, self.n), "x"); _dev_f64(y, (self.batch, self.m), "y")
+        return int(_lib.lib().osqp_batch_warm_start(self.h, _dptr(x), _dptr(y)))
+
+    def time_iteration(self, reps=0):
+        ms = _lib.c_float(0)
+        if _lib.lib().osqp_batch_time_iteration(self.h, int(reps), C.byref(ms)):
+            raise RuntimeError("time_iteration failed")
+        return ms.value
+
+    def cleanup(self):
+        if getattr(self, "h", None):
+            _lib.lib().osqp_batch_cleanup(self.h)
+        self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.cleanup()
+        except Exception:
+            pass

@@ -1,0 +1,440 @@
+"""GPU parity tests (pytest -m gpu): the HIP path, called through the C-ABI, against the CPU oracle on
+the same seeded inputs, against the committed golden fixtures, and -- at BASELINE.json's full sizes --
+through size-independent properties.
+
+Tolerances (north_star "within a stated fp64 tolerance"):
+  integers (perm given, etree, Lnz, Lp, Li)            exact
+  Lx, D, Dinv vs oracle                                rel 1e-12 (operation order differs: right-looking vs up-looking)
+  solve output vs oracle                               rel 1e-10
+  ADMM iterates after 200 fixed-rho iterations         rel 1e-8
+  reference known answers (x, y, obj)                  1e-4 = TESTS_TOL (tests/minunit.h:13)
+"""
+import numpy as np
+import pytest
+from scipy import sparse
+
+import oracle_bindings as ob
+from helpers import dense_from_L, full_kkt, load_golden, osqp_inf
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+TESTS_TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def R():
+    import osqp_recursive_ldl_amd as R
+    return R
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to("cuda:0")
+
+
+def relerr(a, b):
+    return float(np.max(np.abs(np.asarray(a) - np.asarray(b))) / max(1.0, float(np.max(np.abs(b)))))
+
+
+# ------------------------------------------------------------------ legacy vtable (config 1 plumbing) ----
+def test_legacy_vtable_solve_linsys_golden(R):
+    """tests/solve_linsys/test_solve_linsys.h:12-48 through the HIP backend (same pattern the reference uses
+    to test a second backend: identical suite, different solver enum)."""
+    d = load_golden("solve_linsys")["data"]
+    m = d["test_solve_KKT_m"]
+    s = R.HipLDLSolver(d["test_solve_KKT_Pu"], d["test_solve_KKT_A"], d["test_solve_KKT_sigma"],
+                       np.full(m, d["test_solve_KKT_rho"]))
+    assert s.status == 0 and s.type == 20
+    x = s.solve(d["test_solve_KKT_rhs"])
+    assert np.max(np.abs(x - d["test_solve_KKT_x"])) < TESTS_TOL
+    assert np.max(np.abs(x - d["test_solve_KKT_x"])) < 1e-10
+    s.free()
+
+
+def test_legacy_vtable_polish_and_updates(R):
+    d = load_golden("update_matrices")["data"]
+    P, A = d["test_form_KKT_Pu"], d["test_form_KKT_A"]
+    n, m = d["test_form_KKT_n"], d["test_form_KKT_m"]
+    rhs = np.random.default_rng(1).standard_normal(n + m)
+    # polish=1: raw KKT solution with delta on the (2,2) block (qdldl_interface.c:254-265, :563-565)
+    s = R.HipLDLSolver(P, A, 1e-3, None, polish=1)
+    assert s.status == 0
+    x = s.solve(rhs)
+    K = full_kkt(P, A, 1e-3, np.full(m, 1e3))
+    assert np.max(np.abs(K @ x - rhs)) < 1e-9
+    s.free()
+    # update_matrices / update_rho_vec through the vtable == fresh oracle factorisation
+    rho = np.full(m, d["test_form_KKT_rho"])
+    s = R.HipLDLSolver(P, A, d["test_form_KKT_sigma"], rho)
+    assert s.update_matrices(d["test_form_KKT_Pu_new"], d["test_form_KKT_A_new"]) == 0
+    rho2 = np.linspace(0.3, 3.0, m)
+    assert s.update_rho_vec(rho2) == 0
+    x = s.solve(rhs)
+    o = ob.OracleLinsys(d["test_form_KKT_Pu_new"], d["test_form_KKT_A_new"], d["test_form_KKT_sigma"], rho2)
+    assert relerr(x, o.solve(rhs)) < 1e-10
+    s.free()
+
+
+def test_non_cvx_init_error(R):
+    """tests/non_cvx/test_non_cvx.h:31-36: fewer than n positive pivots -> OSQP_NONCVX_ERROR (5), handle NULL."""
+    d = load_golden("non_cvx")
+    s = R.HipLDLSolver(d["P"], d["A"], 1e-6, np.full(d["m"], 0.1))
+    assert s.status == 5
+    s2 = R.HipLDLSolver(d["P"], d["A"], float(d["sols"]["sigma_new"]), np.full(d["m"], 0.1))
+    assert s2.status == 0
+    s2.free()
+
+
+# ------------------------------------------------------------------ batched factor / solve / updates ----
+@pytest.mark.parametrize("shape", [(20, 35, 0.2, 5), (50, 100, 0.15, 1000), (7, 0, 0.4, 3), (1, 1, 1.0, 9)])
+def test_batched_factor_and_solve_match_oracle(R, shape):
+    n, m, dens, pseed = shape
+    wl = R.workloads.SharedPatternQPs(n=n, m=m, density=dens, pattern_seed=pseed)
+    B = 6
+    Px, Ax, q, l, u = wl.values(B)
+    rho = 0.05 + np.random.default_rng(0).random((B, m))
+    ls = R.BatchLinsys(wl.P_pattern, wl.A_pattern, dev(Px), dev(Ax), 1e-6, dev(rho))
+    assert ls.status == 0
+    sym = ls.export_symbolic()
+    st = ls.factor_status()
+    assert (st == n).all()
+    rhs = np.random.default_rng(1).standard_normal((B, n + m))
+    sol = ls.solve(dev(rhs)).cpu().numpy()
+    for b in range(B):
+        P, qq, A, ll, uu = wl.instance(b)
+        o = ob.OracleLinsys(P, A, 1e-6, rho[b], perm=sym["perm"])
+        e = o.export()
+        for k in ("etree", "Lnz", "Lp", "Li"):
+            assert (e[k] == sym[k]).all(), k                      # integers: bit-exact
+        f = ls.export_factor(b)
+        assert relerr(f["Lx"], e["Lx"]) < 1e-12
+        assert np.max(np.abs(f["D"] - e["D"]) / np.abs(e["D"])) < 1e-12
+        assert np.max(np.abs(f["Dinv"] - e["Dinv"]) / np.abs(e["Dinv"])) < 1e-12
+        assert relerr(sol[b], o.solve(rhs[b])) < 1e-10
+        # identity P K P' = L D L' (quantities no reference test inspects)
+        N = n + m
+        K = full_kkt(P, A, 1e-6, rho[b]) if m else (sparse.csc_matrix(P) + sparse.triu(P, 1).T).toarray() + 1e-6 * np.eye(n)
+        Kp = K[np.ix_(sym["perm"], sym["perm"])]
+        Ld = dense_from_L(sym["Lp"], sym["Li"], f["Lx"], N)
+        assert np.max(np.abs(Ld @ np.diag(f["D"]) @ Ld.T - Kp)) <= 1e-12 * max(1.0, np.max(np.abs(K)))
+    ls.free()
+
+
+def test_batched_update_rho_vec_and_matrices_match_fresh_factorisation(R):
+    wl = R.workloads.SharedPatternQPs(n=20, m=35, density=0.2, pattern_seed=11)
+    B = 5
+    Px, Ax, q, l, u = wl.values(B)
+    Px2, Ax2, _, _, _ = wl.values(B, seed0=100)
+    rho = np.full((B, wl.m), 0.1)
+    rho2 = 0.05 + np.random.default_rng(3).random((B, wl.m))
+    ls = R.BatchLinsys(wl.P_pattern, wl.A_pattern, dev(Px), dev(Ax), 1e-6, dev(rho))
+    sym = ls.export_symbolic()
+    assert ls.update_rho_vec(dev(rho2)) == 0
+    fresh = R.BatchLinsys(wl.P_pattern, wl.A_pattern, dev(Px), dev(Ax), 1e-6, dev(rho2))
+    for b in range(B):
+        assert np.array_equal(ls.export_factor(b)["Lx"], fresh.export_factor(b)["Lx"])   # same kernel, same inputs
+    # masked update: only instances 1 and 3 move
+    mask = torch.tensor([0, 1, 0, 1, 0], dtype=torch.int32, device="cuda:0")
+    before = [ls.export_factor(b)["Lx"].copy() for b in range(B)]
+    assert ls.update_rho_vec(dev(rho), mask) == 0
+    for b in range(B):
+        now = ls.export_factor(b)["Lx"]
+        if b in (1, 3):
+            P, qq, A, ll, uu = wl.instance(b)
+            o = ob.OracleLinsys(P, A, 1e-6, rho[b], perm=sym["perm"])
+            assert relerr(now, o.export()["Lx"]) < 1e-12
+        else:
+            assert np.array_equal(now, before[b])
+    # update_matrices (qdldl_interface.c:590-602): new P and A values, same pattern
+    assert ls.update_rho_vec(dev(rho)) == 0
+    assert ls.update_matrices(dev(Px2), dev(Ax2)) == 0
+    rhs = np.random.default_rng(5).standard_normal((B, wl.n + wl.m))
+    sol = ls.solve(dev(rhs)).cpu().numpy()
+    for b in range(B):
+        P, qq, A, ll, uu = wl.instance(b, seed0=100)
+        o = ob.OracleLinsys(P, A, 1e-6, rho[b], perm=sym["perm"])
+        assert relerr(ls.export_factor(b)["Lx"], o.export()["Lx"]) < 1e-12
+        assert relerr(sol[b], o.solve(rhs[b])) < 1e-10
+    ls.free(); fresh.free()
+
+
+def test_batch_with_one_non_convex_instance_reports_it(R):
+    wl = R.workloads.SharedPatternQPs(n=10, m=12, density=0.3, pattern_seed=2)
+    Px, Ax, q, l, u = wl.values(4)
+    Px[2] = -Px[2]                       # indefinite P for instance 2
+    h = R.BatchLinsys(wl.P_pattern, wl.A_pattern, dev(Px), dev(Ax), 1e-6, dev(np.full((4, wl.m), 0.1)))
+    assert h.status == 5                 # RLDL_NONCVX_ERROR, handle not created (qdldl_interface.c:298-303)
+
+
+def test_user_permutation_and_large_problem_global_memory_path(R):
+    """nnzL + N above the LDS budget exercises the global-memory variants of factor / solve."""
+    wl = R.workloads.MPCStageQPs(N=12)
+    B = 3
+    Px, Ax, q, l, u = wl.values(B)
+    rho = np.full((B, wl.m), 0.1)
+    perm = R.workloads.stage_permutation(*wl.dims)
+    ls = R.BatchLinsys(wl.P_pattern, wl.A_pattern, dev(Px), dev(Ax), 1e-6, dev(rho), perm=perm)
+    assert ls.status == 0
+    d = ls.dims()
+    assert 8 * (d["nnzL"] + d["n"] + d["m"]) > 64 * 1024
+    sym = ls.export_symbolic()
+    assert (sym["perm"] == perm).all()
+    rhs = np.random.default_rng(2).standard_normal((B, wl.n + wl.m))
+    sol = ls.solve(dev(rhs)).cpu().numpy()
+    for b in range(B):
+        P, qq, A, ll, uu = wl.instance(b)
+        o = ob.OracleLinsys(P, A, 1e-6, rho[b], perm=perm)
+        assert relerr(ls.export_factor(b)["Lx"], o.export()["Lx"]) < 1e-11
+        assert relerr(sol[b], o.solve(rhs[b])) < 1e-9
+    ls.free()
+
+
+# ------------------------------------------------------------------ stage-recursive strategy ----
+def test_recursive_init_uses_closed_form_permutation_and_restart_equals_refactor(R):
+    wl = R.workloads.MPCStageQPs(N=6)
+    B = 4
+    Px, Ax, q, l, u = wl.values(B)
+    rho = np.full((B, wl.m), 0.1)
+    ls = R.BatchLinsys.recursive(wl.dims, wl.P_pattern, wl.A_pattern, dev(Px), dev(Ax), 1e-6, dev(rho))
+    assert ls.status == 0
+    sym = ls.export_symbolic()
+    assert (sym["perm"] == R.workloads.stage_permutation(*wl.dims)).all()      # bit-exact integers
+    for b in range(B):
+        P, qq, A, ll, uu = wl.instance(b)
+        K = full_kkt(P, A, 1e-6, rho[b])
+        Kp = K[np.ix_(sym["perm"], sym["perm"])]
+        f = ls.export_factor(b)
+        Ld = dense_from_L(sym["Lp"], sym["Li"], f["Lx"], wl.n + wl.m)
+        assert np.max(np.abs(Ld @ np.diag(f["D"]) @ Ld.T - Kp)) <= 1e-11 * np.max(np.abs(K))
+    # config 5: perturb P, A of stages >= k only; restart-from-stage must equal a full refactor
+    k = 3
+    rg = np.random.default_rng(7)
+    Px2 = Px * np.where(wl.P_stage >= k, 1 + 0.05 * rg.standard_normal(Px.shape), 1.0)
+    Ax2 = Ax * np.where((wl.A_stage >= k) & (Ax != -1.0), 1 + 0.05 * rg.standard_normal(Ax.shape), 1.0)
+    assert ls.update_from_stage(k, dev(Px2), dev(Ax2), None) == 0
+    full = R.BatchLinsys.recursive(wl.dims, wl.P_pattern, wl.A_pattern, dev(Px2), dev(Ax2), 1e-6, dev(rho))
+    rhs = np.random.default_rng(3).standard_normal((B, wl.n + wl.m))
+    s1 = ls.solve(dev(rhs)).cpu().numpy(); s2 = full.solve(dev(rhs)).cpu().numpy()
+    for b in range(B):
+        assert relerr(ls.export_factor(b)["Lx"], full.export_factor(b)["Lx"]) < 1e-12
+        assert relerr(ls.export_factor(b)["D"], full.export_factor(b)["D"]) < 1e-12
+    assert relerr(s1, s2) < 1e-10
+    # a rho change touches every constraint pivot: restart from stage 0 == update_rho_vec
+    rho2 = np.full((B, wl.m), 0.4)
+    assert ls.update_from_stage(0, None, None, dev(rho2)) == 0
+    assert full.update_rho_vec(dev(rho2)) == 0
+    for b in range(B):
+        assert relerr(ls.export_factor(b)["Lx"], full.export_factor(b)["Lx"]) < 1e-12
+    ls.free(); full.free()
+
+
+# ------------------------------------------------------------------ ADMM driver ----
+FIXED = dict(rho=0.1, sigma=1e-6, alpha=1.6, max_iter=200, check_termination=0, adaptive_rho=0, warm_start=0, scaling=0)
+
+
+def test_admm_200_fixed_iterations_match_oracle(R):
+    """Config 2 at oracle-sized batch: factor + 200 ADMM iterations, identical rho schedule."""
+    wl = R.workloads.SharedPatternQPs()           # n=50, m=100, density 0.15
+    B = 6
+    Px, Ax, q, l, u = wl.values(B)
+    w = R.OSQPBatch(wl.P_pattern, wl.A_pattern, dev(Px), dev(Ax), dev(q), dev(l), dev(u), **FIXED)
+    assert w.status == 0
+    r = w.solve()
+    perm = w.linsys().export_symbolic()["perm"]
+    for b in range(B):
+        P, qq, A, ll, uu = wl.instance(b)
+        ro = ob.OracleOSQP(P, qq, A, ll, uu, perm=perm, **FIXED).solve()
+        assert relerr(r["x"][b].cpu().numpy(), ro["x_iter"]) < 1e-8
+        assert relerr(r["y"][b].cpu().numpy(), ro["y_iter"]) < 1e-8
+        assert relerr(r["z"][b].cpu().numpy(), ro["z_iter"]) < 1e-8
+        assert int(r["status"][b]) == ro["status"] and int(r["iter"][b]) == ro["iter"] == 200
+        assert abs(float(r["pri_res"][b]) - ro["pri_res"]) < 1e-8 * max(1, ro["pri_res"])
+        assert abs(float(r["dua_res"][b]) - ro["dua_res"]) < 1e-8 * max(1, ro["dua_res"])
+        assert abs(float(r["obj"][b]) - ro["obj"]) < 1e-8 * max(1, abs(ro["obj"]))
+    w.cleanup()
+
+
+def test_admm_termination_and_adaptive_rho_match_oracle(R):
+    wl = R.workloads.SharedPatternQPs(n=20, m=30, density=0.25, pattern_seed=21)
+    B = 8
+    Px, Ax, q, l, u = wl.values(B)
+    l[:, :4] = u[:, :4] = 0.5 * (l[:, :4] + u[:, :4])          # some equality rows -> rho_vec is not uniform
+    u[:, 4] = 1e30; l[:, 5] = -1e30; l[:, 6] = -1e30; u[:, 6] = 1e30   # one-sided and free rows
+    kw = dict(rho=0.1, sigma=1e-6, alpha=1.6, max_iter=4000, check_termination=25, adaptive_rho=1,
+              adaptive_rho_interval=50, eps_abs=1e-5, eps_rel=1e-5, warm_start=0, scaling=0)
+    w = R.OSQPBatch(wl.P_pattern, wl.A_pattern, dev(Px), dev(Ax), dev(q), dev(l), dev(u), **kw)
+    r = w.solve()
+    perm = w.linsys().export_symbolic()["perm"]
+    for b in range(B):
+        P, qq, A, ll, uu = wl.instance(b)
+        ll = l[b]; uu = u[b]
+        ro = ob.OracleOSQP(P, qq, A, ll, uu, perm=perm, **kw).solve()
+        assert int(r["status"][b]) == ro["status"] == 1
+        assert int(r["iter"][b]) == ro["iter"], (b, int(r["iter"][b]), ro["iter"])
+        assert relerr(r["x"][b].cpu().numpy(), ro["x"]) < 1e-7
+        assert relerr(r["y"][b].cpu().numpy(), ro["y"]) < 1e-7
+    w.cleanup()
+
+
+def _solve_golden(R, P, q, A, l, u, reps=3, **kw):
+    """Run a reference fixture as a batch of `reps` identical instances."""
+    Pc, Ac = R.CscPattern(P, upper=True), R.CscPattern(A)
+    base = dict(eps_abs=1e-7, eps_rel=1e-7, max_iter=20000, check_termination=1, scaling=0, adaptive_rho=1,
+                adaptive_rho_interval=25)
+    base.update(kw)
+    tile = lambda v: dev(np.tile(np.asarray(v, float), (reps, 1)))
+    w = R.OSQPBatch(Pc, Ac, tile(Pc.x), tile(Ac.x), tile(q), tile(osqp_inf(l)), tile(osqp_inf(u)), **base)
+    return w
+
+
+def test_basic_qp_golden_and_updates(R):
+    d = load_golden("basic_qp"); s = d["sols"]
+    w = _solve_golden(R, d["P"], d["q"], d["A"], d["l"], d["u"])
+    assert w.status == 0
+    r = w.solve()
+    for b in range(3):
+        assert int(r["status"][b]) == 1
+        assert np.max(np.abs(r["x"][b].cpu().numpy() - s["x_test"])) < TESTS_TOL
+        assert np.max(np.abs(r["y"][b].cpu().numpy() - s["y_test"])) < TESTS_TOL
+        assert abs(float(r["obj"][b]) - s["obj_value_test"]) < TESTS_TOL
+    # osqp_update_lin_cost + osqp_update_bounds (test_basic_qp.h:88-240) vs a fresh oracle solve
+    tile = lambda v: dev(np.tile(np.asarray(v, float), (3, 1)))
+    assert w.update_lin_cost(tile(s["q_new"])) == 0
+    assert w.update_bounds(tile(osqp_inf(s["l_new"])), tile(osqp_inf(s["u_new"]))) == 0
+    r = w.solve()
+    ro = ob.OracleOSQP(d["P"], s["q_new"], d["A"], osqp_inf(s["l_new"]), osqp_inf(s["u_new"]), eps_abs=1e-7, eps_rel=1e-7,
+                       max_iter=20000, check_termination=1, scaling=0, adaptive_rho=1, adaptive_rho_interval=25).solve()
+    assert int(r["status"][0]) == ro["status"] == 1
+    assert np.max(np.abs(r["x"][0].cpu().numpy() - ro["x"])) < TESTS_TOL
+    assert np.max(np.abs(r["y"][0].cpu().numpy() - ro["y"])) < TESTS_TOL
+    w.cleanup()
+
+
+def test_basic_qp_update_rho_same_iteration_count(R):
+    """tests/basic_qp/test_basic_qp.h:651-779."""
+    d = load_golden("basic_qp")
+    kw = dict(adaptive_rho=0, eps_abs=5e-5, eps_rel=5e-5, check_termination=1, max_iter=4000)
+    a = _solve_golden(R, d["P"], d["q"], d["A"], d["l"], d["u"], rho=0.7, **kw)
+    ra = a.solve()
+    b = _solve_golden(R, d["P"], d["q"], d["A"], d["l"], d["u"], rho=0.1, warm_start=0, **kw)
+    b.solve()
+    assert b.update_rho(0.7) == 0
+    rb = b.solve()
+    assert int(ra["iter"][0]) == int(rb["iter"][0]) > 0
+    assert np.max(np.abs(ra["x"][0].cpu().numpy() - rb["x"][0].cpu().numpy())) < 1e-9
+    a.cleanup(); b.cleanup()
+
+
+def test_update_matrices_golden(R):
+    """tests/update_matrices/test_update_matrices.h:74-313 (osqp_update_P / _A / _P_A known answers)."""
+    d = load_golden("update_matrices")["data"]
+    w = _solve_golden(R, d["test_solve_Pu"], d["test_solve_q"], d["test_solve_A"], d["test_solve_l"], d["test_solve_u"], reps=2)
+    r = w.solve()
+    assert int(r["status"][0]) == 1
+    assert np.max(np.abs(r["x"][0].cpu().numpy() - d["test_solve_x"])) < TESTS_TOL
+    assert abs(float(r["obj"][0]) - d["test_solve_obj_value"]) < TESTS_TOL
+    Pn = sparse.csc_matrix(d["test_solve_Pu_new"]); Pn.sort_indices()
+    An = sparse.csc_matrix(d["test_solve_A_new"]); An.sort_indices()
+    tile = lambda v: dev(np.tile(np.asarray(v, float), (2, 1)))
+    assert w.update_P_A(Px=tile(Pn.data)) == 0
+    r = w.solve()
+    assert np.max(np.abs(r["x"][1].cpu().numpy() - d["test_solve_P_new_x"])) < TESTS_TOL
+    assert abs(float(r["obj"][1]) - d["test_solve_P_new_obj_value"]) < TESTS_TOL
+    assert w.update_P_A(Px=tile(Pn.data), Ax=tile(An.data)) == 0
+    r = w.solve()
+    assert np.max(np.abs(r["x"][0].cpu().numpy() - d["test_solve_P_A_new_x"])) < TESTS_TOL
+    assert abs(float(r["obj"][0]) - d["test_solve_P_A_new_obj_value"]) < TESTS_TOL
+    w.cleanup()
+
+
+def test_unconstrained_and_infeasibility_golden(R):
+    d = load_golden("unconstrained"); s = d["sols"]
+    w = _solve_golden(R, d["P"], d["q"], d["A"], d["l"], d["u"], reps=2)
+    r = w.solve()
+    assert int(r["status"][0]) == 1
+    assert np.max(np.abs(r["x"][0].cpu().numpy() - s["x_test"])) < TESTS_TOL
+    assert abs(float(r["obj"][0]) - s["obj_value_test"]) < TESTS_TOL
+    w.cleanup()
+    g = load_golden("primal_dual_infeasibility")["data"]
+    cases = [("A12", "u1", (1,)), ("A12", "u2", (-3,)), ("A34", "u3", (-4,)), ("A34", "u4", (-3, -4))]
+    for Ak, uk, ok in cases:
+        w = _solve_golden(R, g["P"], g["q"], g[Ak], g["l"], g[uk], reps=2, eps_abs=1e-6, eps_rel=1e-6, max_iter=2000,
+                          check_termination=25)
+        r = w.solve()
+        assert int(r["status"][0]) in ok, (Ak, uk, int(r["status"][0]))
+        if ok == (1,):
+            assert np.max(np.abs(r["x"][0].cpu().numpy() - g["x1"])) < TESTS_TOL
+            assert np.max(np.abs(r["y"][0].cpu().numpy() - g["y1"])) < TESTS_TOL
+            assert abs(float(r["obj"][0]) - g["obj_value1"]) < TESTS_TOL
+        w.cleanup()
+    # non-convex divergence -> OSQP_NON_CVX with obj == OSQP_NAN (test_non_cvx.h:53-58)
+    d = load_golden("non_cvx")
+    w = _solve_golden(R, d["P"], d["q"], d["A"], d["l"], d["u"], reps=2, sigma=float(d["sols"]["sigma_new"]),
+                      eps_abs=1e-3, eps_rel=1e-3, max_iter=4000, check_termination=25, adaptive_rho_interval=100)
+    r = w.solve()
+    assert int(r["status"][0]) == -7 and float(r["obj"][0]) == float(0x7fc00000)
+    w.cleanup()
+
+
+def test_warm_start_converges_immediately(R):
+    wl = R.workloads.SharedPatternQPs(n=15, m=20, density=0.3, pattern_seed=4)
+    B = 4
+    Px, Ax, q, l, u = wl.values(B)
+    kw = dict(eps_abs=1e-6, eps_rel=1e-6, check_termination=1, adaptive_rho=0, scaling=0, max_iter=20000)
+    w = R.OSQPBatch(wl.P_pattern, wl.A_pattern, dev(Px), dev(Ax), dev(q), dev(l), dev(u), **kw)
+    r = w.solve()
+    assert (r["status"] == 1).all()
+    it0 = r["iter"].clone()
+    w2 = R.OSQPBatch(wl.P_pattern, wl.A_pattern, dev(Px), dev(Ax), dev(q), dev(l), dev(u), **kw)
+    assert w2.warm_start(r["x"], r["y"]) == 0
+    r2 = w2.solve()
+    assert (r2["status"] == 1).all() and (r2["iter"] <= torch.clamp(it0 // 4, min=2)).all()
+    w.cleanup(); w2.cleanup()
+
+
+# ------------------------------------------------------------------ full-size properties (BASELINE sizes) ----
+def test_full_size_batch_4096_properties(R):
+    """Metric shape n=50, m=100, batch=4096: size-independent properties instead of an oracle sweep."""
+    wl = R.workloads.SharedPatternQPs()
+    B = 4096
+    Px, Ax, q, l, u = wl.values(B)
+    rho = np.full((B, wl.m), 0.1)
+    dPx, dAx = dev(Px), dev(Ax)
+    ls = R.BatchLinsys(wl.P_pattern, wl.A_pattern, dPx, dAx, 1e-6, dev(rho))
+    assert ls.status == 0 and (ls.factor_status() == wl.n).all()
+    N = wl.n + wl.m
+    g = torch.Generator(device="cuda:0"); g.manual_seed(0)
+    rhs = torch.randn((B, N), dtype=torch.float64, device="cuda:0", generator=g)
+    sol = ls.solve(rhs.clone())
+    # (1) linearity: solve(a*r1 + r2) == a*solve(r1) + solve(r2) on the x-part
+    r2 = torch.randn((B, N), dtype=torch.float64, device="cuda:0", generator=g)
+    s2 = ls.solve(r2.clone())
+    s3 = ls.solve((2.5 * rhs + r2).clone())
+    assert float((s3[:, :wl.n] - (2.5 * sol[:, :wl.n] + s2[:, :wl.n])).abs().max()) < 1e-7
+    # (2) residual K * raw = rhs on a spread sample of instances (raw nu recovered from the epilogue)
+    for b in range(0, B, 257):
+        P, qq, A, ll, uu = wl.instance(b)
+        K = full_kkt(P, A, 1e-6, rho[b])
+        out = sol[b].cpu().numpy(); r = rhs[b].cpu().numpy()
+        raw = np.concatenate([out[:wl.n], (out[wl.n:] - r[wl.n:]) * rho[b]])
+        assert np.max(np.abs(K @ raw - r)) < 1e-8 * max(1.0, np.max(np.abs(raw)))
+    # (3) refactor idempotence: update_matrices with the same values reproduces L bit for bit
+    f0 = ls.export_factor(1234)["Lx"].copy()
+    assert ls.update_matrices(dPx, dAx) == 0
+    assert np.array_equal(ls.export_factor(1234)["Lx"], f0)
+    # (4) every instance of the batch equals the same instance solved in a batch of its own
+    one = R.BatchLinsys(wl.P_pattern, wl.A_pattern, dPx[4095:4096].contiguous(), dAx[4095:4096].contiguous(), 1e-6,
+                        dev(rho[4095:4096]))
+    assert np.array_equal(one.export_factor(0)["Lx"], ls.export_factor(4095)["Lx"])
+    ls.free(); one.free()
+    # (5) fused ADMM at full batch: all instances reach the fixed iteration count and identical
+    #     instances give identical results (batch position must not matter)
+    qd, ld, ud = dev(q), dev(l), dev(u)
+    dPx[1] = dPx[0]; dAx[1] = dAx[0]; qd[1] = qd[0]; ld[1] = ld[0]; ud[1] = ud[0]
+    dPx[4095] = dPx[0]; dAx[4095] = dAx[0]; qd[4095] = qd[0]; ld[4095] = ld[0]; ud[4095] = ud[0]
+    w = R.OSQPBatch(wl.P_pattern, wl.A_pattern, dPx, dAx, qd, ld, ud, **FIXED)
+    r = w.solve()
+    assert (r["iter"] == 200).all()
+    assert torch.equal(r["x"][0], r["x"][1]) and torch.equal(r["x"][0], r["x"][4095])
+    assert bool(torch.isfinite(r["x"]).all())
+    w.cleanup()

@@ -1,0 +1,177 @@
+"""CPU tests (no GPU): the product's host-side symbolic analysis against the oracle and against
+independent numpy/scipy restatements; C-ABI surface; loud failure without a device.
+
+Integer quantities are compared EXACTLY (permutation given, etree, Lnz, Lp, Li, KKT pattern, maps).
+"""
+import ctypes as C
+import re
+import os
+
+import numpy as np
+import pytest
+from scipy import sparse
+
+import oracle_bindings as ob
+from helpers import dense_symbolic, full_kkt, load_golden
+
+import osqp_recursive_ldl_amd as R
+from osqp_recursive_ldl_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_abi_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "osqp_rldl_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = set(re.findall(r"\b([A-Za-z0-9_]*(?:hipldl|rldl_|osqp_batch)[A-Za-z0-9_]*)\s*\(", hdr))
+    names = {n for n in names if not n.startswith("c_")}
+    assert len(names) >= 30
+    L = C.CDLL(_lib.LIB_PATH)
+    missing = [n for n in sorted(names) if not hasattr(L, n)]
+    assert not missing, missing
+    assert set(_lib.EXPORTED) <= names | {"rldl_version"}
+    assert b"gfx950" in R.lib().rldl_version()
+
+
+def test_struct_prefix_matches_linsys_solver_layout():
+    """include/types.h:298-319: type, solve, free, update_matrices, update_rho_vec, nthreads -- in this order."""
+    f = [n for n, _ in _lib.HipldlSolver._fields_]
+    assert f[:6] == ["type", "solve", "free", "update_matrices", "update_rho_vec", "nthreads"]
+    assert _lib.HipldlSolver.solve.offset == 8 and _lib.HipldlSolver.nthreads.offset == 40
+
+
+def _problem(seed, n=20, m=35, density=0.2):
+    wl = R.workloads.SharedPatternQPs(n=n, m=m, density=density, pattern_seed=seed)
+    return wl, wl.instance(0)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_symbolic_matches_oracle_given_the_same_permutation(seed):
+    wl, (P, q, A, l, u) = _problem(seed)
+    n, m = wl.n, wl.m
+    s = R.symbolic_analyze(wl.P_pattern, wl.A_pattern)
+    perm = s["perm"]
+    assert sorted(perm.tolist()) == list(range(n + m))
+    o = ob.OracleLinsys(P, A, 1e-6, np.full(m, 0.1), perm=perm)
+    e = o.export()
+    assert (e["P"] == perm).all()
+    assert (e["etree"] == s["etree"]).all()
+    assert (e["Lnz"] == s["Lnz"]).all()
+    assert (e["Lp"] == s["Lp"]).all()
+    assert (e["Li"] == s["Li"]).all()
+    # KKT pattern: the oracle's csc_symperm output has the same entries per column (rows unsorted there)
+    Kp, Ki, Kx = o.export_KKT()
+    assert (Kp == s["KKTp"]).all()
+    for j in range(n + m):
+        assert sorted(Ki[Kp[j]:Kp[j + 1]].tolist()) == s["KKTi"][Kp[j]:Kp[j + 1]].tolist()
+    # independent dense symbolic factorisation
+    K = full_kkt(P, A, 1e-6, np.full(m, 0.1))
+    Kperm = K[np.ix_(perm, perm)]
+    et, Lnz, cols = dense_symbolic(np.triu(Kperm != 0))
+    assert (et == s["etree"]).all() and (Lnz == s["Lnz"]).all()
+
+
+@pytest.mark.parametrize("seed", [4, 5])
+def test_scatter_maps_rebuild_the_permuted_kkt(seed):
+    wl, (P, q, A, l, u) = _problem(seed, n=12, m=18, density=0.3)
+    n, m = wl.n, wl.m
+    sigma, rho = 0.37, np.linspace(0.5, 2.0, m)
+    s = R.symbolic_analyze(wl.P_pattern, wl.A_pattern)
+    Kx = np.zeros(s["nnzKKT"])
+    Pd, Ad = sparse.csc_matrix(P), sparse.csc_matrix(A)
+    Pd.sort_indices(); Ad.sort_indices()
+    cols = np.repeat(np.arange(n), np.diff(Pd.indptr))
+    Kx[:] = np.nan
+    Kx[s["PtoKKT"]] = Pd.data + sigma * (Pd.indices == cols)
+    Kx[s["AtoKKT"]] = Ad.data
+    Kx[s["rhotoKKT"]] = -1.0 / rho
+    Kx[np.isnan(Kx)] = sigma                       # sigma-only slots (P columns without a stored diagonal)
+    Kdense = np.zeros((n + m, n + m))
+    for j in range(n + m):
+        for p in range(s["KKTp"][j], s["KKTp"][j + 1]):
+            i = s["KKTi"][p]
+            assert i <= j
+            Kdense[i, j] = Kx[p]
+    Kdense = Kdense + np.triu(Kdense, 1).T
+    K = full_kkt(P, A, sigma, rho)
+    perm = s["perm"]
+    assert np.max(np.abs(Kdense - K[np.ix_(perm, perm)])) == 0.0
+
+
+def test_form_kkt_pattern_against_reference_fixture():
+    """tests/update_matrices fixture (reference generator): with the identity permutation the product's
+    KKT pattern must be exactly triu of the fixture's KKT (test_update_matrices.h:37-48)."""
+    d = load_golden("update_matrices")["data"]
+    n, m = d["test_form_KKT_n"], d["test_form_KKT_m"]
+    s = R.symbolic_analyze(d["test_form_KKT_Pu"], d["test_form_KKT_A"], perm=np.arange(n + m))
+    ref = sparse.csc_matrix(d["test_form_KKT_KKTu"]); ref.sort_indices()
+    assert (s["KKTp"] == ref.indptr).all() and (s["KKTi"] == ref.indices).all()
+    Pu = sparse.csc_matrix(d["test_form_KKT_Pu"]); Pu.sort_indices()
+    A = sparse.csc_matrix(d["test_form_KKT_A"]); A.sort_indices()
+    cols = np.repeat(np.arange(n), np.diff(Pu.indptr))
+    Kx = np.full(s["nnzKKT"], np.nan)
+    Kx[s["PtoKKT"]] = Pu.data + d["test_form_KKT_sigma"] * (Pu.indices == cols)
+    Kx[s["AtoKKT"]] = A.data
+    Kx[s["rhotoKKT"]] = -1.0 / d["test_form_KKT_rho"]
+    Kx[np.isnan(Kx)] = d["test_form_KKT_sigma"]
+    assert np.max(np.abs(Kx - ref.data)) < 1e-14
+
+
+def test_user_permutation_is_respected_and_validated():
+    wl, (P, q, A, l, u) = _problem(6, n=8, m=10, density=0.3)
+    N = wl.n + wl.m
+    perm = np.random.default_rng(0).permutation(N)
+    s = R.symbolic_analyze(wl.P_pattern, wl.A_pattern, perm=perm)
+    assert (s["perm"] == perm).all()
+    bad = perm.copy(); bad[0] = bad[1]
+    with pytest.raises(ValueError):
+        R.symbolic_analyze(wl.P_pattern, wl.A_pattern, perm=bad)
+
+
+def test_rejects_lower_triangular_P():
+    P = sparse.csc_matrix(np.array([[1.0, 0.0], [0.5, 1.0]]))
+    A = sparse.csc_matrix(np.array([[1.0, 1.0]]))
+    with pytest.raises(ValueError):
+        R.symbolic_analyze(P, A)
+
+
+def test_min_degree_reduces_fill_on_metric_shape():
+    wl = R.workloads.SharedPatternQPs()          # n=50, m=100, density 0.15
+    s = R.symbolic_analyze(wl.P_pattern, wl.A_pattern)
+    nat = R.symbolic_analyze(wl.P_pattern, wl.A_pattern, perm=np.arange(150))
+    assert s["nnzL"] < 0.5 * nat["nnzL"]
+    assert 1500 < s["nnzL"] < 2600               # ~1970 with AMD on this shape
+    assert s["etree_height"] <= 60
+
+
+def test_stage_permutation_closed_form():
+    for dims in [(20, 12, 4, 10, 12), (3, 2, 1, 2, 2), (1, 3, 2, 1, 3)]:
+        N, nx, nu, ny, nt = dims
+        tot = N * (nx + nu) + N * (nx + ny) + nt
+        perm = np.zeros(tot, np.int64)
+        R.lib().rldl_stage_permutation(N, nx, nu, ny, nt, perm.ctypes.data_as(_lib.IP))
+        assert (perm == R.workloads.stage_permutation(*dims)).all()
+        assert sorted(perm.tolist()) == list(range(tot))
+
+
+def test_mpc_stage_order_gives_block_tridiagonal_band():
+    wl = R.workloads.MPCStageQPs(N=5)
+    perm = R.workloads.stage_permutation(*wl.dims)
+    s = R.symbolic_analyze(wl.P_pattern, wl.A_pattern, perm=perm)
+    # every L column reaches at most into the next two stage blocks
+    band = max((s["Li"][s["Lp"][j]:s["Lp"][j + 1]].max() - j) for j in range(wl.n + wl.m) if s["Lnz"][j])
+    assert band <= 2 * (wl.nx + wl.ny) + wl.nx + wl.nu
+    assert s["etree_height"] > 0
+
+
+def test_compute_entry_points_fail_loudly_without_a_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    wl, (P, q, A, l, u) = _problem(1, n=5, m=6)
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        R.HipLDLSolver(P, A, 1e-6, np.full(wl.m, 0.1))
+    h = C.c_void_p()
+    Pc, Ac = R.CscPattern(wl.P_pattern), R.CscPattern(wl.A_pattern)
+    rc = R.lib().rldl_batch_init(C.byref(h), 1, Pc.ref, Ac.ref, None, None, 1e-6, None, 0, None, None)
+    assert rc == _lib.RLDL_NO_DEVICE_ERROR and not h.value
