@@ -168,7 +168,7 @@ def test_batch_with_one_non_convex_instance_reports_it(R):
 
 def test_user_permutation_and_large_problem_global_memory_path(R):
     """nnzL + N above the LDS budget exercises the global-memory variants of factor / solve."""
-    wl = R.workloads.MPCStageQPs(N=12)
+    wl = R.workloads.MPCStageQPs(N=20)
     B = 3
     Px, Ax, q, l, u = wl.values(B)
     rho = np.full((B, wl.m), 0.1)
