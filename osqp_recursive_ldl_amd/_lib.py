@@ -163,6 +163,13 @@ def lib():
             raise RuntimeError(
                 "libosqp_rldl_hip.so is not built (%s); run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C osqp_recursive_ldl_amd/csrc`.  There is no CPU fallback." % LIB_PATH)
+        try:
+            # PyTorch-ROCm wheels bundle their own libamdhip64/libhsa-runtime64.  Two HIP runtimes in one
+            # process cannot both open the device, so torch's copy must be the one already loaded when our
+            # library's DT_NEEDED libamdhip64.so.7 is resolved (it is then reused by soname).
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         missing = [s for s in EXPORTED if not hasattr(L, s)]
         if missing:
