@@ -56,6 +56,16 @@ static int upload_symbolic(rldl_batch *h) {
   UP(KtoW, s->nnzK, int); UP(Udst, s->npairs, int); UP(Uab, s->npairs, unsigned int); UP(Up, s->N + 1, long long);
   UP(Pp, s->n + 1, int); UP(Pi, s->nnzP, int); UP(Prp, s->n + 1, int); UP(Prj, s->nnzP, int); UP(Prpos, s->nnzP, int);
   UP(Ap, s->n + 1, int); UP(Ai, s->nnzA, int); UP(Arp, s->m + 1, int); UP(Arj, s->nnzA, int); UP(Arpos, s->nnzA, int);
+  UP(LtoS, s->nnzL, int);
+  D->plan = (const int *)dev_upload(s->plan, sizeof(int) * (size_t)(s->plan_ok ? ((s->plan_words + 3) & ~3) : 0), &ok); /* blob is calloc'ed with 4 words of slack */
+  D->ldF = (s->nS + s->N + 1) & ~1;
+  D->dbg = getenv("RLDL_DBG") ? atoi(getenv("RLDL_DBG")) : 0;
+  D->nS = s->nS; D->nO = s->nO; D->ngroups = s->ngroups; D->plan_ok = s->plan_ok; D->plan_words = s->plan_ok ? s->plan_words : 0;
+  D->po_gstart = s->po_gstart; D->po_gflag = s->po_gflag; D->po_gaptr = s->po_gaptr; D->po_grptr = s->po_grptr;
+  D->po_gToff = s->po_gToff; D->po_fsp = s->po_fsp; D->po_bsp = s->po_bsp; D->po_acol = s->po_acol; D->po_aoff = s->po_aoff;
+  D->po_arow = s->po_arow; D->po_coloff = s->po_coloff; D->po_fsb = s->po_fsb; D->po_fsc = s->po_fsc; D->po_bsb = s->po_bsb;
+  D->po_bsc = s->po_bsc; D->po_fsig = s->po_fsig; D->po_bsig = s->po_bsig; D->po_fcol = s->po_fcol; D->po_brs = s->po_brs;
+  D->po_perm = s->po_perm;
 #undef UP
   return ok ? 0 : -1;
 }
@@ -64,7 +74,7 @@ static void free_dev_symbolic(rldl_dev_sym *D) {
 #define FR(f) if (D->f) (void)hipFree((void *)D->f)
   FR(perm); FR(PtoK); FR(AtoK); FR(rhotoK); FR(sigK); FR(Pisdiag); FR(Lp); FR(Li); FR(Rp); FR(Rj); FR(Rpos);
   FR(KtoW); FR(Udst); FR(Uab); FR(Up); FR(Pp); FR(Pi); FR(Prp); FR(Prj); FR(Prpos); FR(Ap); FR(Ai); FR(Arp);
-  FR(Arj); FR(Arpos);
+  FR(Arj); FR(Arpos); FR(LtoS); FR(plan);
 #undef FR
   memset(D, 0, sizeof(*D));
 }
@@ -74,8 +84,8 @@ void rldl_batch_free(rldl_batch *h) {
   if (h->stream_owned && h->stream) (void)hipStreamSynchronize((hipStream_t)h->stream);
   free_dev_symbolic(&h->dsym);
   if (h->num.Kx) (void)hipFree(h->num.Kx);
-  if (h->num.LD) (void)hipFree(h->num.LD);
-  if (h->num.Dinv) (void)hipFree(h->num.Dinv);
+  if (h->num.F) (void)hipFree(h->num.F);
+  if (h->num.D) (void)hipFree(h->num.D);
   if (h->num.rho_inv) (void)hipFree(h->num.rho_inv);
   if (h->num.status) (void)hipFree(h->num.status);
   if (h->ev0) (void)hipEventDestroy((hipEvent_t)h->ev0);
@@ -119,8 +129,10 @@ static c_int batch_create(rldl_batch **hp, c_int batch, const csc *P, const csc 
   if (upload_symbolic(h)) { rldl_batch_free(h); return RLDL_MEM_ALLOC_ERROR; }
   h->num.batch = (int)batch; h->num.sigma = sigma;
   h->num.Kx = (double *)dev_alloc(sizeof(double) * (size_t)batch * (size_t)h->sym->nnzK, &ok);
-  h->num.LD = (double *)dev_alloc(sizeof(double) * (size_t)batch * (size_t)(h->sym->nnzL + h->sym->N), &ok);
-  h->num.Dinv = (double *)dev_alloc(sizeof(double) * (size_t)batch * (size_t)h->sym->N, &ok);
+  h->num.F = (double *)dev_alloc(sizeof(double) * (size_t)batch * (size_t)h->dsym.ldF, &ok);
+  h->num.D = (double *)dev_alloc(sizeof(double) * (size_t)batch * (size_t)h->sym->N, &ok);
+  /* padding slots of the plan's dense triangles are never written by the factor kernel: zero them once */
+  if (ok && !HIP_OK(hipMemset(h->num.F, 0, sizeof(double) * (size_t)batch * (size_t)h->dsym.ldF))) ok = 0;
   h->num.rho_inv = (double *)dev_alloc(sizeof(double) * (size_t)batch * (size_t)h->sym->m, &ok);
   h->num.status = (int *)dev_alloc(sizeof(int) * (size_t)batch, &ok);
   h->status_host = (int *)calloc((size_t)batch, sizeof(int));
@@ -213,6 +225,26 @@ c_int rldl_symbolic_analyze(const csc *P, const csc *A, c_int polish, const c_in
   return 0;
 }
 
+/* Host-only export of the solve plan (tests emulate the device schedule on the CPU with it).
+ * meta[0..23] = {plan_ok, nS, nO, ngroups, plan_words, po_gstart, po_gflag, po_gToff, po_fsp, po_bsp, po_fsb, po_fsc,
+ *                po_bsb, po_bsc, po_fsig, po_bsig, po_fcol, po_brs, po_perm, N, nnzL, 0...}; blob/LtoS may be NULL. */
+c_int rldl_plan_export(const csc *P, const csc *A, c_int polish, const c_int *perm_in, c_int *meta, int *blob, c_int blob_cap,
+                       c_int *LtoS) {
+  rldl_symbolic *s = 0;
+  c_int i;
+  if (!P || !A || !meta) return 1;
+  if (rldl_symbolic_create(&s, P->n, A->m, P->p, P->i, A->p, A->i, polish != 0, perm_in)) return RLDL_LINSYS_SOLVER_INIT_ERROR;
+  for (i = 0; i < 24; i++) meta[i] = 0;
+  meta[0] = s->plan_ok; meta[1] = s->nS; meta[2] = s->nO; meta[3] = s->ngroups; meta[4] = s->plan_ok ? s->plan_words : 0;
+  meta[5] = s->po_gstart; meta[6] = s->po_gflag; meta[7] = s->po_gToff; meta[8] = s->po_fsp; meta[9] = s->po_bsp;
+  meta[10] = s->po_fsb; meta[11] = s->po_fsc; meta[12] = s->po_bsb; meta[13] = s->po_bsc; meta[14] = s->po_fsig;
+  meta[15] = s->po_bsig; meta[16] = s->po_fcol; meta[17] = s->po_brs; meta[18] = s->po_perm; meta[19] = s->N; meta[20] = s->nnzL;
+  if (blob && s->plan_ok && blob_cap >= s->plan_words) memcpy(blob, s->plan, sizeof(int) * (size_t)s->plan_words);
+  if (LtoS) for (i = 0; i < s->nnzL; i++) LtoS[i] = s->LtoS[i];
+  rldl_symbolic_free(s);
+  return 0;
+}
+
 c_int rldl_batch_export_symbolic(const rldl_batch *h, c_int *perm, c_int *etree, c_int *Lnz, c_int *Lp, c_int *Li,
                                  c_int *KKTp, c_int *KKTi, c_int *PtoKKT, c_int *AtoKKT, c_int *rhotoKKT) {
   const rldl_symbolic *s;
@@ -224,14 +256,20 @@ c_int rldl_batch_export_symbolic(const rldl_batch *h, c_int *perm, c_int *etree,
 
 c_int rldl_batch_export_factor(const rldl_batch *h, c_int inst, c_float *Lx, c_float *D, c_float *Dinv, c_float *KKTx) {
   const rldl_symbolic *s;
-  size_t nW;
+  size_t nF;
+  double *tmp;
+  int p;
   if (!h || inst < 0 || inst >= h->batch) return 1;
   s = h->sym;
-  nW = (size_t)(s->nnzL + s->N);
+  nF = (size_t)h->dsym.ldF;
   if (!HIP_OK(hipStreamSynchronize((hipStream_t)h->stream))) return 1;
-  if (Lx && s->nnzL && !HIP_OK(hipMemcpy(Lx, h->num.LD + (size_t)inst * nW, sizeof(double) * (size_t)s->nnzL, hipMemcpyDeviceToHost))) return 1;
-  if (D && !HIP_OK(hipMemcpy(D, h->num.LD + (size_t)inst * nW + s->nnzL, sizeof(double) * (size_t)s->N, hipMemcpyDeviceToHost))) return 1;
-  if (Dinv && !HIP_OK(hipMemcpy(Dinv, h->num.Dinv + (size_t)inst * s->N, sizeof(double) * (size_t)s->N, hipMemcpyDeviceToHost))) return 1;
+  tmp = (double *)malloc(sizeof(double) * (nF ? nF : 1));
+  if (!tmp) return 1;
+  if (!HIP_OK(hipMemcpy(tmp, h->num.F + (size_t)inst * nF, sizeof(double) * nF, hipMemcpyDeviceToHost))) { free(tmp); return 1; }
+  if (Lx) for (p = 0; p < s->nnzL; p++) Lx[p] = tmp[s->LtoS[p]];       /* back to CSC order */
+  if (Dinv) memcpy(Dinv, tmp + s->nS, sizeof(double) * (size_t)s->N);
+  free(tmp);
+  if (D && !HIP_OK(hipMemcpy(D, h->num.D + (size_t)inst * s->N, sizeof(double) * (size_t)s->N, hipMemcpyDeviceToHost))) return 1;
   if (KKTx && !HIP_OK(hipMemcpy(KKTx, h->num.Kx + (size_t)inst * s->nnzK, sizeof(double) * (size_t)s->nnzK, hipMemcpyDeviceToHost))) return 1;
   return 0;
 }

@@ -20,6 +20,14 @@ typedef struct {
   const unsigned int *Uab;
   const long long *Up;
   const int *Pp, *Pi, *Prp, *Prj, *Prpos, *Ap, *Ai, *Arp, *Arj, *Arpos;
+  /* factor storage layout + grouped solve plan (rldl_plan.c) */
+  const int *LtoS;             /* [nnzL] CSC position -> storage slot */
+  const int *plan;             /* packed blob, plan_words int32 */
+  int nS, nO, ngroups, plan_ok, plan_words;
+  int dbg;                     /* timing experiments only (env RLDL_DBG): bit mask of phases to skip; 0 in production */
+  int ldF;                     /* row stride of rldl_dev_num.F in doubles: nS + N rounded up to even (16-byte rows) */
+  int po_gstart, po_gflag, po_gaptr, po_grptr, po_gToff, po_fsp, po_bsp, po_acol, po_aoff, po_arow, po_coloff, po_fsb,
+      po_fsc, po_bsb, po_bsc, po_fsig, po_bsig, po_fcol, po_brs, po_perm;
 } rldl_dev_sym;
 
 /* per-batch numeric state of the linear-system backend (DEVICE pointers, instance-major) */
@@ -27,8 +35,8 @@ typedef struct {
   int batch;
   double sigma;
   double *Kx;       /* [batch][nnzK]   permuted KKT values                     */
-  double *LD;       /* [batch][nnzL+N] L values (CSC order) followed by D      */
-  double *Dinv;     /* [batch][N]                                              */
+  double *F;        /* [batch][ldF]    factor in plan slot order (nS), then Dinv (N): what `solve` streams */
+  double *D;        /* [batch][N]      pivots (inertia check, export)           */
   double *rho_inv;  /* [batch][m]      param2 of the KKT (delta when polishing) */
   int *status;      /* [batch]         #positive pivots, or -1 on a zero pivot */
 } rldl_dev_num;

@@ -15,6 +15,8 @@
 //   k_set_rho_vec  : set_rho_vec / update_rho_vec      src/auxil.c:79-145
 //   k_finalize     : tail of osqp_solve                src/osqp.c:541-641, store_solution src/auxil.c:527-565
 #include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
 
 #include "rldl_device.h"
 
@@ -97,33 +99,41 @@ __global__ __launch_bounds__(WAVE) void k_factor(rldl_dev_sym S, rldl_dev_num Nn
   extern __shared__ double sh[];
   const int lane = threadIdx.x;
   const int nW = S.nnzL + S.N;
-  double *out = Nn.LD + (size_t)inst * nW;
-  double *W = USE_LDS ? sh : out;
+  double *F = Nn.F + (size_t)inst * S.ldF;          // plan slot order, then Dinv
+  double *Dg = Nn.D + (size_t)inst * S.N;
   const double *K = Nn.Kx + (size_t)inst * S.nnzK;
   int npos = 0, bad = 0;
+  // workspace element i: L entry (CSC position i) for i < nnzL, pivot D[i - nnzL] otherwise
+  auto W = [&](int i) -> double & {
+    if (USE_LDS) return sh[i];
+    return i < S.nnzL ? F[S.LtoS[i]] : Dg[i - S.nnzL];
+  };
 
   if (c_start <= 0) {
-    for (int i = lane; i < nW; i += WAVE) W[i] = 0.0;
+    for (int i = lane; i < nW; i += WAVE) W(i) = 0.0;
     __syncthreads();
-    for (int k = lane; k < S.nnzK; k += WAVE) W[S.KtoW[k]] = K[k];
+    for (int k = lane; k < S.nnzK; k += WAVE) W(S.KtoW[k]) = K[k];
     __syncthreads();
   } else {
     // Restart (LDL_update_from_pivot semantics, src/recursive_ldl.c:946-1110): columns < c_start keep
     // their L and D; the trailing part is rebuilt from the KKT values plus the replayed contributions
     // of the kept columns.
     const int l0 = S.Lp[c_start];
-    if (USE_LDS) for (int i = lane; i < nW; i += WAVE) W[i] = out[i];
+    if (USE_LDS) {
+      for (int i = lane; i < S.nnzL; i += WAVE) sh[i] = F[S.LtoS[i]];
+      for (int j = lane; j < S.N; j += WAVE) sh[S.nnzL + j] = Dg[j];
+    }
     __syncthreads();
-    for (int i = l0 + lane; i < S.nnzL; i += WAVE) W[i] = 0.0;
-    for (int j = c_start + lane; j < S.N; j += WAVE) W[S.nnzL + j] = 0.0;
+    for (int i = l0 + lane; i < S.nnzL; i += WAVE) W(i) = 0.0;
+    for (int j = c_start + lane; j < S.N; j += WAVE) W(S.nnzL + j) = 0.0;
     __syncthreads();
     for (int k = lane; k < S.nnzK; k += WAVE) {
       const int w = S.KtoW[k];
-      if ((w >= l0 && w < S.nnzL) || w >= S.nnzL + c_start) W[w] = K[k];
+      if ((w >= l0 && w < S.nnzL) || w >= S.nnzL + c_start) W(w) = K[k];
     }
     __syncthreads();
     for (int c = 0; c < c_start; c++) {
-      const double d = W[S.nnzL + c];
+      const double d = W(S.nnzL + c);
       if (d > 0.0) npos++;
       const int base = S.Lp[c], cnt = S.Lp[c + 1] - base;
       if (cnt == 0 || S.Li[base + cnt - 1] < c_start) continue;   // column does not reach the trailing part
@@ -132,7 +142,7 @@ __global__ __launch_bounds__(WAVE) void k_factor(rldl_dev_sym S, rldl_dev_num Nn
         const int dst = S.Udst[t];
         if ((dst >= l0 && dst < S.nnzL) || dst >= S.nnzL + c_start) {
           const unsigned ab = S.Uab[t];
-          W[dst] -= W[base + (ab & 0xffffu)] * (W[base + (ab >> 16)] * d);   // stored L is already scaled by 1/d
+          W(dst) -= W(base + (ab & 0xffffu)) * (W(base + (ab >> 16)) * d);   // stored L is already scaled by 1/d
         }
       }
       __syncthreads();
@@ -140,7 +150,7 @@ __global__ __launch_bounds__(WAVE) void k_factor(rldl_dev_sym S, rldl_dev_num Nn
   }
 
   for (int j = c_start > 0 ? c_start : 0; j < S.N; j++) {
-    const double d = W[S.nnzL + j];
+    const double d = W(S.nnzL + j);
     if (d == 0.0) { bad = 1; break; }
     if (d > 0.0) npos++;
     const int base = S.Lp[j], c = S.Lp[j + 1] - base;
@@ -149,18 +159,19 @@ __global__ __launch_bounds__(WAVE) void k_factor(rldl_dev_sym S, rldl_dev_num Nn
     const long long t0 = S.Up[j], t1 = S.Up[j + 1];
     for (long long t = t0 + lane; t < t1; t += WAVE) {
       const unsigned ab = S.Uab[t];
-      const double wa = W[base + (ab & 0xffffu)], wb = W[base + (ab >> 16)];
-      W[S.Udst[t]] -= wa * (wb * dinv);
+      const double wa = W(base + (ab & 0xffffu)), wb = W(base + (ab >> 16));
+      W(S.Udst[t]) -= wa * (wb * dinv);
     }
     __syncthreads();
-    for (int a = lane; a < c; a += WAVE) W[base + a] *= dinv;
+    for (int a = lane; a < c; a += WAVE) W(base + a) *= dinv;
     // no barrier needed: later columns never read column j again (only the write-out below does)
   }
   __syncthreads();
-  if (USE_LDS)
-    for (int i = lane; i < nW; i += WAVE) out[i] = W[i];
-  double *Dinv = Nn.Dinv + (size_t)inst * S.N;
-  for (int j = lane; j < S.N; j += WAVE) Dinv[j] = 1.0 / W[S.nnzL + j];
+  if (USE_LDS) {
+    for (int i = lane; i < S.nnzL; i += WAVE) F[S.LtoS[i]] = sh[i];
+    for (int j = lane; j < S.N; j += WAVE) Dg[j] = sh[S.nnzL + j];
+  }
+  for (int j = lane; j < S.N; j += WAVE) F[S.nS + j] = 1.0 / W(S.nnzL + j);   // Dinv rides behind the factor
   if (lane == 0) Nn.status[inst] = bad ? -1 : npos;
 }
 
@@ -171,11 +182,12 @@ __global__ __launch_bounds__(WAVE) void k_factor(rldl_dev_sym S, rldl_dev_num Nn
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void tri_solve(const rldl_dev_sym &S, const double *Lv, const double *__restrict__ Dinv,
                                           double *xs, int lane) {
+  // generic fallback: Lv is in plan slot order, reached through LtoS
   for (int j = 0; j < S.N; j++) {
     const int base = S.Lp[j], c = S.Lp[j + 1] - base;
     if (c == 0) continue;
     const double xj = xs[j];
-    for (int a = lane; a < c; a += WAVE) xs[S.Li[base + a]] -= Lv[base + a] * xj;
+    for (int a = lane; a < c; a += WAVE) xs[S.Li[base + a]] -= Lv[S.LtoS[base + a]] * xj;
     __syncthreads();
   }
   for (int j = lane; j < S.N; j += WAVE) xs[j] *= Dinv[j];
@@ -184,7 +196,7 @@ __device__ __forceinline__ void tri_solve(const rldl_dev_sym &S, const double *L
     const int base = S.Rp[i], c = S.Rp[i + 1] - base;
     if (c == 0) continue;
     const double xi = xs[i];
-    for (int a = lane; a < c; a += WAVE) xs[S.Rj[base + a]] -= Lv[S.Rpos[base + a]] * xi;
+    for (int a = lane; a < c; a += WAVE) xs[S.Rj[base + a]] -= Lv[S.LtoS[S.Rpos[base + a]]] * xi;
     __syncthreads();
   }
 }
@@ -194,12 +206,12 @@ __global__ __launch_bounds__(WAVE) void k_solve(rldl_dev_sym S, rldl_dev_num Nn,
   const int inst = blockIdx.x, lane = threadIdx.x;
   extern __shared__ double sh[];
   double *xs = sh;               // [N]
-  double *Ls = sh + S.N;         // [nnzL] when USE_LDS
-  const double *Lg = Nn.LD + (size_t)inst * (S.nnzL + S.N);
-  const double *Dinv = Nn.Dinv + (size_t)inst * S.N;
+  double *Ls = sh + S.N;         // [nS] when USE_LDS
+  const double *Lg = Nn.F + (size_t)inst * S.ldF;
+  const double *Dinv = Lg + S.nS;
   double *b = b_all + (size_t)inst * S.N;
   if (USE_LDS)
-    for (int i = lane; i < S.nnzL; i += WAVE) Ls[i] = Lg[i];
+    for (int i = lane; i < S.nS; i += WAVE) Ls[i] = Lg[i];
   for (int j = lane; j < S.N; j += WAVE) xs[j] = b[S.perm[j]];          // permute_x  :538-541
   __syncthreads();
   tri_solve(S, USE_LDS ? Ls : Lg, Dinv, xs, lane);
@@ -225,16 +237,16 @@ __global__ __launch_bounds__(WAVE) void k_admm_iter(rldl_dev_sym S, rldl_dev_num
   if (W.status[inst] != ST_UNSOLVED) return;
   extern __shared__ double sh[];
   double *xs = sh;               // [N] permuted rhs / solution
-  double *Ls = sh + S.N;         // [nnzL]
+  double *Ls = sh + S.N;         // [nS]
   const int n = S.n, m = S.m;
-  const double *Lg = Nn.LD + (size_t)inst * (S.nnzL + S.N);
-  const double *Dinv = Nn.Dinv + (size_t)inst * S.N;
+  const double *Lg = Nn.F + (size_t)inst * S.ldF;
+  const double *Dinv = Lg + S.nS;
   const double *ri = Nn.rho_inv + (size_t)inst * m;
   double *x = W.x + (size_t)inst * n, *z = W.z + (size_t)inst * m, *y = W.y + (size_t)inst * m;
   const double *q = W.q + (size_t)inst * n;
 
   if (USE_LDS)
-    for (int i = lane; i < S.nnzL; i += WAVE) Ls[i] = Lg[i];
+    for (int i = lane; i < S.nS; i += WAVE) Ls[i] = Lg[i];
   // compute_rhs (auxil.c:164-178) gathered straight into permuted order (permute_x)
   for (int j = lane; j < S.N; j += WAVE) {
     const int o = S.perm[j];
@@ -515,12 +527,420 @@ __global__ __launch_bounds__(WAVE) void k_matvec_A(rldl_dev_sym S, rldl_dev_admm
   }
 }
 
+
+// ================================================================================================
+// v2: plan-driven triangular solve (rldl_plan.c).  WPB instances per workgroup share one LDS copy of
+// the plan; each wave stages its instance's factor (plan slot order) + Dinv in LDS with 16-byte loads
+// and then runs, per group of <= 64 indices (one lane per index):
+//   forward : per-lane gather over the out-of-group entries of its row, then the in-group dense
+//             triangle swept column by column -- the pivot value is broadcast with v_readlane, the
+//             column of L comes from LDS (addresses independent of x, so the reads pipeline);
+//   backward: x *= Dinv folded into the load, per-lane gather over the out-of-group entries of its
+//             column, then the in-group triangle swept row by row (descending) the same way.
+// No atomics, no cross-lane reductions, deterministic summation order.
+// ================================================================================================
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ double readlane_f64(double v, int src) {   // src must be wave-uniform
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+
+
+#define SU 8   // sweep steps whose L reads are kept in flight (two batches, ping-pong)
+#define GU 4   // gather steps per batch
+// w: plan blob (LDS), Sv: [nS factor slots | N Dinv] (LDS), xs: [N] permuted rhs in / solution out (LDS)
+__device__ __forceinline__ void plan_tri_solve(const rldl_dev_sym &S, const int *w, const double *Sv, double *xs, int lane) {
+  const int ng = S.ngroups;
+  const double *Dinv = Sv + S.nS;
+  const int zs = S.ldF + ((S.N + 1) & ~1);                       // per-wave slot holding 0.0 (set by the caller)
+  const unsigned short *fsig = reinterpret_cast<const unsigned short *>(w + S.po_fsig);
+  const unsigned short *bsig = reinterpret_cast<const unsigned short *>(w + S.po_bsig);
+  const unsigned short *fcol = reinterpret_cast<const unsigned short *>(w + S.po_fcol);
+  // ================= forward: L y = b =================
+  for (int k = 0; k < ng; k++) {
+    const int g0 = __builtin_amdgcn_readfirstlane(w[S.po_gstart + k]);
+    const int g = __builtin_amdgcn_readfirstlane(w[S.po_gstart + k + 1]) - g0;
+    const int fs0 = __builtin_amdgcn_readfirstlane(w[S.po_fsp + k]);
+    const int nfs = (S.dbg & 1) ? 0 : __builtin_amdgcn_readfirstlane(w[S.po_fsp + k + 1]) - fs0;
+    const int na = ((S.dbg & 2) || !__builtin_amdgcn_readfirstlane(w[S.po_gflag + k])) ? 0 : g - 1;
+    if (nfs == 0 && na == 0) continue;                           // nothing flows into this group
+    const bool act = lane < g;
+    const int r = g0 + lane;
+    if (nfs > 0) {
+      // jagged-diagonal gather: lane i owns the row with the i-th most out-of-group entries; step t touches
+      // lanes [0, cnt_t): value slot base_t + lane (consecutive -> conflict-free), column index alongside
+      const int jr = act ? fsig[r] : 0;
+      double ga = act ? xs[jr] : 0.0;
+      for (int t0 = 0; t0 < nfs; t0 += WAVE) {
+        const int nb = min(WAVE, nfs - t0);
+        const int vb = lane < nb ? w[S.po_fsb + fs0 + t0 + lane] : 0;
+        const int vc = lane < nb ? w[S.po_fsc + fs0 + t0 + lane] : 0;
+        for (int t = 0; t < nb; t += GU) {
+          double v[GU], xv[GU];
+#pragma unroll
+          for (int u = 0; u < GU; u++) {
+            const bool ok = t + u < nb;
+            const int ts = ok ? t + u : 0;
+            const int base = __builtin_amdgcn_readlane(vb, ts), cnt = __builtin_amdgcn_readlane(vc, ts);
+            const bool on = ok && lane < cnt;
+            v[u] = Sv[on ? base + lane : zs];
+            xv[u] = xs[fcol[on ? base + lane : 0]];
+          }
+#pragma unroll
+          for (int u = 0; u < GU; u++) ga = fma(-v[u], xv[u], ga);
+        }
+      }
+      if (act) xs[jr] = ga;
+      wave_sync();
+    }
+    if (na > 0) {
+      // in-group sweep over the row-major packed triangle: lane i owns local row i, whose entries L(i, 0..i-1)
+      // start at Tb + i (i-1)/2, so step a reads rowp[a] (a DS immediate offset inside an unrolled batch).
+      // Two batches of reads are always in flight (ping-pong, no register copies).
+      double acc = act ? xs[r] : 0.0;
+      const int Tb = __builtin_amdgcn_readfirstlane(w[S.po_gToff + k]);
+      const int nst = g - 1;
+      const int lc = lane < g ? lane : g - 1;
+      const double *rowp = Sv + Tb + ((lc * (lc - 1)) >> 1);
+      double tA[SU], tB[SU];
+      auto loadF = [&](int s0, double (&tb)[SU]) {
+#pragma unroll
+        for (int u = 0; u < SU; u++) tb[u] = rowp[s0 + u];       // lanes <= step read past their row: masked below
+      };
+      auto procF = [&](int s0, const double (&tb)[SU]) {
+#pragma unroll
+        for (int u = 0; u < SU; u++) {
+          const int a = s0 + u;
+          if (a < nst) {                                           // wave-uniform
+            const double xj = readlane_f64(acc, a);                // pivot broadcast (ignores exec)
+            if (lane > a) acc = fma(-tb[u], xj, acc);              // rows below the pivot
+          }
+        }
+      };
+      loadF(0, tA);
+      for (int a = 0; a < nst; a += 2 * SU) {
+        loadF(a + SU, tB);
+        procF(a, tA);
+        loadF(a + 2 * SU, tA);
+        procF(a + SU, tB);
+      }
+      if (act) xs[r] = acc;
+      wave_sync();
+    }
+  }
+  // ================= backward: D^-1 then L' x = y =================
+  for (int k = ng - 1; k >= 0; k--) {
+    const int g0 = __builtin_amdgcn_readfirstlane(w[S.po_gstart + k]);
+    const int g = __builtin_amdgcn_readfirstlane(w[S.po_gstart + k + 1]) - g0;
+    const int bs0 = __builtin_amdgcn_readfirstlane(w[S.po_bsp + k]);
+    const int nbs = (S.dbg & 4) ? 0 : __builtin_amdgcn_readfirstlane(w[S.po_bsp + k + 1]) - bs0;
+    const int nr = ((S.dbg & 8) || !__builtin_amdgcn_readfirstlane(w[S.po_gflag + k])) ? 0 : g - 1;
+    const bool act = lane < g;
+    const int c = g0 + lane;
+    if (nbs == 0 && nr == 0) {                                   // only the diagonal scaling is left
+      if (act) xs[c] *= Dinv[c];
+      wave_sync();
+      continue;
+    }
+    if (nbs > 0) {
+      const int jc = act ? bsig[c] : 0;
+      double gb = act ? xs[jc] * Dinv[jc] : 0.0;
+      for (int t0 = 0; t0 < nbs; t0 += WAVE) {
+        const int nb = min(WAVE, nbs - t0);
+        const int vb = lane < nb ? w[S.po_bsb + bs0 + t0 + lane] : 0;
+        const int vc = lane < nb ? w[S.po_bsc + bs0 + t0 + lane] : 0;
+        for (int t = 0; t < nb; t += GU) {
+          double v[GU], xv[GU];
+#pragma unroll
+          for (int u = 0; u < GU; u++) {
+            const bool ok = t + u < nb;
+            const int ts = ok ? t + u : 0;
+            const int base = __builtin_amdgcn_readlane(vb, ts), cnt = __builtin_amdgcn_readlane(vc, ts);
+            const bool on = ok && lane < cnt;
+            const unsigned rs = (unsigned)w[S.po_brs + (on ? base + lane : 0)];   // row | slot << 16
+            v[u] = Sv[on ? (int)(rs >> 16) : zs];
+            xv[u] = xs[rs & 0xffffu];
+          }
+#pragma unroll
+          for (int u = 0; u < GU; u++) gb = fma(-v[u], xv[u], gb);
+        }
+      }
+      if (act) xs[jc] = gb;
+      wave_sync();
+    }
+    if (nr > 0) {
+      // backward sweep: lane j owns local column j; step s uses row il = g-1-s, whose entries L(il, 0..il-1)
+      // sit at Tb + il (il-1)/2 + lane (consecutive lanes -> conflict-free)
+      double acc = act ? (nbs > 0 ? xs[c] : xs[c] * Dinv[c]) : 0.0;
+      const int Tb = __builtin_amdgcn_readfirstlane(w[S.po_gToff + k]);
+      const int nst = g - 1;
+      const double *lanep = Sv + Tb + lane;
+      double tA[SU], tB[SU];
+      auto loadB = [&](int s0, double (&tb)[SU]) {
+#pragma unroll
+        for (int u = 0; u < SU; u++) {
+          int il = g - 1 - (s0 + u);
+          il = il > 0 ? il : 0;
+          tb[u] = lanep[(il * (il - 1)) >> 1];
+        }
+      };
+      auto procB = [&](int s0, const double (&tb)[SU]) {
+#pragma unroll
+        for (int u = 0; u < SU; u++) {
+          const int il = g - 1 - (s0 + u);
+          if (il > 0) {
+            const double xi = readlane_f64(acc, il);
+            if (lane < il) acc = fma(-tb[u], xi, acc);             // columns left of the pivot
+          }
+        }
+      };
+      loadB(0, tA);
+      for (int a = 0; a < nst; a += 2 * SU) {
+        loadB(a + SU, tB);
+        procB(a, tA);
+        loadB(a + 2 * SU, tA);
+        procB(a + SU, tB);
+      }
+      if (act) xs[c] = acc;
+      wave_sync();
+    }
+  }
+}
+
+// cooperative staging: plan blob -> LDS by LDS-DMA, 16-byte pieces spread over the workgroup's waves
+// (the device copy of the blob is padded to a multiple of 4 words)
+__device__ __forceinline__ void stage_plan(const rldl_dev_sym &S, int *wl) {
+  typedef __attribute__((address_space(1))) const void *gptr_t;
+  typedef __attribute__((address_space(3))) void *lptr_t;
+  const int np = (S.plan_words + 3) >> 2, lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
+  for (int base = wv * WAVE; base < np; base += blockDim.x) {
+    const int i = base + lane;
+    if (i < np) __builtin_amdgcn_global_load_lds((gptr_t)(S.plan + 4 * (size_t)i), (lptr_t)(wl + 4 * (size_t)base), 16, 0, 0);
+  }
+}
+// factor row -> LDS with LDS-DMA: every 1 KiB piece is one global_load_lds_dwordx4 wave-instruction, all
+// pieces are issued back to back (no VGPR staging, one vmcnt wait for the whole row).  Rows are 16-byte
+// aligned (ldF even, hipMalloc base), the LDS destination of lane t is base + 16 t.
+__device__ __forceinline__ void stage_factor_dma(const rldl_dev_sym &S, const double *Fg, double *Sv, int lane) {
+  const int n2 = S.ldF >> 1;                                   // number of 16-byte pieces in the row
+  typedef __attribute__((address_space(1))) const void *gptr_t;
+  typedef __attribute__((address_space(3))) void *lptr_t;
+  for (int base = 0; base < n2; base += WAVE) {
+    const int i = base + lane;
+    if (i < n2)
+      __builtin_amdgcn_global_load_lds((gptr_t)(Fg + 2 * (size_t)i), (lptr_t)(Sv + 2 * (size_t)base), 16, 0, 0);
+  }
+}
+__device__ __forceinline__ void wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+__global__ __launch_bounds__(1024) void k_plan_solve(rldl_dev_sym S, rldl_dev_num Nn, double *__restrict__ b_all, int per_wave) {
+  extern __shared__ __attribute__((aligned(16))) double sh[];
+  const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+  const int inst = blockIdx.x * wpb + wv;
+  int *wl = reinterpret_cast<int *>(sh + (size_t)wpb * per_wave);
+  double *Sv = sh + (size_t)wv * per_wave;                     // [ldF] factor + Dinv (16-byte aligned)
+  double *xs = Sv + S.ldF;                                     // [N]
+  if (lane == 0) Sv[S.ldF + ((S.N + 1) & ~1)] = 0.0;
+  const bool live = inst < Nn.batch;
+  double *b = b_all + (size_t)(live ? inst : 0) * S.N;
+  stage_plan(S, wl);
+  if (live) {
+    stage_factor_dma(S, Nn.F + (size_t)inst * S.ldF, Sv, lane);
+    const int *permg = S.plan + S.po_perm;                     // global copy: lets the rhs gather start before the barrier
+    for (int j0 = 0; j0 < S.N; j0 += 4 * WAVE) {               // permute_x  qdldl_interface.c:538-541
+      double v[4];
+#pragma unroll
+      for (int t = 0; t < 4; t++) { const int j = j0 + t * WAVE + lane; v[t] = j < S.N ? b[permg[j]] : 0.0; }
+#pragma unroll
+      for (int t = 0; t < 4; t++) { const int j = j0 + t * WAVE + lane; if (j < S.N) xs[j] = v[t]; }
+    }
+  }
+  wait_dma();
+  __syncthreads();
+  if (!live) return;
+  const int *perm = wl + S.po_perm;
+  plan_tri_solve(S, wl, Sv, xs, lane);
+  if (S.polish) {
+    for (int j = lane; j < S.N; j += WAVE) b[perm[j]] = xs[j];  // permutet_x :544-547, raw solution :563-565
+  } else {
+    const double *ri = Nn.rho_inv + (size_t)inst * S.m;
+    for (int j0 = 0; j0 < S.N; j0 += 4 * WAVE) {
+      double bo[4], rr[4];
+      int oo[4];
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        const int j = j0 + t * WAVE + lane;
+        oo[t] = j < S.N ? perm[j] : -1;
+        const bool con = oo[t] >= S.n;
+        bo[t] = con ? b[oo[t]] : 0.0;
+        rr[t] = con ? ri[oo[t] - S.n] : 0.0;
+      }
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        const int j = j0 + t * WAVE + lane;
+        if (oo[t] < 0) continue;
+        if (oo[t] < S.n) b[oo[t]] = xs[j];                      // x_tilde :572-574
+        else b[oo[t]] = bo[t] + rr[t] * xs[j];                  // z_tilde :577-579
+      }
+    }
+  }
+}
+
+// One fused ADMM iteration (auxil.c:164-228).  All global loads a wave needs (factor row via LDS-DMA,
+// x/q or z/y/rho_inv/l/u/rho per owned position) are issued before the first wait, so a wave pays about
+// two memory latencies per iteration instead of one per loop trip.
+template <int TMAX>   // positions per lane held in registers: covers N <= 64*TMAX
+__global__ __launch_bounds__(1024) void k_plan_admm(rldl_dev_sym S, rldl_dev_num Nn, rldl_dev_admm W, int per_wave) {
+  extern __shared__ __attribute__((aligned(16))) double sh[];
+  const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+  const int inst = blockIdx.x * wpb + wv;
+  int *wl = reinterpret_cast<int *>(sh + (size_t)wpb * per_wave);
+  double *Sv = sh + (size_t)wv * per_wave;
+  double *xs = Sv + S.ldF;
+  if (lane == 0) Sv[S.ldF + ((S.N + 1) & ~1)] = 0.0;
+  const int st = inst < Nn.batch ? W.status[inst] : 0;          // latency overlaps with the plan / perm loads below
+  stage_plan(S, wl);
+  const int *permg = S.plan + S.po_perm;
+  int oo[TMAX];
+#pragma unroll
+  for (int t = 0; t < TMAX; t++) { const int j = t * WAVE + lane; oo[t] = j < S.N ? permg[j] : -1; }
+  const bool live = inst < Nn.batch && st == ST_UNSOLVED;
+  const int n = S.n, m = S.m;
+  const size_t io = (size_t)(live ? inst : 0);
+  const double *ri = Nn.rho_inv + io * m;
+  double *x = W.x + io * n, *z = W.z + io * m, *y = W.y + io * m;
+  const double *q = W.q + io * n, *l = W.l + io * m, *u = W.u + io * m, *rv = W.rho_vec + io * m;
+  // per owned permuted position: o = perm[j]; variables carry (x_prev, q), constraints (z_prev, y, rho_inv, l, u, rho)
+  double va[TMAX], vb[TMAX], vr[TMAX], vl[TMAX], vu[TMAX], vrho[TMAX];
+  if (live) {
+    if (!(S.dbg & 16)) stage_factor_dma(S, Nn.F + io * S.ldF, Sv, lane);
+#pragma unroll
+    for (int t = 0; t < TMAX; t++) {
+      // branch-free: every lane loads from a valid address chosen by pointer select, so all loads of all
+      // positions are in flight together (a conditional load would split the block and wait per branch)
+      const int o = oo[t];
+      const bool con = o >= n;
+      const int iv = con || o < 0 ? 0 : o, ic = con ? o - n : 0;
+      const double *pa = con ? z + ic : x + iv;
+      const double *pb = con ? y + ic : q + iv;
+      va[t] = *pa;
+      vb[t] = *pb;
+      vr[t] = ri[ic];
+      vl[t] = l[ic];
+      vu[t] = u[ic];
+      vrho[t] = rv[ic];
+    }
+    // compute_rhs (auxil.c:164-178) straight into permuted order (permute_x)
+#pragma unroll
+    for (int t = 0; t < TMAX; t++) {
+      const int j = t * WAVE + lane;
+      if (oo[t] >= 0) xs[j] = oo[t] < n ? W.sigma * va[t] - vb[t] : va[t] - vr[t] * vb[t];
+    }
+  }
+  wait_dma();
+  __syncthreads();
+  if (!live) return;
+  if (!(S.dbg & 32)) plan_tri_solve(S, wl, Sv, xs, lane);
+  const double alpha = W.alpha;
+  double *dx = W.delta_x + io * n, *dy = W.delta_y + io * m;
+#pragma unroll
+  for (int t = 0; t < TMAX; t++) {
+    const int o = oo[t];
+    if (o < 0) continue;
+    const double s = xs[t * WAVE + lane];
+    if (o < n) {
+      const double xp = va[t];
+      const double xn = alpha * s + (1.0 - alpha) * xp;       // update_x :188-201
+      x[o] = xn;
+      dx[o] = xn - xp;
+    } else {
+      const int i = o - n;
+      const double zp = va[t], yi = vb[t], r = vr[t];
+      const double zt = (zp - r * yi) + r * s;                 // z_tilde, qdldl_interface.c:577-579
+      const double mix = alpha * zt + (1.0 - alpha) * zp;
+      double zn = mix + r * yi;                                // update_z :203-215
+      zn = fmin(fmax(zn, vl[t]), vu[t]);                       // project, proj.c:4-14
+      const double d = vrho[t] * (mix - zn);                   // update_y :217-228
+      z[i] = zn;
+      dy[i] = d;
+      y[i] = yi + d;
+    }
+  }
+}
+
 }  // namespace
 
 // ================================================================================================
 // extern "C" launchers (enqueue only)
 // ================================================================================================
 static inline int launch_status() { return hipGetLastError() == hipSuccess ? 0 : -1; }
+
+// ---- plan kernels: geometry ----
+#define LDS_PER_CU (160 * 1024)
+static int plan_per_wave_doubles(const rldl_dev_sym *S) { return S->ldF + ((S->N + 1) & ~1) + 2; }  // factor+Dinv | xs | zero slot
+static size_t plan_lds_bytes(const rldl_dev_sym *S, int wpb) {
+  return sizeof(double) * (size_t)wpb * (size_t)plan_per_wave_doubles(S) + sizeof(int) * (size_t)((S->plan_words + 3) & ~3);
+}
+// waves per workgroup (1..16) that maximise resident waves per CU; asks the runtime what actually fits
+// (the usable LDS per CU is below the nominal 160 KiB).  RLDL_WPB forces a value for experiments.
+static int plan_pick_wpb_for(const rldl_dev_sym *S, const void *kernel) {
+  static int cache_words = -1, cache_ldf = -1, cache_best = 0;
+  static const void *cache_kernel = 0;
+  if (cache_kernel == kernel && cache_words == S->plan_words && cache_ldf == S->ldF) return cache_best;
+  int best = 0, best_waves = 0;
+  const char *force = getenv("RLDL_WPB");
+  for (int wpb = 1; wpb <= 16; wpb *= 2) {
+    const size_t b = plan_lds_bytes(S, wpb);
+    if (b > (size_t)LDS_PER_CU) continue;
+    if (force && atoi(force) != wpb) continue;
+    if (b > 64 * 1024 && hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b) != hipSuccess) continue;
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, wpb * WAVE, b) != hipSuccess) continue;
+    const int waves = nb * wpb;
+    if (waves > best_waves) { best = wpb; best_waves = waves; }
+  }
+  (void)hipGetLastError();
+  cache_kernel = kernel; cache_words = S->plan_words; cache_ldf = S->ldF; cache_best = best;
+  if (getenv("RLDL_VERBOSE")) fprintf(stderr, "[rldl] plan kernel: wpb=%d, %d waves/CU, %zu B LDS per workgroup\n", best, best_waves, plan_lds_bytes(S, best ? best : 1));
+  return best;
+}
+static int plan_pick_wpb(const rldl_dev_sym *S) {   // feasibility only (any kernel): LDS budget
+  for (int wpb = 1; wpb <= 16; wpb *= 2)
+    if (plan_lds_bytes(S, wpb) <= (size_t)LDS_PER_CU) return wpb;
+  return 0;
+}
+static bool plan_usable(const rldl_dev_sym *S) { return S->plan_ok && S->ngroups > 0 && plan_pick_wpb(S) > 0; }
+static bool plan_admm_usable(const rldl_dev_sym *S) { return plan_usable(S) && S->N <= 8 * WAVE; }
+
+static int launch_plan_solve(const rldl_dev_sym *S, const rldl_dev_num *Nn, double *d_b, void *stream) {
+  const int wpb = plan_pick_wpb_for(S, (const void *)k_plan_solve);
+  if (wpb <= 0) return -1;
+  const size_t lds = plan_lds_bytes(S, wpb);
+  if (lds > 64 * 1024 && hipFuncSetAttribute((const void *)k_plan_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+  const int grid = (Nn->batch + wpb - 1) / wpb;
+  hipLaunchKernelGGL(k_plan_solve, dim3(grid), dim3(wpb * WAVE), lds, (hipStream_t)stream, *S, *Nn, d_b, plan_per_wave_doubles(S));
+  return launch_status();
+}
+template <int TMAX>
+static int launch_plan_admm_t(const rldl_dev_sym *S, const rldl_dev_num *Nn, const rldl_dev_admm *W, void *stream) {
+  const int wpb = plan_pick_wpb_for(S, (const void *)k_plan_admm<TMAX>);
+  if (wpb <= 0) return -1;
+  const size_t lds = plan_lds_bytes(S, wpb);
+  if (lds > 64 * 1024 && hipFuncSetAttribute((const void *)k_plan_admm<TMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+  const int grid = (Nn->batch + wpb - 1) / wpb;
+  hipLaunchKernelGGL(k_plan_admm<TMAX>, dim3(grid), dim3(wpb * WAVE), lds, (hipStream_t)stream, *S, *Nn, *W, plan_per_wave_doubles(S));
+  return launch_status();
+}
+static int launch_plan_admm(const rldl_dev_sym *S, const rldl_dev_num *Nn, const rldl_dev_admm *W, void *stream) {
+  if (S->N <= 2 * WAVE) return launch_plan_admm_t<2>(S, Nn, W, stream);
+  if (S->N <= 4 * WAVE) return launch_plan_admm_t<4>(S, Nn, W, stream);
+  return launch_plan_admm_t<8>(S, Nn, W, stream);
+}
 
 extern "C" int rldl_launch_kkt_assemble(const rldl_dev_sym *S, const rldl_dev_num *Nn, const double *d_Px,
                                         const double *d_Ax, const double *d_rho_vec, int set_sigma_only,
@@ -552,7 +972,8 @@ extern "C" int rldl_launch_factor_from(const rldl_dev_sym *S, const rldl_dev_num
 
 extern "C" int rldl_launch_solve(const rldl_dev_sym *S, const rldl_dev_num *Nn, double *d_b, void *stream) {
   if (Nn->batch <= 0) return 0;
-  const size_t lds = sizeof(double) * (size_t)(S->nnzL + S->N);
+  if (plan_usable(S)) return launch_plan_solve(S, Nn, d_b, stream);
+  const size_t lds = sizeof(double) * (size_t)(S->nS + S->N);
   if (lds <= RLDL_LDS_LIMIT)
     hipLaunchKernelGGL(k_solve<true>, dim3(Nn->batch), dim3(WAVE), lds, (hipStream_t)stream, *S, *Nn, d_b);
   else
@@ -563,7 +984,8 @@ extern "C" int rldl_launch_solve(const rldl_dev_sym *S, const rldl_dev_num *Nn, 
 
 extern "C" int rldl_launch_admm_iter(const rldl_dev_sym *S, const rldl_dev_num *Nn, const rldl_dev_admm *W, void *stream) {
   if (Nn->batch <= 0) return 0;
-  const size_t lds = sizeof(double) * (size_t)(S->nnzL + S->N);
+  if (plan_admm_usable(S)) return launch_plan_admm(S, Nn, W, stream);
+  const size_t lds = sizeof(double) * (size_t)(S->nS + S->N);
   if (lds <= RLDL_LDS_LIMIT)
     hipLaunchKernelGGL(k_admm_iter<true>, dim3(Nn->batch), dim3(WAVE), lds, (hipStream_t)stream, *S, *Nn, *W);
   else

@@ -1,0 +1,254 @@
+/*
+ * rldl_plan.c -- host-side builder of the grouped triangular-solve plan (plain C99).
+ *
+ * The forward/back substitution of the reference (QDLDL_solve, call site qdldl_interface.c:553; loop
+ * bodies src/recursive_ldl.c:62-116) walks L column by column.  On a 64-lane wavefront that is one
+ * dependent LDS round trip per column.  The plan turns the same arithmetic into:
+ *   - GROUPS of at most 64 consecutive indices (chosen by dynamic programming), one lane per index;
+ *   - a per-lane GATHER over the entries that connect a group to other, already final, indices, laid out
+ *     as jagged diagonals (rows sorted by length, so step t touches a dense prefix of lanes);
+ *   - an in-group SWEEP over a packed dense triangle, where the pivot value travels between lanes with
+ *     v_readlane instead of through memory.
+ * The factor is stored on the device directly in the plan's slot order (what `solve` streams):
+ *   slots [0, nO)   out-of-group entries in FORWARD jagged-diagonal order (group, step, lane)
+ *   slots [nO, nS)  per-group triangles, ROW-MAJOR packed: local row il >= 1 holds its il entries L(il, 0..il-1)
+ *                   at Tb + il (il-1)/2 (zero padded), so the forward sweep reads lane-constant base + step
+ *                   (DS immediate offsets) and the backward sweep reads uniform base + lane
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "rldl_symbolic.h"
+
+#define GROUP_MAX 64
+
+typedef struct { int key, idx; } kv;
+static int cmp_kv_desc(const void *a, const void *b) { /* by key descending, ties by index ascending */
+  const kv *x = (const kv *)a, *y = (const kv *)b;
+  if (x->key != y->key) return x->key > y->key ? -1 : 1;
+  return x->idx < y->idx ? -1 : (x->idx > y->idx ? 1 : 0);
+}
+
+int rldl_plan_build(rldl_symbolic *s) {
+  const int N = s->N;
+  int *group_of = 0, *gstart = 0, *blob = 0, *rowcnt = 0, *colcnt = 0, *coloff = 0;
+  int *fpos_of_row = 0, *bpos_of_col = 0, *fsteps_base = 0, *fsteps_cnt = 0, *bsteps_base = 0, *bsteps_cnt = 0,
+      *fstep_ptr = 0, *bstep_ptr = 0, *slot_of_csr = 0;
+  unsigned char *col_active = 0, *row_active = 0;
+  kv *order = 0;
+  int ng = 0, i, k, c, p, q, nO = 0, tri = 0, na = 0, nr = 0, words, nfs = 0, nbs = 0, rc = -2;
+
+  s->plan_ok = 0;
+  s->LtoS = (int *)malloc(sizeof(int) * (size_t)(s->nnzL > 0 ? s->nnzL : 1));
+  group_of = (int *)malloc(sizeof(int) * (size_t)(N + 1));
+  gstart = (int *)malloc(sizeof(int) * (size_t)(N + 2));
+  col_active = (unsigned char *)calloc((size_t)N + 1, 1);
+  row_active = (unsigned char *)calloc((size_t)N + 1, 1);
+  coloff = (int *)malloc(sizeof(int) * (size_t)(N + 1));
+  rowcnt = (int *)calloc((size_t)N + 2, sizeof(int));
+  colcnt = (int *)calloc((size_t)N + 2, sizeof(int));
+  fpos_of_row = (int *)malloc(sizeof(int) * (size_t)(N + 1));
+  bpos_of_col = (int *)malloc(sizeof(int) * (size_t)(N + 1));
+  order = (kv *)malloc(sizeof(kv) * (size_t)(GROUP_MAX + 1));
+  slot_of_csr = (int *)malloc(sizeof(int) * (size_t)(s->nnzL > 0 ? s->nnzL : 1));
+  if (!s->LtoS || !group_of || !gstart || !col_active || !row_active || !coloff || !rowcnt || !colcnt || !fpos_of_row ||
+      !bpos_of_col || !order || !slot_of_csr)
+    goto out;
+
+  /* ---- grouping by dynamic programming over cut points ----
+   * cost of a group [i, j): zero padding of its packed triangle + 4 per sweep step - 1 per in-group entry
+   * (entries kept inside a group ride the register sweep instead of the per-lane gather) + a fixed
+   * sequential overhead per group.  Dense blocks (the Schur-complement tail of a KKT matrix, the stage blocks
+   * of an MPC problem) become groups; runs of mutually independent columns cost nothing wherever cut. */
+  {
+    double *best = (double *)malloc(sizeof(double) * (size_t)(N + 1));
+    int *from = (int *)malloc(sizeof(int) * (size_t)(N + 1));
+    int j;
+    const double group_cost = getenv("RLDL_GROUP_COST") ? atof(getenv("RLDL_GROUP_COST")) : 24.0;
+    if (!best || !from) { free(best); free(from); goto out; }
+    best[0] = 0.0; from[0] = 0;
+    for (j = 1; j <= N; j++) {
+      double pad = 0.0, ein = 0.0, steps = 0.0;
+      int lo = j - GROUP_MAX < 0 ? 0 : j - GROUP_MAX;
+      best[j] = 1e300; from[j] = j - 1;
+      for (i = j - 1; i >= lo; i--) {          /* grow the group [i, j) to the left by column i */
+        int cnt = 0;
+        for (p = s->Lp[i]; p < s->Lp[i + 1] && s->Li[p] < j; p++) cnt++;
+        ein += cnt;
+        {
+          const double g = (double)(j - i);
+          pad = ein > 0 ? 0.5 * g * (g - 1.0) - ein : 0.0;    /* the whole packed triangle is stored */
+          steps = ein > 0 ? 2.0 * (g - 1.0) : 0.0;             /* forward + backward sweep steps */
+          double cst = best[i] + pad + 4.0 * steps - ein + group_cost;
+          if (cst < best[j]) { best[j] = cst; from[j] = i; }
+        }
+      }
+    }
+    ng = 0;
+    for (j = N; j > 0; j = from[j]) ng++;
+    k = ng;
+    for (j = N; j > 0; j = from[j]) gstart[--k] = from[j];
+    gstart[ng] = N;
+    free(best); free(from);
+  }
+  for (k = 0; k < ng; k++)
+    for (i = gstart[k]; i < gstart[k + 1]; i++) group_of[i] = k;
+
+  /* ---- classify entries ---- */
+  for (c = 0; c < N; c++)
+    for (p = s->Lp[c]; p < s->Lp[c + 1]; p++) {
+      int r = s->Li[p];
+      if (group_of[r] == group_of[c]) { col_active[c] = 1; row_active[r] = 1; }
+      else { nO++; rowcnt[r]++; colcnt[c]++; }
+    }
+  if (N >= 65536 || nO >= 65536) { rc = 0; goto out; }       /* packed 16-bit fields would overflow */
+
+  /* triangle base slots (absolute); coloff[] is reused as "triangle base of the index's group" (-1: none) */
+  for (k = 0; k < ng; k++) {
+    int g0 = gstart[k], g = gstart[k + 1] - g0, any = 0;
+    for (i = 0; i < g; i++) any |= col_active[g0 + i];
+    for (i = 0; i < g; i++) coloff[g0 + i] = any ? nO + tri : -1;
+    if (any) { tri += g * (g - 1) / 2; na += g - 1; nr += g - 1; }
+  }
+  s->nO = nO; s->nS = nO + tri; s->ngroups = ng;
+
+  /* ---- jagged-diagonal orders: count steps ---- */
+  fstep_ptr = (int *)calloc((size_t)ng + 1, sizeof(int));
+  bstep_ptr = (int *)calloc((size_t)ng + 1, sizeof(int));
+  if (!fstep_ptr || !bstep_ptr) goto out;
+  for (k = 0; k < ng; k++) {
+    int g0 = gstart[k], g1 = gstart[k + 1], mf = 0, mb = 0;
+    for (i = g0; i < g1; i++) { if (rowcnt[i] > mf) mf = rowcnt[i]; if (colcnt[i] > mb) mb = colcnt[i]; }
+    fstep_ptr[k + 1] = fstep_ptr[k] + mf;
+    bstep_ptr[k + 1] = bstep_ptr[k] + mb;
+  }
+  nfs = fstep_ptr[ng]; nbs = bstep_ptr[ng];
+  fsteps_base = (int *)calloc((size_t)nfs + 1, sizeof(int)); fsteps_cnt = (int *)calloc((size_t)nfs + 1, sizeof(int));
+  bsteps_base = (int *)calloc((size_t)nbs + 1, sizeof(int)); bsteps_cnt = (int *)calloc((size_t)nbs + 1, sizeof(int));
+  if (!fsteps_base || !fsteps_cnt || !bsteps_base || !bsteps_cnt) goto out;
+
+  /* ---- blob layout ---- */
+  words = 0;
+  s->po_gstart = words; words += ng + 1;
+  s->po_gflag = words; words += ng + 1;
+  s->po_gaptr = words; words += ng + 1;
+  s->po_grptr = words; words += ng + 1;
+  s->po_gToff = words; words += ng + 1;
+  s->po_fsp = words; words += ng + 1;
+  s->po_bsp = words; words += ng + 1;
+  s->po_acol = s->po_aoff = s->po_arow = s->po_coloff = 0;   /* (generic column lists are gone: every triangle is full) */
+  s->po_fsb = words; words += nfs;
+  s->po_fsc = words; words += nfs;
+  s->po_bsb = words; words += nbs;
+  s->po_bsc = words; words += nbs;
+  s->po_fsig = words; words += (N + 1) / 2;
+  s->po_bsig = words; words += (N + 1) / 2;
+  s->po_fcol = words; words += (nO + 1) / 2;
+  s->po_brs = words; words += nO;
+  s->po_perm = words; words += N;
+  blob = (int *)calloc((size_t)words + 4, sizeof(int));
+  if (!blob) goto out;
+
+  for (k = 0; k <= ng; k++) {
+    blob[s->po_gstart + k] = gstart[k];
+    blob[s->po_fsp + k] = fstep_ptr[k];
+    blob[s->po_bsp + k] = bstep_ptr[k];
+  }
+  for (k = 0; k < ng; k++) {
+    int g0 = gstart[k];
+    blob[s->po_gaptr + k] = 0; blob[s->po_grptr + k] = 0;
+    blob[s->po_gToff + k] = coloff[g0] < 0 ? s->nS : coloff[g0];
+    blob[s->po_gflag + k] = coloff[g0] >= 0 ? 1 : 0;         /* 1: the group has a packed triangle to sweep */
+  }
+  for (i = 0; i < N; i++) blob[s->po_perm + i] = s->perm[i];
+
+  /* ---- forward jagged diagonals: rows of each group by out-of-group count (descending) ---- */
+  {
+    unsigned short *fsig = (unsigned short *)(blob + s->po_fsig), *fcol = (unsigned short *)(blob + s->po_fcol);
+    int slot = 0;
+    for (k = 0; k < ng; k++) {
+      int g0 = gstart[k], g = gstart[k + 1] - g0, nst = fstep_ptr[k + 1] - fstep_ptr[k], t;
+      for (i = 0; i < g; i++) { order[i].key = rowcnt[g0 + i]; order[i].idx = g0 + i; }
+      qsort(order, (size_t)g, sizeof(kv), cmp_kv_desc);
+      for (i = 0; i < g; i++) { fsig[g0 + i] = (unsigned short)order[i].idx; fpos_of_row[order[i].idx] = i; }
+      for (t = 0; t < nst; t++) {
+        int cnt = 0;
+        for (i = 0; i < g; i++) if (order[i].key > t) cnt++;
+        fsteps_base[fstep_ptr[k] + t] = slot; fsteps_cnt[fstep_ptr[k] + t] = cnt;
+        slot += cnt;
+      }
+    }
+    /* slot of the t-th out-of-group entry (ascending column) of row r = base(step t of its group) + lane(r) */
+    for (i = 0; i < N; i++) {
+      int t = 0;
+      for (q = s->Rp[i]; q < s->Rp[i + 1]; q++) {
+        int cc = s->Rj[q];
+        if (group_of[cc] == group_of[i]) { slot_of_csr[q] = -1; continue; }
+        slot_of_csr[q] = fsteps_base[fstep_ptr[group_of[i]] + t] + fpos_of_row[i];
+        fcol[slot_of_csr[q]] = (unsigned short)cc;
+        t++;
+      }
+    }
+    for (k = 0; k < nfs; k++) { blob[s->po_fsb + k] = fsteps_base[k]; blob[s->po_fsc + k] = fsteps_cnt[k]; }
+  }
+  /* storage map: CSC position -> slot */
+  for (i = 0; i < N; i++)
+    for (q = s->Rp[i]; q < s->Rp[i + 1]; q++) {
+      int cc = s->Rj[q], pcsc = s->Rpos[q];
+      { const int il = i - gstart[group_of[i]], jl = cc - gstart[group_of[i]];
+        s->LtoS[pcsc] = slot_of_csr[q] >= 0 ? slot_of_csr[q] : coloff[i] + il * (il - 1) / 2 + jl; }
+    }
+  /* ---- backward jagged diagonals: columns of each group by out-of-group count (descending) ---- */
+  {
+    unsigned short *bsig = (unsigned short *)(blob + s->po_bsig);
+    int e = 0;
+    for (k = 0; k < ng; k++) {
+      int g0 = gstart[k], g = gstart[k + 1] - g0, nst = bstep_ptr[k + 1] - bstep_ptr[k], t;
+      for (i = 0; i < g; i++) { order[i].key = colcnt[g0 + i]; order[i].idx = g0 + i; }
+      qsort(order, (size_t)g, sizeof(kv), cmp_kv_desc);
+      for (i = 0; i < g; i++) { bsig[g0 + i] = (unsigned short)order[i].idx; bpos_of_col[order[i].idx] = i; }
+      for (t = 0; t < nst; t++) {
+        int cnt = 0;
+        for (i = 0; i < g; i++) if (order[i].key > t) cnt++;
+        bsteps_base[bstep_ptr[k] + t] = e; bsteps_cnt[bstep_ptr[k] + t] = cnt;
+        e += cnt;
+      }
+    }
+    for (c = 0; c < N; c++) {
+      int t = 0;
+      for (p = s->Lp[c]; p < s->Lp[c + 1]; p++) {
+        int r = s->Li[p];
+        if (group_of[r] == group_of[c]) continue;
+        blob[s->po_brs + bsteps_base[bstep_ptr[group_of[c]] + t] + bpos_of_col[c]] =
+            (int)((unsigned)r | ((unsigned)s->LtoS[p] << 16));
+        t++;
+      }
+    }
+    for (k = 0; k < nbs; k++) { blob[s->po_bsb + k] = bsteps_base[k]; blob[s->po_bsc + k] = bsteps_cnt[k]; }
+  }
+
+  s->plan = blob; blob = 0;
+  s->plan_words = words;
+  s->plan_ok = 1;
+  if (getenv("RLDL_VERBOSE")) {
+    int full = 0;
+    for (k = 0; k < ng; k++) full += s->plan[s->po_gflag + k];
+    fprintf(stderr, "[rldl] plan: N=%d nnzL=%d -> nS=%d (nO=%d, triangles=%d, padding=%d), %d groups (%d closed-form):", N,
+            s->nnzL, s->nS, nO, tri, s->nS - s->nnzL, ng, full);
+    for (k = 0; k < ng && k < 16; k++) fprintf(stderr, " [%d,%d)", gstart[k], gstart[k + 1]);
+    fprintf(stderr, "%s, sweep steps %d fwd / %d bwd, gather steps %d fwd / %d bwd, %d plan words\n", ng > 16 ? " ..." : "", na,
+            nr, nfs, nbs, words);
+  }
+  rc = 0;
+
+out:
+  if (rc == 0 && !s->plan_ok) {                               /* identity layout for the generic kernels */
+    for (p = 0; p < s->nnzL; p++) s->LtoS[p] = p;
+    s->nS = s->nnzL; s->nO = s->nnzL; s->ngroups = 0;
+  }
+  free(group_of); free(gstart); free(col_active); free(row_active); free(coloff); free(rowcnt); free(colcnt);
+  free(fpos_of_row); free(bpos_of_col); free(order); free(slot_of_csr);
+  free(fsteps_base); free(fsteps_cnt); free(bsteps_base); free(bsteps_cnt); free(fstep_ptr); free(bstep_ptr); free(blob);
+  return rc;
+}

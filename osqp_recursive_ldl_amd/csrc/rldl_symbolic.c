@@ -156,6 +156,7 @@ void rldl_symbolic_free(rldl_symbolic *s) {
   free(s->Rp); free(s->Rj); free(s->Rpos); free(s->KtoW); free(s->Up); free(s->Udst); free(s->Uab);
   free(s->Pp); free(s->Pi); free(s->Prp); free(s->Prj); free(s->Prpos);
   free(s->Ap); free(s->Ai); free(s->Arp); free(s->Arj); free(s->Arpos);
+  free(s->LtoS); free(s->plan);
   free(s);
 }
 
@@ -359,6 +360,8 @@ int rldl_symbolic_create(rldl_symbolic **out, long long n64, long long m64, cons
   }
 
   free(T); free(uAp); free(uAi); free(work); free(mark); free(stack); free(fill);
+  T = 0; uAp = uAi = work = mark = stack = fill = 0;
+  if ((rc = rldl_plan_build(s))) goto fail;
   *out = s;
   return 0;
 fail:

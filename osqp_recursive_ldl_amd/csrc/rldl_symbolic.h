@@ -45,6 +45,16 @@ typedef struct {
   int *Udst;
   unsigned int *Uab;
   long long npairs;
+  /* ---- solve plan (see rldl_plan_build): storage layout of the factor + grouped schedule ---- */
+  int plan_ok;                 /* 0: limits exceeded, only the generic (v1) kernels may be used */
+  int nS;                      /* factor storage slots per instance (>= nnzL; padding slots stay zero) */
+  int nO;                      /* out-of-group entries (stored first, CSC order) */
+  int ngroups;
+  int *LtoS;                   /* [nnzL] CSC position -> storage slot */
+  int *plan;                   /* packed int32 blob uploaded to the device */
+  int plan_words;
+  int po_gstart, po_gflag, po_gaptr, po_grptr, po_gToff, po_fsp, po_bsp, po_acol, po_aoff, po_arow, po_coloff, po_fsb,
+      po_fsc, po_bsb, po_bsc, po_fsig, po_bsig, po_fcol, po_brs, po_perm;        /* word offsets of the sub-arrays inside `plan` */
   /* problem matrices for the residual kernels: CSC as given plus row-order (CSR) access maps */
   int *Pp, *Pi, *Prp, *Prj, *Prpos;   /* P upper triangular n x n */
   int *Ap, *Ai, *Arp, *Arj, *Arpos;   /* A m x n */
@@ -58,6 +68,13 @@ int rldl_symbolic_create(rldl_symbolic **out, long long n, long long m, const lo
                          const long long *Pi, const long long *Ap, const long long *Ai, int polish,
                          const long long *perm_in);
 void rldl_symbolic_free(rldl_symbolic *s);
+
+/* Build the grouped solve plan for s (called by rldl_symbolic_create).  Indices 0..N-1 are cut into
+ * consecutive groups of at most 64 (a dense trailing block becomes one group).  L entries whose row and
+ * column fall in the same group live in a packed, zero-padded dense triangle per group (swept with
+ * wave-level broadcasts on the device); all other entries are "out-of-group" and are gathered per lane
+ * (by row in the forward sweep, by column in the backward sweep).  Returns 0, or -2 on out of memory. */
+int rldl_plan_build(rldl_symbolic *s);
 
 /* fill-reducing ordering of a symmetric pattern given by its upper triangle (CSC, n columns) */
 int rldl_order_min_degree(int n, const int *Ap, const int *Ai, int *perm);

@@ -258,3 +258,76 @@ def symbolic_analyze(P, A, polish=0, perm=None):
     out["PtoKKT"] = out["PtoKKT"][:Pc.nnz]; out["AtoKKT"] = out["AtoKKT"][:Ac.nnz]; out["rhotoKKT"] = out["rhotoKKT"][:m]
     out.update(nnzKKT=nk.value, nnzL=nl.value, etree_height=h.value, n=n, m=m)
     return out
+
+
+def plan_export(P, A, polish=0, perm=None):
+    """Host-only export of the grouped solve plan (see csrc/rldl_plan.c): dict of numpy arrays."""
+    L = _lib.lib()
+    Pc = P if isinstance(P, CscPattern) else CscPattern(P)
+    Ac = A if isinstance(A, CscPattern) else CscPattern(A)
+    pm = None if perm is None else np.ascontiguousarray(perm, dtype=np.int64)
+    meta = np.zeros(24, np.int64)
+    if L.rldl_plan_export(Pc.ref, Ac.ref, int(polish), None if pm is None else _ip(pm), _ip(meta), None, 0, None):
+        raise ValueError("rldl_plan_export failed")
+    words, nnzL = int(meta[4]), int(meta[20])
+    blob = np.zeros(max(words, 1), np.int32)
+    LtoS = np.zeros(max(nnzL, 1), np.int64)
+    L.rldl_plan_export(Pc.ref, Ac.ref, int(polish), None if pm is None else _ip(pm), _ip(meta),
+                       blob.ctypes.data_as(C.POINTER(C.c_int)), words, _ip(LtoS))
+    names = ["plan_ok", "nS", "nO", "ngroups", "plan_words", "po_gstart", "po_gflag", "po_gToff", "po_fsp", "po_bsp", "po_fsb",
+             "po_fsc", "po_bsb", "po_bsc", "po_fsig", "po_bsig", "po_fcol", "po_brs", "po_perm", "N", "nnzL"]
+    out = {k: int(meta[i]) for i, k in enumerate(names)}
+    out["blob"] = blob[:words]
+    out["LtoS"] = LtoS[:nnzL]
+    return out
+
+
+def plan_emulate_solve(plan, S, Dinv, x):
+    """CPU emulation of the device schedule (plan_tri_solve in csrc/rldl_kernels.hip), one instance:
+    S = factor in plan slot order [nS], Dinv [N], x = permuted right-hand side [N] -> L^-T D^-1 L^-1 x."""
+    w = plan["blob"]
+    u16 = lambda off: w[off:].view(np.uint16)
+    fsig, bsig, fcol = u16(plan["po_fsig"]), u16(plan["po_bsig"]), u16(plan["po_fcol"])
+    xs = np.array(x, float)
+    ng = plan["ngroups"]
+    gs = w[plan["po_gstart"]:plan["po_gstart"] + ng + 1]
+    for k in range(ng):                                   # forward
+        g0, g = int(gs[k]), int(gs[k + 1] - gs[k])
+        fs0, fs1 = int(w[plan["po_fsp"] + k]), int(w[plan["po_fsp"] + k + 1])
+        if fs1 > fs0:
+            ga = np.array([xs[fsig[g0 + i]] for i in range(g)])
+            for t in range(fs0, fs1):
+                base, cnt = int(w[plan["po_fsb"] + t]), int(w[plan["po_fsc"] + t])
+                for i in range(cnt):
+                    ga[i] -= S[base + i] * xs[fcol[base + i]]
+            for i in range(g):
+                xs[fsig[g0 + i]] = ga[i]
+        if w[plan["po_gflag"] + k]:
+            Tb = int(w[plan["po_gToff"] + k])
+            acc = xs[g0:g0 + g].copy()
+            for a in range(g - 1):
+                for i in range(a + 1, g):
+                    acc[i] -= S[Tb + i * (i - 1) // 2 + a] * acc[a]
+            xs[g0:g0 + g] = acc
+    for k in range(ng - 1, -1, -1):                       # backward
+        g0, g = int(gs[k]), int(gs[k + 1] - gs[k])
+        bs0, bs1 = int(w[plan["po_bsp"] + k]), int(w[plan["po_bsp"] + k + 1])
+        scaled = False
+        if bs1 > bs0:
+            gb = np.array([xs[bsig[g0 + i]] * Dinv[bsig[g0 + i]] for i in range(g)])
+            for t in range(bs0, bs1):
+                base, cnt = int(w[plan["po_bsb"] + t]), int(w[plan["po_bsc"] + t])
+                for i in range(cnt):
+                    rs = int(w[plan["po_brs"] + base + i]) & 0xffffffff
+                    gb[i] -= S[rs >> 16] * xs[rs & 0xffff]
+            for i in range(g):
+                xs[bsig[g0 + i]] = gb[i]
+            scaled = True
+        acc = xs[g0:g0 + g].copy() if scaled else xs[g0:g0 + g] * Dinv[g0:g0 + g]
+        if w[plan["po_gflag"] + k]:
+            Tb = int(w[plan["po_gToff"] + k])
+            for il in range(g - 1, 0, -1):
+                for j in range(il):
+                    acc[j] -= S[Tb + il * (il - 1) // 2 + j] * acc[il]
+        xs[g0:g0 + g] = acc
+    return xs

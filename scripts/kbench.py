@@ -1,0 +1,19 @@
+#!/usr/bin/env python3
+"""Kernel micro-benchmark for the fused ADMM-iteration kernel on the metric shape (timing experiments).
+RLDL_DBG=<mask> skips phases (results are then wrong; timing only):
+  1 fwd gather, 2 fwd sweep, 4 bwd gather, 8 bwd sweep, 16 factor DMA, 32 whole tri-solve."""
+import os, sys, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import osqp_recursive_ldl_amd as R
+B = int(os.environ.get("KB_BATCH", "4096"))
+wl = R.workloads.SharedPatternQPs()
+Px, Ax, q, l, u = wl.values(B)
+t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+w = R.OSQPBatch(wl.P_pattern, wl.A_pattern, t(Px), t(Ax), t(q), t(l), t(u), rho=0.1, max_iter=20, check_termination=0,
+                adaptive_rho=0, warm_start=0, scaling=0)
+w.solve()
+ms = min(w.time_iteration(200) for _ in range(3))
+d = w.linsys().dims()
+by = 8 * (d["nnzL"] + 3 * 150 + 100) + 8 * (3 * 50 + 8 * 100)
+print(json.dumps({"dbg": os.environ.get("RLDL_DBG", "0"), "batch": B, "us_per_launch": 1e3 * ms, "GBs": by * B / (ms * 1e-3) / 1e9}))

@@ -175,3 +175,42 @@ def test_compute_entry_points_fail_loudly_without_a_device():
     Pc, Ac = R.CscPattern(wl.P_pattern), R.CscPattern(wl.A_pattern)
     rc = R.lib().rldl_batch_init(C.byref(h), 1, Pc.ref, Ac.ref, None, None, 1e-6, None, 0, None, None)
     assert rc == _lib.RLDL_NO_DEVICE_ERROR and not h.value
+
+
+@pytest.mark.parametrize("case", ["arrowhead", "small", "tiny", "mpc", "unconstrained"])
+def test_solve_plan_schedule_reproduces_the_reference_substitution(case):
+    """The device schedule (groups, jagged-diagonal gathers, packed-triangle sweeps; csrc/rldl_plan.c) emulated on
+    the CPU from the exported plan must equal the reference's column substitution (src/recursive_ldl.c:62-116) on
+    the oracle's factor -- and every L entry must own exactly one storage slot."""
+    from osqp_recursive_ldl_amd.linsys import plan_emulate_solve, plan_export
+    perm = None
+    if case == "arrowhead":
+        wl = R.workloads.SharedPatternQPs()
+    elif case == "small":
+        wl = R.workloads.SharedPatternQPs(n=20, m=35, density=0.2, pattern_seed=5)
+    elif case == "tiny":
+        wl = R.workloads.SharedPatternQPs(n=1, m=1, density=1.0, pattern_seed=9)
+    elif case == "unconstrained":
+        wl = R.workloads.SharedPatternQPs(n=7, m=0, density=0.4, pattern_seed=3)
+    else:
+        wl = R.workloads.MPCStageQPs(N=6)
+        perm = R.workloads.stage_permutation(*wl.dims)
+    n, m = wl.n, wl.m
+    P, q, A, l, u = wl.instance(0)
+    pl = plan_export(wl.P_pattern, wl.A_pattern, perm=perm)
+    sym = R.symbolic_analyze(wl.P_pattern, wl.A_pattern, perm=perm)
+    assert pl["plan_ok"] == 1 and pl["nS"] >= sym["nnzL"]
+    assert len(set(pl["LtoS"].tolist())) == sym["nnzL"] and (pl["LtoS"] < pl["nS"]).all() and (pl["LtoS"] >= 0).all()
+    gs = pl["blob"][pl["po_gstart"]:pl["po_gstart"] + pl["ngroups"] + 1]
+    assert gs[0] == 0 and gs[-1] == n + m and (np.diff(gs) > 0).all() and (np.diff(gs) <= 64).all()
+    rho = np.full(m, 0.1)
+    o = ob.OracleLinsys(P, A, 1e-6, rho, perm=sym["perm"])
+    e = o.export()
+    S = np.zeros(pl["nS"])
+    S[pl["LtoS"]] = e["Lx"]
+    rhs = np.random.default_rng(0).standard_normal(n + m)
+    got = plan_emulate_solve(pl, S, e["Dinv"], rhs[sym["perm"]])
+    ref = rhs[sym["perm"]].copy()
+    ob.lib().orc_qdldl_solve.argtypes = [ob.c_int, ob.IP, ob.IP, ob.FP, ob.FP, ob.FP]
+    ob.lib().orc_qdldl_solve(n + m, ob.ip(e["Lp"]), ob.ip(e["Li"]), ob.fp(e["Lx"]), ob.fp(e["Dinv"]), ob.fp(ref))
+    assert np.max(np.abs(got - ref)) <= 1e-12 * max(1.0, np.max(np.abs(ref)))
