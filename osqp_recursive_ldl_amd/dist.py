@@ -44,13 +44,20 @@ def gather_results(res, n, m, sizes=None):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return unpack_results(rec, n, m)
     world = dist.get_world_size()
-    if sizes is None or len(set(sizes)) == 1:
-        out = torch.empty((world * rec.shape[0], rec.shape[1]), dtype=rec.dtype, device=rec.device)
-        dist.all_gather_into_tensor(out, rec)
+    if sizes is None:
+        sizes = [rec.shape[0]] * world
+    smax = max(sizes)
+    if rec.shape[0] < smax:                              # ragged shards: pad to the largest, trim after the gather
+        pad = torch.zeros((smax - rec.shape[0], rec.shape[1]), dtype=rec.dtype, device=rec.device)
+        rec = torch.cat([rec, pad], 0)
+    if dist.get_backend() != "gloo":
+        out = torch.empty((world * smax, rec.shape[1]), dtype=rec.dtype, device=rec.device)
+        dist.all_gather_into_tensor(out, rec)          # RCCL: one collective over xGMI
+        parts = list(out.view(world, smax, rec.shape[1]).unbind(0))
     else:
-        parts = [torch.empty((s, rec.shape[1]), dtype=rec.dtype, device=rec.device) for s in sizes]
+        parts = [torch.empty((smax, rec.shape[1]), dtype=rec.dtype, device=rec.device) for _ in range(world)]
         dist.all_gather(parts, rec)
-        out = torch.cat(parts, 0)
+    out = torch.cat([p[:s] for p, s in zip(parts, sizes)], 0)
     return unpack_results(out, n, m)
 
 
