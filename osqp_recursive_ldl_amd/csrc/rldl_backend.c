@@ -65,7 +65,15 @@ static int upload_symbolic(rldl_batch *h) {
   D->po_gToff = s->po_gToff; D->po_fsp = s->po_fsp; D->po_bsp = s->po_bsp; D->po_acol = s->po_acol; D->po_aoff = s->po_aoff;
   D->po_arow = s->po_arow; D->po_coloff = s->po_coloff; D->po_fsb = s->po_fsb; D->po_fsc = s->po_fsc; D->po_bsb = s->po_bsb;
   D->po_bsc = s->po_bsc; D->po_fsig = s->po_fsig; D->po_bsig = s->po_bsig; D->po_fcol = s->po_fcol; D->po_brs = s->po_brs;
-  D->po_perm = s->po_perm;
+  D->po_perm = s->po_perm; D->po_apad = s->po_apad; D->nOp = s->nOp;
+  D->arrow_ok = s->plan_ok ? s->arrow_ok : 0; D->arrow_group = s->arrow_group; D->arrow_steps = s->arrow_steps;
+  if (D->arrow_ok) {
+    int t, f0 = s->plan[s->po_fsp + s->arrow_group];
+    D->arrow_g0 = s->plan[s->po_gstart + s->arrow_group];
+    D->arrow_g = s->plan[s->po_gstart + s->arrow_group + 1] - D->arrow_g0;
+    D->arrow_tb = s->plan[s->po_gflag + s->arrow_group] ? s->plan[s->po_gToff + s->arrow_group] - s->nOp : -1;
+    for (t = 0; t < s->arrow_steps && t < 32; t++) { D->arrow_base[t] = s->plan[s->po_fsb + f0 + t]; D->arrow_cnt[t] = s->plan[s->po_fsc + f0 + t]; }
+  }
 #undef UP
   return ok ? 0 : -1;
 }

@@ -873,6 +873,293 @@ __global__ __launch_bounds__(1024) void k_plan_admm(rldl_dev_sym S, rldl_dev_num
   }
 }
 
+
+// ================================================================================================
+// Arrowhead specialisation (plan->arrow_ok): all out-of-group entries feed ONE dense group (the Schur
+// tail of a KKT matrix ordered by minimum degree) and no other group has a triangle.  Then
+//   * the coupling values (jagged-diagonal order, one row per lane) are loaded STRAIGHT from HBM into
+//     registers -- fully coalesced, never staged in LDS -- together with their column indices from a
+//     padded [step][64] table;
+//   * forward: the tail rows gather from the (already final) head entries out of registers, then the
+//     packed triangle is swept forward and -- without leaving registers -- scaled by Dinv and swept back;
+//   * backward for the head columns is the transposed gather: every tail lane scatters L(r,c) x_r into
+//     x_c with LDS double atomics (ds_add_f64) from the same registers.
+// LDS per wave is only the triangle + Dinv + x (12.2 KB at the metric shape -> 12 waves per CU), there is
+// no shared plan copy and therefore no workgroup barrier.
+// ================================================================================================
+template <int TG>
+struct ArrowRegs {
+  double v[TG];            // coupling values of this lane's row, step-major
+  unsigned ix[(TG + 1) / 2];  // packed column indices: step 2k in the low half, 2k+1 in the high half
+};
+
+// loads issued by every live wave before its first wait
+template <int TG>
+__device__ __forceinline__ void arrow_load_idx(const rldl_dev_sym &S, int lane, ArrowRegs<TG> &R) {
+  const unsigned *ap = reinterpret_cast<const unsigned *>(S.plan + S.po_apad);
+#pragma unroll
+  for (int t2 = 0; t2 < (TG + 1) / 2; t2++) R.ix[t2] = 2 * t2 < S.arrow_steps ? ap[t2 * 64 + lane] : 0u;
+}
+// coupling values: LDS (slots [0, nOp) staged by LDS-DMA at the start of the wave's buffer) -> registers
+template <int TG>
+__device__ __forceinline__ void arrow_load_val(const rldl_dev_sym &S, const double *Ov, int lane, ArrowRegs<TG> &R) {
+#pragma unroll
+  for (int t = 0; t < TG; t++) {
+    double val = 0.0;
+    if (t < S.arrow_steps) {                                    // uniform
+      const int base = S.arrow_base[t], cnt = S.arrow_cnt[t];   // kernarg segment -> scalar loads
+      val = Ov[base + (lane < cnt ? lane : 0)];
+      val = lane < cnt ? val : 0.0;
+    }
+    R.v[t] = val;
+  }
+}
+
+// Tv: LDS [triangle | Dinv] = factor slots [nOp, ldF); xs: LDS permuted rhs in / solution out
+template <int TG>
+__device__ __forceinline__ void arrow_tri_solve(const rldl_dev_sym &S, const ArrowRegs<TG> &R, const double *Tv, double *xs,
+                                                int g0, int g, int jr, int lane) {
+  const double *Dinv = Tv + (S.nS - S.nOp);
+  const bool act = lane < g;
+  const int nst = (S.dbg & 2) ? 0 : g - 1;
+  // ---- forward gather of the tail rows out of registers ----
+  double ga = act ? xs[jr] : 0.0;
+  if (!(S.dbg & 1)) {
+#pragma unroll
+    for (int t = 0; t < TG; t++)
+      if (t < S.arrow_steps) {
+        const unsigned col = (t & 1) ? R.ix[t >> 1] >> 16 : R.ix[t >> 1] & 0xffffu;
+        ga = fma(-R.v[t], xs[col], ga);
+      }
+  }
+  if (act) xs[jr] = ga;
+  wave_sync();
+  double acc = act ? xs[g0 + lane] : 0.0;
+  const int lc = act ? lane : g - 1;
+  if (S.arrow_tb >= 0) {
+    const int Tb = S.arrow_tb;
+    // ---- forward sweep (row-major packed triangle: lane i reads rowp[a]) ----
+    {
+      const double *rowp = Tv + Tb + ((lc * (lc - 1)) >> 1);
+      double tA[SU], tB[SU];
+      auto loadF = [&](int s0, double (&tb)[SU]) {
+#pragma unroll
+        for (int u = 0; u < SU; u++) tb[u] = rowp[s0 + u];
+      };
+      auto procF = [&](int s0, const double (&tb)[SU]) {
+#pragma unroll
+        for (int u = 0; u < SU; u++) {
+          const int a = s0 + u;
+          if (a < nst) {
+            const double xj = readlane_f64(acc, a);
+            if (lane > a) acc = fma(-tb[u], xj, acc);
+          }
+        }
+      };
+      loadF(0, tA);
+      for (int a = 0; a < nst; a += 2 * SU) {
+        loadF(a + SU, tB);
+        procF(a, tA);
+        loadF(a + 2 * SU, tA);
+        procF(a + SU, tB);
+      }
+    }
+    // ---- D^-1, then backward sweep, all in registers ----
+    if (act) acc *= Dinv[g0 + lane];
+    if (!(S.dbg & 8)) {
+      const double *lanep = Tv + Tb + lane;
+      double tA[SU], tB[SU];
+      auto loadB = [&](int s0, double (&tb)[SU]) {
+#pragma unroll
+        for (int u = 0; u < SU; u++) {
+          int il = g - 1 - (s0 + u);
+          il = il > 0 ? il : 0;
+          tb[u] = lanep[(il * (il - 1)) >> 1];
+        }
+      };
+      auto procB = [&](int s0, const double (&tb)[SU]) {
+#pragma unroll
+        for (int u = 0; u < SU; u++) {
+          const int il = g - 1 - (s0 + u);
+          if (il > 0) {
+            const double xi = readlane_f64(acc, il);
+            if (lane < il) acc = fma(-tb[u], xi, acc);
+          }
+        }
+      };
+      loadB(0, tA);
+      for (int a = 0; a < g - 1; a += 2 * SU) {
+        loadB(a + SU, tB);
+        procB(a, tA);
+        loadB(a + 2 * SU, tA);
+        procB(a + SU, tB);
+      }
+    }
+  } else if (act) {
+    acc *= Dinv[g0 + lane];
+  }
+  if (act) xs[g0 + lane] = acc;
+  // every index outside the tail group: x = y * Dinv (its forward step was the identity)
+  for (int j = lane; j < S.N; j += WAVE)
+    if (j < g0 || j >= g0 + g) xs[j] *= Dinv[j];
+  wave_sync();
+  // ---- transposed gather: scatter L(r, c) x_r into the head columns with LDS double atomics ----
+  if (!(S.dbg & 4)) {
+    const double xr = act ? xs[jr] : 0.0;
+#pragma unroll
+    for (int t = 0; t < TG; t++)
+      if (t < S.arrow_steps) {
+        const unsigned col = (t & 1) ? R.ix[t >> 1] >> 16 : R.ix[t >> 1] & 0xffffu;
+        const double pr = R.v[t] * xr;
+        if (R.v[t] != 0.0) unsafeAtomicAdd(&xs[col], -pr);
+      }
+  }
+  wave_sync();
+}
+
+// triangle + Dinv part of the factor row -> LDS by LDS-DMA (slots [nOp, ldF), 16-byte aligned since nOp is even)
+__device__ __forceinline__ void arrow_stage(const rldl_dev_sym &S, const double *Fg, double *Tv, int lane, int first) {
+  typedef __attribute__((address_space(1))) const void *gptr_t;
+  typedef __attribute__((address_space(3))) void *lptr_t;
+  // first != 0: coupling values, slots [0, nOp); else triangle + Dinv, slots [nOp, ldF).  Both land at Tv.
+  const int n2 = first ? S.nOp >> 1 : (S.ldF - S.nOp) >> 1;
+  const double *src = first ? Fg : Fg + S.nOp;
+  for (int base = 0; base < n2; base += WAVE) {
+    const int i = base + lane;
+    if (i < n2) __builtin_amdgcn_global_load_lds((gptr_t)(src + 2 * (size_t)i), (lptr_t)(Tv + 2 * (size_t)base), 16, 0, 0);
+  }
+}
+
+template <int TG>
+__global__ __launch_bounds__(256, 3) void k_arrow_solve(rldl_dev_sym S, rldl_dev_num Nn, double *__restrict__ b_all, int per_wave) {
+  extern __shared__ __attribute__((aligned(16))) double sh[];
+  const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+  const int inst = blockIdx.x * wpb + wv;
+  if (inst >= Nn.batch) return;
+  double *Tv = sh + (size_t)wv * per_wave;
+  double *xs = Tv + (per_wave - ((S.N + 1) & ~1) - 2);
+  const double *Fg = Nn.F + (size_t)inst * S.ldF;
+  double *b = b_all + (size_t)inst * S.N;
+  const int *permg = S.plan + S.po_perm;
+  const int g0 = S.arrow_g0, g = S.arrow_g;
+  ArrowRegs<TG> R;
+  arrow_stage(S, Fg, Tv, lane, 1);                              // coupling values first ...
+  arrow_load_idx<TG>(S, lane, R);
+  const int jr = lane < g ? reinterpret_cast<const unsigned short *>(S.plan + S.po_fsig)[g0 + lane] : 0;
+  wait_dma();
+  arrow_load_val<TG>(S, Tv, lane, R);                           // ... into registers ...
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  arrow_stage(S, Fg, Tv, lane, 0);                              // ... then the triangle + Dinv over the same LDS
+  for (int j0 = 0; j0 < S.N; j0 += 4 * WAVE) {                 // permute_x  qdldl_interface.c:538-541
+    double v[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) { const int j = j0 + t * WAVE + lane; v[t] = j < S.N ? b[permg[j]] : 0.0; }
+#pragma unroll
+    for (int t = 0; t < 4; t++) { const int j = j0 + t * WAVE + lane; if (j < S.N) xs[j] = v[t]; }
+  }
+  wait_dma();
+  wave_sync();
+  arrow_tri_solve<TG>(S, R, Tv, xs, g0, g, jr, lane);
+  if (S.polish) {
+    for (int j = lane; j < S.N; j += WAVE) b[permg[j]] = xs[j];
+  } else {
+    const double *ri = Nn.rho_inv + (size_t)inst * S.m;
+    for (int j0 = 0; j0 < S.N; j0 += 4 * WAVE) {
+      double bo[4], rr[4];
+      int oo[4];
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        const int j = j0 + t * WAVE + lane;
+        oo[t] = j < S.N ? permg[j] : -1;
+        const int ic = oo[t] >= S.n ? oo[t] - S.n : 0;
+        bo[t] = b[oo[t] >= S.n ? oo[t] : 0];
+        rr[t] = ri[ic];
+      }
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        const int j = j0 + t * WAVE + lane;
+        if (oo[t] < 0) continue;
+        if (oo[t] < S.n) b[oo[t]] = xs[j];
+        else b[oo[t]] = bo[t] + rr[t] * xs[j];
+      }
+    }
+  }
+}
+
+template <int TMAX, int TG>
+__global__ __launch_bounds__(256, 3) void k_arrow_admm(rldl_dev_sym S, rldl_dev_num Nn, rldl_dev_admm W, int per_wave) {
+  extern __shared__ __attribute__((aligned(16))) double sh[];
+  const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+  const int inst = blockIdx.x * wpb + wv;
+  if (inst >= Nn.batch) return;
+  const int st = W.status[inst];                                // latency overlaps with the index loads below
+  double *Tv = sh + (size_t)wv * per_wave;
+  double *xs = Tv + (per_wave - ((S.N + 1) & ~1) - 2);
+  const int *permg = S.plan + S.po_perm;
+  int oo[TMAX];
+#pragma unroll
+  for (int t = 0; t < TMAX; t++) { const int j = t * WAVE + lane; oo[t] = j < S.N ? permg[j] : -1; }
+  const int g0 = S.arrow_g0, g = S.arrow_g;
+  const int jr = lane < g ? reinterpret_cast<const unsigned short *>(S.plan + S.po_fsig)[g0 + lane] : 0;
+  if (st != ST_UNSOLVED) return;
+  const int n = S.n, m = S.m;
+  const size_t io = (size_t)inst;
+  const double *Fg = Nn.F + io * S.ldF;
+  const double *ri = Nn.rho_inv + io * m;
+  double *x = W.x + io * n, *z = W.z + io * m, *y = W.y + io * m;
+  const double *q = W.q + io * n, *l = W.l + io * m, *u = W.u + io * m, *rv = W.rho_vec + io * m;
+  ArrowRegs<TG> R;
+  arrow_stage(S, Fg, Tv, lane, 1);                              // coupling values first ...
+  arrow_load_idx<TG>(S, lane, R);
+  double va[TMAX], vb[TMAX], vr[TMAX], vl[TMAX], vu[TMAX], vrho[TMAX];
+#pragma unroll
+  for (int t = 0; t < TMAX; t++) {
+    const int o = oo[t];
+    const bool con = o >= n;
+    const int iv = con || o < 0 ? 0 : o, ic = con ? o - n : 0;
+    const double *pa = con ? z + ic : x + iv;
+    const double *pb = con ? y + ic : q + iv;
+    va[t] = *pa; vb[t] = *pb; vr[t] = ri[ic]; vl[t] = l[ic]; vu[t] = u[ic]; vrho[t] = rv[ic];
+  }
+  wait_dma();
+  arrow_load_val<TG>(S, Tv, lane, R);                           // ... into registers ...
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (!(S.dbg & 16)) arrow_stage(S, Fg, Tv, lane, 0);           // ... then the triangle + Dinv over the same LDS
+#pragma unroll
+  for (int t = 0; t < TMAX; t++) {                              // compute_rhs (auxil.c:164-178) in permuted order
+    const int j = t * WAVE + lane;
+    if (oo[t] >= 0) xs[j] = oo[t] < n ? W.sigma * va[t] - vb[t] : va[t] - vr[t] * vb[t];
+  }
+  wait_dma();
+  wave_sync();
+  if (!(S.dbg & 32)) arrow_tri_solve<TG>(S, R, Tv, xs, g0, g, jr, lane);
+  const double alpha = W.alpha;
+  double *dx = W.delta_x + io * n, *dy = W.delta_y + io * m;
+#pragma unroll
+  for (int t = 0; t < TMAX; t++) {
+    const int o = oo[t];
+    if (o < 0) continue;
+    const double s = xs[t * WAVE + lane];
+    if (o < n) {
+      const double xp = va[t];
+      const double xn = alpha * s + (1.0 - alpha) * xp;       // update_x :188-201
+      x[o] = xn;
+      dx[o] = xn - xp;
+    } else {
+      const int i = o - n;
+      const double zp = va[t], yi = vb[t], r = vr[t];
+      const double zt = (zp - r * yi) + r * s;                 // z_tilde, qdldl_interface.c:577-579
+      const double mix = alpha * zt + (1.0 - alpha) * zp;
+      double zn = mix + r * yi;                                // update_z :203-215
+      zn = fmin(fmax(zn, vl[t]), vu[t]);                       // project, proj.c:4-14
+      const double d = vrho[t] * (mix - zn);                   // update_y :217-228
+      z[i] = zn;
+      dy[i] = d;
+      y[i] = yi + d;
+    }
+  }
+}
+
 }  // namespace
 
 // ================================================================================================
@@ -942,6 +1229,76 @@ static int launch_plan_admm(const rldl_dev_sym *S, const rldl_dev_num *Nn, const
   return launch_plan_admm_t<8>(S, Nn, W, stream);
 }
 
+
+// ---- arrowhead kernels: geometry ----
+static int arrow_per_wave_doubles(const rldl_dev_sym *S) {
+  const int stage = S->ldF - S->nOp > S->nOp ? S->ldF - S->nOp : S->nOp;   // the two halves of the row share this buffer
+  return stage + ((S->N + 1) & ~1) + 2;
+}
+static int arrow_pick_wpb(const rldl_dev_sym *S, const void *kernel, size_t *lds_out) {
+  static const void *ck = 0; static int cl = -1, cn = -1, cbest = 0; static size_t clds = 0;
+  if (ck == kernel && cl == S->ldF && cn == S->nOp) { *lds_out = clds; return cbest; }
+  int best = 0, best_waves = 0; size_t best_lds = 0;
+  const char *force = getenv("RLDL_WPB");
+  for (int wpb = 1; wpb <= 4; wpb *= 2) {                      // kernels are compiled for at most 256 threads
+    const size_t b = sizeof(double) * (size_t)wpb * (size_t)arrow_per_wave_doubles(S);
+    if (b > (size_t)LDS_PER_CU) continue;
+    if (force && atoi(force) != wpb) continue;
+    if (b > 64 * 1024 && hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b) != hipSuccess) continue;
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, wpb * WAVE, b) != hipSuccess) continue;
+    if (nb * wpb > best_waves) { best = wpb; best_waves = nb * wpb; best_lds = b; }
+  }
+  (void)hipGetLastError();
+  ck = kernel; cl = S->ldF; cn = S->nOp; cbest = best; clds = best_lds;
+  if (getenv("RLDL_VERBOSE")) fprintf(stderr, "[rldl] arrow kernel: wpb=%d, %d waves/CU, %zu B LDS per workgroup\n", best, best_waves, best_lds);
+  *lds_out = best_lds;
+  return best;
+}
+static bool arrow_usable(const rldl_dev_sym *S) {
+  return S->plan_ok && S->arrow_ok && S->arrow_steps <= 32 && !getenv("RLDL_NO_ARROW") &&
+         sizeof(double) * (size_t)arrow_per_wave_doubles(S) <= (size_t)LDS_PER_CU;
+}
+template <int TG>
+static int launch_arrow_solve_t(const rldl_dev_sym *S, const rldl_dev_num *Nn, double *d_b, void *stream) {
+  size_t lds = 0;
+  const int wpb = arrow_pick_wpb(S, (const void *)k_arrow_solve<TG>, &lds);
+  if (wpb <= 0) return -1;
+  if (lds > 64 * 1024 && hipFuncSetAttribute((const void *)k_arrow_solve<TG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+  hipLaunchKernelGGL(k_arrow_solve<TG>, dim3((Nn->batch + wpb - 1) / wpb), dim3(wpb * WAVE), lds, (hipStream_t)stream, *S, *Nn, d_b,
+                     arrow_per_wave_doubles(S));
+  return launch_status();
+}
+static int launch_arrow_solve(const rldl_dev_sym *S, const rldl_dev_num *Nn, double *d_b, void *stream) {
+  if (S->arrow_steps <= 8) return launch_arrow_solve_t<8>(S, Nn, d_b, stream);
+  if (S->arrow_steps <= 16) return launch_arrow_solve_t<16>(S, Nn, d_b, stream);
+  if (S->arrow_steps <= 24) return launch_arrow_solve_t<24>(S, Nn, d_b, stream);
+  return launch_arrow_solve_t<32>(S, Nn, d_b, stream);
+}
+template <int TMAX, int TG>
+static int launch_arrow_admm_t(const rldl_dev_sym *S, const rldl_dev_num *Nn, const rldl_dev_admm *W, void *stream) {
+  size_t lds = 0;
+  const int wpb = arrow_pick_wpb(S, (const void *)k_arrow_admm<TMAX, TG>, &lds);
+  if (wpb <= 0) return -1;
+  if (lds > 64 * 1024 && hipFuncSetAttribute((const void *)k_arrow_admm<TMAX, TG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+  hipLaunchKernelGGL((k_arrow_admm<TMAX, TG>), dim3((Nn->batch + wpb - 1) / wpb), dim3(wpb * WAVE), lds, (hipStream_t)stream, *S, *Nn, *W,
+                     arrow_per_wave_doubles(S));
+  return launch_status();
+}
+template <int TMAX>
+static int launch_arrow_admm_g(const rldl_dev_sym *S, const rldl_dev_num *Nn, const rldl_dev_admm *W, void *stream) {
+  if (S->arrow_steps <= 8) return launch_arrow_admm_t<TMAX, 8>(S, Nn, W, stream);
+  if (S->arrow_steps <= 16) return launch_arrow_admm_t<TMAX, 16>(S, Nn, W, stream);
+  if (S->arrow_steps <= 24) return launch_arrow_admm_t<TMAX, 24>(S, Nn, W, stream);
+  return launch_arrow_admm_t<TMAX, 32>(S, Nn, W, stream);
+}
+static int launch_arrow_admm(const rldl_dev_sym *S, const rldl_dev_num *Nn, const rldl_dev_admm *W, void *stream) {
+  if (S->N <= 2 * WAVE) return launch_arrow_admm_g<2>(S, Nn, W, stream);
+  if (S->N <= 3 * WAVE) return launch_arrow_admm_g<3>(S, Nn, W, stream);
+  if (S->N <= 4 * WAVE) return launch_arrow_admm_g<4>(S, Nn, W, stream);
+  return launch_arrow_admm_g<8>(S, Nn, W, stream);
+}
+
 extern "C" int rldl_launch_kkt_assemble(const rldl_dev_sym *S, const rldl_dev_num *Nn, const double *d_Px,
                                         const double *d_Ax, const double *d_rho_vec, int set_sigma_only,
                                         const int *d_mask, void *stream) {
@@ -972,6 +1329,7 @@ extern "C" int rldl_launch_factor_from(const rldl_dev_sym *S, const rldl_dev_num
 
 extern "C" int rldl_launch_solve(const rldl_dev_sym *S, const rldl_dev_num *Nn, double *d_b, void *stream) {
   if (Nn->batch <= 0) return 0;
+  if (arrow_usable(S)) return launch_arrow_solve(S, Nn, d_b, stream);
   if (plan_usable(S)) return launch_plan_solve(S, Nn, d_b, stream);
   const size_t lds = sizeof(double) * (size_t)(S->nS + S->N);
   if (lds <= RLDL_LDS_LIMIT)
@@ -984,6 +1342,7 @@ extern "C" int rldl_launch_solve(const rldl_dev_sym *S, const rldl_dev_num *Nn, 
 
 extern "C" int rldl_launch_admm_iter(const rldl_dev_sym *S, const rldl_dev_num *Nn, const rldl_dev_admm *W, void *stream) {
   if (Nn->batch <= 0) return 0;
+  if (arrow_usable(S) && S->N <= 8 * WAVE) return launch_arrow_admm(S, Nn, W, stream);
   if (plan_admm_usable(S)) return launch_plan_admm(S, Nn, W, stream);
   const size_t lds = sizeof(double) * (size_t)(S->nS + S->N);
   if (lds <= RLDL_LDS_LIMIT)

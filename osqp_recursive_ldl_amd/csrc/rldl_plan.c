@@ -37,7 +37,8 @@ int rldl_plan_build(rldl_symbolic *s) {
       *fstep_ptr = 0, *bstep_ptr = 0, *slot_of_csr = 0;
   unsigned char *col_active = 0, *row_active = 0;
   kv *order = 0;
-  int ng = 0, i, k, c, p, q, nO = 0, tri = 0, na = 0, nr = 0, words, nfs = 0, nbs = 0, rc = -2;
+  int ng = 0, i, k, c, p, q, nO = 0, nOp = 0, tri = 0, na = 0, nr = 0, words, nfs = 0, nbs = 0, rc = -2;
+  int arrow_k = -1, arrow_steps = 0, ngather = 0, ntri = 0;
 
   s->plan_ok = 0;
   s->LtoS = (int *)malloc(sizeof(int) * (size_t)(s->nnzL > 0 ? s->nnzL : 1));
@@ -104,14 +105,16 @@ int rldl_plan_build(rldl_symbolic *s) {
     }
   if (N >= 65536 || nO >= 65536) { rc = 0; goto out; }       /* packed 16-bit fields would overflow */
 
-  /* triangle base slots (absolute); coloff[] is reused as "triangle base of the index's group" (-1: none) */
+  /* triangle base slots (absolute); coloff[] is reused as "triangle base of the index's group" (-1: none).
+   * The triangles start at an even slot so the part of the row behind the gather values is 16-byte aligned. */
+  nOp = (nO + 1) & ~1;
   for (k = 0; k < ng; k++) {
     int g0 = gstart[k], g = gstart[k + 1] - g0, any = 0;
     for (i = 0; i < g; i++) any |= col_active[g0 + i];
-    for (i = 0; i < g; i++) coloff[g0 + i] = any ? nO + tri : -1;
+    for (i = 0; i < g; i++) coloff[g0 + i] = any ? nOp + tri : -1;
     if (any) { tri += g * (g - 1) / 2; na += g - 1; nr += g - 1; }
   }
-  s->nO = nO; s->nS = nO + tri; s->ngroups = ng;
+  s->nO = nO; s->nOp = nOp; s->nS = nOp + tri; s->ngroups = ng;
 
   /* ---- jagged-diagonal orders: count steps ---- */
   fstep_ptr = (int *)calloc((size_t)ng + 1, sizeof(int));
@@ -147,6 +150,17 @@ int rldl_plan_build(rldl_symbolic *s) {
   s->po_fcol = words; words += (nO + 1) / 2;
   s->po_brs = words; words += nO;
   s->po_perm = words; words += N;
+  /* "arrowhead" patterns: exactly one group receives out-of-group entries (the dense Schur tail of a KKT matrix)
+   * and no other group has a triangle.  They get a padded [step][64] column-index table so the device can keep
+   * the coupling values and their indices in registers (k_arrow_* kernels). */
+  for (k = 0; k < ng; k++) {
+    if (fstep_ptr[k + 1] > fstep_ptr[k]) { ngather++; arrow_k = k; arrow_steps = fstep_ptr[k + 1] - fstep_ptr[k]; }
+    if (coloff[gstart[k]] >= 0) ntri++;
+  }
+  s->arrow_ok = (ngather == 1 && arrow_steps <= 32 && ntri <= 1 && (ntri == 0 || coloff[gstart[arrow_k]] >= 0)) ? 1 : 0;
+  s->arrow_group = s->arrow_ok ? arrow_k : -1;
+  s->arrow_steps = s->arrow_ok ? arrow_steps : 0;
+  s->po_apad = words; words += s->arrow_ok ? ((arrow_steps + 1) / 2) * 64 : 0;   /* dword [ceil(steps/2)][64]: idx(t even) | idx(t odd) << 16 */
   blob = (int *)calloc((size_t)words + 4, sizeof(int));
   if (!blob) goto out;
 
@@ -191,6 +205,13 @@ int rldl_plan_build(rldl_symbolic *s) {
       }
     }
     for (k = 0; k < nfs; k++) { blob[s->po_fsb + k] = fsteps_base[k]; blob[s->po_fsc + k] = fsteps_cnt[k]; }
+    if (s->arrow_ok) {                                       /* padded column indices; padding -> column 0 (its value is 0) */
+      unsigned *apad = (unsigned *)(blob + s->po_apad);
+      int t, f0 = fstep_ptr[arrow_k];
+      for (t = 0; t < arrow_steps; t++)
+        for (i = 0; i < fsteps_cnt[f0 + t]; i++)
+          apad[(t >> 1) * 64 + i] |= (unsigned)fcol[fsteps_base[f0 + t] + i] << (16 * (t & 1));
+    }
   }
   /* storage map: CSC position -> slot */
   for (i = 0; i < N; i++)
@@ -245,7 +266,7 @@ int rldl_plan_build(rldl_symbolic *s) {
 out:
   if (rc == 0 && !s->plan_ok) {                               /* identity layout for the generic kernels */
     for (p = 0; p < s->nnzL; p++) s->LtoS[p] = p;
-    s->nS = s->nnzL; s->nO = s->nnzL; s->ngroups = 0;
+    s->nS = s->nnzL; s->nO = s->nnzL; s->nOp = s->nnzL; s->ngroups = 0; s->arrow_ok = 0;
   }
   free(group_of); free(gstart); free(col_active); free(row_active); free(coloff); free(rowcnt); free(colcnt);
   free(fpos_of_row); free(bpos_of_col); free(order); free(slot_of_csr);
