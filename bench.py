@@ -118,11 +118,20 @@ def main():
                                "adaptive_rho=0, check_termination=0, scaling=0)" % (B, args.iters),
                    "batch_per_gpu": B, "n": n, "m": m, "nnzKKT": dims["nnzKKT"], "nnzL": dims["nnzL"],
                    "admm_iters": args.iters, "parallelism": "batch-sharded x%d, all-gather of results" % world},
-        "roofline": {"bound": "hbm", "kernel": "k_admm_iter (fused rhs + permuted tri-solve + x/z/y update)",
+        "roofline": {"bound": "hbm", "kernel": "fused ADMM iteration: rhs + permuted tri-solve + x/z/y update (k_arrow_admm on arrowhead patterns, else k_plan_admm)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": None, "bytes_per_instance": iter_bytes, "tri_solve_bytes_per_instance": tri_bytes,
                      "kernel_ms": k_ms},
     }
+    # HBM traffic of the same kernel comes from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE cannot
+    # be read from inside the process); it is reported only when it was measured on this very configuration
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_v4_pmc_traffic.json")))
+        if B == 4096 and pmc.get("algorithmic_bytes_per_launch") == iter_bytes * B:
+            out["roofline"]["traffic"] = pmc["traffic_bytes_per_launch"]
+            out["roofline"]["traffic_source"] = "profiles/r1_v4_pmc_traffic.json (rocprofv3 --pmc, separate passes)"
+    except (OSError, ValueError):
+        pass
     status = res["status"]
     out["config"]["status_counts"] = {str(int(k)): int((status == k).sum()) for k in torch.unique(status)}
 

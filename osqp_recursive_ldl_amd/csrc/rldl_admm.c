@@ -199,11 +199,14 @@ c_int osqp_batch_solve(osqp_batch *w) {
   (void)hipEventRecord((hipEvent_t)w->ev0, st);
   for (iter = 1; iter <= w->st.max_iter; iter++) {
     int do_adapt;
+    can_check = w->st.check_termination && (iter % w->st.check_termination == 0);
+    do_adapt = w->st.adaptive_rho && w->st.adaptive_rho_interval && (iter % w->st.adaptive_rho_interval == 0);
+    /* delta_x / delta_y feed only the infeasibility tests of a check: store them just on those iterations
+     * (and on the last one, whose check is the tail of osqp_solve) */
+    w->W.write_delta = (can_check || do_adapt || iter == w->st.max_iter) ? 1 : 0;
     if (rldl_launch_admm_iter(&w->ls->dsym, &w->ls->num, &w->W, w->stream)) return 1;
     launches++;
     last_iter = iter;
-    can_check = w->st.check_termination && (iter % w->st.check_termination == 0);
-    do_adapt = w->st.adaptive_rho && w->st.adaptive_rho_interval && (iter % w->st.adaptive_rho_interval == 0);
     if (can_check || do_adapt) {
       if (rldl_launch_admm_check(&w->ls->dsym, &w->W, (int)iter, (can_check ? 1 : 0) | (do_adapt ? 2 : 0), 0, w->stream)) return 1;
       if (do_adapt) { /* osqp_update_rho -> update_rho_vec -> refactor, only where rho moved */
@@ -305,6 +308,7 @@ c_int osqp_batch_time_iteration(osqp_batch *w, c_int reps, c_float *ms_per_launc
     return 0;
   }
   if (fill_int(w, w->W.status, ST_UNSOLVED)) return 1;
+  w->W.write_delta = 0;
   (void)hipEventRecord((hipEvent_t)w->ev0, (hipStream_t)w->stream);
   for (r = 0; r < reps; r++)
     if (rldl_launch_admm_iter(&w->ls->dsym, &w->ls->num, &w->W, w->stream)) return 1;

@@ -57,6 +57,7 @@ typedef struct {
   int *status, *iter, *rho_updates;                    /* [batch] */
   int *refactor;                                       /* [batch] mask written by the adapt-rho step */
   int *n_active;                                       /* [1] instances still iterating */
+  int write_delta;                                     /* 1: this iteration also stores delta_x / delta_y (a check follows) */
 } rldl_dev_admm;
 
 /* shared-memory footprint (bytes) of the LDS-resident variants; the launchers pick the global-memory

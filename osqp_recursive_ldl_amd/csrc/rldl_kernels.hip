@@ -266,7 +266,7 @@ __global__ __launch_bounds__(WAVE) void k_admm_iter(rldl_dev_sym S, rldl_dev_num
       const double xp = x[o];
       const double xn = alpha * s + (1.0 - alpha) * xp;       // update_x :188-201
       x[o] = xn;
-      dx[o] = xn - xp;
+      if (W.write_delta) dx[o] = xn - xp;
     } else {
       const int i = o - n;
       const double zp = z[i], yi = y[i], r = ri[i];
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(WAVE) void k_admm_iter(rldl_dev_sym S, rldl_dev_num
       zn = fmin(fmax(zn, l[i]), u[i]);                         // project, proj.c:4-14
       const double d = rv[i] * (mix - zn);                     // update_y :217-228
       z[i] = zn;
-      dy[i] = d;
+      if (W.write_delta) dy[i] = d;
       y[i] = yi + d;
     }
   }
@@ -552,6 +552,76 @@ __device__ __forceinline__ double readlane_f64(double v, int src) {   // src mus
 
 
 #define SU 8   // sweep steps whose L reads are kept in flight (two batches, ping-pong)
+
+// In-group sweeps over a row-major packed triangle T (base pointer Tp, group size g); one lane per index.
+// Branch-free inside a batch: the lane predicate and the step-range predicate select the MULTIPLIER (which is
+// off the dependency chain), so the chain per step is v_readlane x2 -> v_fma_f64 only.
+//   forward : step a eliminates local column a; lane i > a reads L(i, a) = rowp[a], rowp = Tp + i (i-1)/2
+//   backward: step s uses local row il = g-1-s; lane j < il reads L(il, j) = Tp[il (il-1)/2 + j]
+__device__ __forceinline__ double sweep_fwd(const double *Tp, int g, int lane, double acc) {
+  const int nst = g - 1, nb = (nst + SU - 1) / SU;
+  const int lc = lane < g ? lane : g - 1;
+  const double *rowp = Tp + ((lc * (lc - 1)) >> 1);
+  double tA[SU], tB[SU];
+  auto load = [&](int s0, double (&tb)[SU]) {
+#pragma unroll
+    for (int u = 0; u < SU; u++) tb[u] = rowp[s0 + u];         // reads past the row / the triangle are masked below
+  };
+  auto proc = [&](int s0, const double (&tb)[SU]) {
+#pragma unroll
+    for (int u = 0; u < SU; u++) {
+      const int a = s0 + u;
+      const double tm = (lane > a && a < nst) ? tb[u] : 0.0;
+      const double xj = readlane_f64(acc, a & 63);
+      acc = fma(-tm, xj, acc);
+    }
+  };
+  int b = 0;
+  if (nb > 0) load(0, tA);
+  while (b + 2 <= nb) {
+    load((b + 1) * SU, tB);
+    proc(b * SU, tA);
+    if (b + 2 < nb) load((b + 2) * SU, tA);
+    proc((b + 1) * SU, tB);
+    b += 2;
+  }
+  if (b < nb) proc(b * SU, tA);
+  return acc;
+}
+__device__ __forceinline__ double sweep_bwd(const double *Tp, int g, int lane, double acc) {
+  const int nst = g - 1, nb = (nst + SU - 1) / SU;
+  const double *lanep = Tp + lane;
+  double tA[SU], tB[SU];
+  auto load = [&](int s0, double (&tb)[SU]) {
+#pragma unroll
+    for (int u = 0; u < SU; u++) {
+      int il = g - 1 - (s0 + u);
+      il = il > 0 ? il : 0;
+      tb[u] = lanep[(il * (il - 1)) >> 1];
+    }
+  };
+  auto proc = [&](int s0, const double (&tb)[SU]) {
+#pragma unroll
+    for (int u = 0; u < SU; u++) {
+      const int il = g - 1 - (s0 + u);
+      const double tm = (il > 0 && lane < il) ? tb[u] : 0.0;
+      const double xi = readlane_f64(acc, il > 0 ? il : 0);
+      acc = fma(-tm, xi, acc);
+    }
+  };
+  int b = 0;
+  if (nb > 0) load(0, tA);
+  while (b + 2 <= nb) {
+    load((b + 1) * SU, tB);
+    proc(b * SU, tA);
+    if (b + 2 < nb) load((b + 2) * SU, tA);
+    proc((b + 1) * SU, tB);
+    b += 2;
+  }
+  if (b < nb) proc(b * SU, tA);
+  return acc;
+}
+
 #define GU 4   // gather steps per batch
 // w: plan blob (LDS), Sv: [nS factor slots | N Dinv] (LDS), xs: [N] permuted rhs in / solution out (LDS)
 __device__ __forceinline__ void plan_tri_solve(const rldl_dev_sym &S, const int *w, const double *Sv, double *xs, int lane) {
@@ -599,36 +669,8 @@ __device__ __forceinline__ void plan_tri_solve(const rldl_dev_sym &S, const int 
       wave_sync();
     }
     if (na > 0) {
-      // in-group sweep over the row-major packed triangle: lane i owns local row i, whose entries L(i, 0..i-1)
-      // start at Tb + i (i-1)/2, so step a reads rowp[a] (a DS immediate offset inside an unrolled batch).
-      // Two batches of reads are always in flight (ping-pong, no register copies).
       double acc = act ? xs[r] : 0.0;
-      const int Tb = __builtin_amdgcn_readfirstlane(w[S.po_gToff + k]);
-      const int nst = g - 1;
-      const int lc = lane < g ? lane : g - 1;
-      const double *rowp = Sv + Tb + ((lc * (lc - 1)) >> 1);
-      double tA[SU], tB[SU];
-      auto loadF = [&](int s0, double (&tb)[SU]) {
-#pragma unroll
-        for (int u = 0; u < SU; u++) tb[u] = rowp[s0 + u];       // lanes <= step read past their row: masked below
-      };
-      auto procF = [&](int s0, const double (&tb)[SU]) {
-#pragma unroll
-        for (int u = 0; u < SU; u++) {
-          const int a = s0 + u;
-          if (a < nst) {                                           // wave-uniform
-            const double xj = readlane_f64(acc, a);                // pivot broadcast (ignores exec)
-            if (lane > a) acc = fma(-tb[u], xj, acc);              // rows below the pivot
-          }
-        }
-      };
-      loadF(0, tA);
-      for (int a = 0; a < nst; a += 2 * SU) {
-        loadF(a + SU, tB);
-        procF(a, tA);
-        loadF(a + 2 * SU, tA);
-        procF(a + SU, tB);
-      }
+      acc = sweep_fwd(Sv + __builtin_amdgcn_readfirstlane(w[S.po_gToff + k]), g, lane, acc);
       if (act) xs[r] = acc;
       wave_sync();
     }
@@ -674,38 +716,8 @@ __device__ __forceinline__ void plan_tri_solve(const rldl_dev_sym &S, const int 
       wave_sync();
     }
     if (nr > 0) {
-      // backward sweep: lane j owns local column j; step s uses row il = g-1-s, whose entries L(il, 0..il-1)
-      // sit at Tb + il (il-1)/2 + lane (consecutive lanes -> conflict-free)
       double acc = act ? (nbs > 0 ? xs[c] : xs[c] * Dinv[c]) : 0.0;
-      const int Tb = __builtin_amdgcn_readfirstlane(w[S.po_gToff + k]);
-      const int nst = g - 1;
-      const double *lanep = Sv + Tb + lane;
-      double tA[SU], tB[SU];
-      auto loadB = [&](int s0, double (&tb)[SU]) {
-#pragma unroll
-        for (int u = 0; u < SU; u++) {
-          int il = g - 1 - (s0 + u);
-          il = il > 0 ? il : 0;
-          tb[u] = lanep[(il * (il - 1)) >> 1];
-        }
-      };
-      auto procB = [&](int s0, const double (&tb)[SU]) {
-#pragma unroll
-        for (int u = 0; u < SU; u++) {
-          const int il = g - 1 - (s0 + u);
-          if (il > 0) {
-            const double xi = readlane_f64(acc, il);
-            if (lane < il) acc = fma(-tb[u], xi, acc);             // columns left of the pivot
-          }
-        }
-      };
-      loadB(0, tA);
-      for (int a = 0; a < nst; a += 2 * SU) {
-        loadB(a + SU, tB);
-        procB(a, tA);
-        loadB(a + 2 * SU, tA);
-        procB(a + SU, tB);
-      }
+      acc = sweep_bwd(Sv + __builtin_amdgcn_readfirstlane(w[S.po_gToff + k]), g, lane, acc);
       if (act) xs[c] = acc;
       wave_sync();
     }
@@ -857,7 +869,7 @@ __global__ __launch_bounds__(1024) void k_plan_admm(rldl_dev_sym S, rldl_dev_num
       const double xp = va[t];
       const double xn = alpha * s + (1.0 - alpha) * xp;       // update_x :188-201
       x[o] = xn;
-      dx[o] = xn - xp;
+      if (W.write_delta) dx[o] = xn - xp;
     } else {
       const int i = o - n;
       const double zp = va[t], yi = vb[t], r = vr[t];
@@ -867,7 +879,7 @@ __global__ __launch_bounds__(1024) void k_plan_admm(rldl_dev_sym S, rldl_dev_num
       zn = fmin(fmax(zn, vl[t]), vu[t]);                       // project, proj.c:4-14
       const double d = vrho[t] * (mix - zn);                   // update_y :217-228
       z[i] = zn;
-      dy[i] = d;
+      if (W.write_delta) dy[i] = d;
       y[i] = yi + d;
     }
   }
@@ -935,69 +947,9 @@ __device__ __forceinline__ void arrow_tri_solve(const rldl_dev_sym &S, const Arr
   if (act) xs[jr] = ga;
   wave_sync();
   double acc = act ? xs[g0 + lane] : 0.0;
-  const int lc = act ? lane : g - 1;
-  if (S.arrow_tb >= 0) {
-    const int Tb = S.arrow_tb;
-    // ---- forward sweep (row-major packed triangle: lane i reads rowp[a]) ----
-    {
-      const double *rowp = Tv + Tb + ((lc * (lc - 1)) >> 1);
-      double tA[SU], tB[SU];
-      auto loadF = [&](int s0, double (&tb)[SU]) {
-#pragma unroll
-        for (int u = 0; u < SU; u++) tb[u] = rowp[s0 + u];
-      };
-      auto procF = [&](int s0, const double (&tb)[SU]) {
-#pragma unroll
-        for (int u = 0; u < SU; u++) {
-          const int a = s0 + u;
-          if (a < nst) {
-            const double xj = readlane_f64(acc, a);
-            if (lane > a) acc = fma(-tb[u], xj, acc);
-          }
-        }
-      };
-      loadF(0, tA);
-      for (int a = 0; a < nst; a += 2 * SU) {
-        loadF(a + SU, tB);
-        procF(a, tA);
-        loadF(a + 2 * SU, tA);
-        procF(a + SU, tB);
-      }
-    }
-    // ---- D^-1, then backward sweep, all in registers ----
-    if (act) acc *= Dinv[g0 + lane];
-    if (!(S.dbg & 8)) {
-      const double *lanep = Tv + Tb + lane;
-      double tA[SU], tB[SU];
-      auto loadB = [&](int s0, double (&tb)[SU]) {
-#pragma unroll
-        for (int u = 0; u < SU; u++) {
-          int il = g - 1 - (s0 + u);
-          il = il > 0 ? il : 0;
-          tb[u] = lanep[(il * (il - 1)) >> 1];
-        }
-      };
-      auto procB = [&](int s0, const double (&tb)[SU]) {
-#pragma unroll
-        for (int u = 0; u < SU; u++) {
-          const int il = g - 1 - (s0 + u);
-          if (il > 0) {
-            const double xi = readlane_f64(acc, il);
-            if (lane < il) acc = fma(-tb[u], xi, acc);
-          }
-        }
-      };
-      loadB(0, tA);
-      for (int a = 0; a < g - 1; a += 2 * SU) {
-        loadB(a + SU, tB);
-        procB(a, tA);
-        loadB(a + 2 * SU, tA);
-        procB(a + SU, tB);
-      }
-    }
-  } else if (act) {
-    acc *= Dinv[g0 + lane];
-  }
+  if (S.arrow_tb >= 0 && nst > 0) acc = sweep_fwd(Tv + S.arrow_tb, g, lane, acc);
+  if (act) acc *= Dinv[g0 + lane];                               // D^-1 without leaving registers
+  if (S.arrow_tb >= 0 && !(S.dbg & 8)) acc = sweep_bwd(Tv + S.arrow_tb, g, lane, acc);
   if (act) xs[g0 + lane] = acc;
   // every index outside the tail group: x = y * Dinv (its forward step was the identity)
   for (int j = lane; j < S.N; j += WAVE)
@@ -1144,7 +1096,7 @@ __global__ __launch_bounds__(256, 3) void k_arrow_admm(rldl_dev_sym S, rldl_dev_
       const double xp = va[t];
       const double xn = alpha * s + (1.0 - alpha) * xp;       // update_x :188-201
       x[o] = xn;
-      dx[o] = xn - xp;
+      if (W.write_delta) dx[o] = xn - xp;
     } else {
       const int i = o - n;
       const double zp = va[t], yi = vb[t], r = vr[t];
@@ -1154,7 +1106,7 @@ __global__ __launch_bounds__(256, 3) void k_arrow_admm(rldl_dev_sym S, rldl_dev_
       zn = fmin(fmax(zn, vl[t]), vu[t]);                       // project, proj.c:4-14
       const double d = vrho[t] * (mix - zn);                   // update_y :217-228
       z[i] = zn;
-      dy[i] = d;
+      if (W.write_delta) dy[i] = d;
       y[i] = yi + d;
     }
   }
