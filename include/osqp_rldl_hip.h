@@ -176,6 +176,16 @@ c_int rldl_batch_init_recursive(rldl_batch **hp, c_int batch, const rldl_stage_d
 c_int rldl_batch_update_from_stage(rldl_batch *h, c_int first_stage, const c_float *d_Px, const c_float *d_Ax,
                                    const c_float *d_rho_vec);
 
+/* Replaces setup_AP_matrices (src/recursive_ldl.c:1873-1970): assemble P (upper triangular) and A from the seven
+ * stage blocks (include/recursive_ldl.h:30-36).  *P_out / *A_out are allocated here (release with rldl_csc_free).
+ * The optional kind/stage/entry arrays (sized by the outputs' nnz; upper bounds: (N-1) nnz(Qi) + nnz(Q0) + nnz(QN) and
+ * N (nnz(Ai) + nnz(Aij)) + nnz(A0) + nnz(AN)) name the source of every stored value
+ * (P kinds: 0=Q0 1=Qi 2=QN; A kinds: 0=A0 1=Ai 2=Aij 3=AN), which is what a batched update_AP_matrices (:1675-1778) needs. */
+c_int rldl_setup_AP_matrices(const rldl_stage_dims *dims, const csc *Q0, const csc *Qi, const csc *QN, const csc *A0,
+                             const csc *Ai, const csc *Aij, const csc *AN, csc **P_out, csc **A_out, c_int *P_kind,
+                             c_int *P_stage, c_int *P_entry, c_int *A_kind, c_int *A_stage, c_int *A_entry);
+void rldl_csc_free(csc *M);
+
 const char *rldl_version(void);
 
 #ifdef __cplusplus

@@ -66,7 +66,7 @@ EXPORTED = [
     "osqp_batch_update_bounds", "osqp_batch_update_rho", "osqp_batch_update_P_A", "osqp_batch_warm_start",
     "osqp_batch_get", "osqp_batch_linsys", "osqp_batch_time_iteration", "osqp_batch_cleanup",
     "rldl_batch_init_recursive", "rldl_batch_update_from_stage", "rldl_version",
-    "rldl_symbolic_analyze", "rldl_stage_permutation", "rldl_plan_export",
+    "rldl_symbolic_analyze", "rldl_stage_permutation", "rldl_plan_export", "rldl_setup_AP_matrices", "rldl_csc_free",
 ]
 
 
@@ -151,6 +151,10 @@ def _declare(L):
     L.rldl_symbolic_analyze.restype = c_int
     L.rldl_plan_export.argtypes = [PC, PC, c_int, IP, IP, C.POINTER(C.c_int), c_int, IP]
     L.rldl_plan_export.restype = c_int
+    L.rldl_setup_AP_matrices.argtypes = [C.POINTER(StageDims)] + [PC] * 7 + [C.POINTER(PC), C.POINTER(PC)] + [IP] * 6
+    L.rldl_setup_AP_matrices.restype = c_int
+    L.rldl_csc_free.argtypes = [PC]
+    L.rldl_csc_free.restype = None
     L.rldl_device_available.restype = C.c_int
 
 

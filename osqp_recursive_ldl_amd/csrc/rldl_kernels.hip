@@ -627,7 +627,7 @@ __device__ __forceinline__ double sweep_bwd(const double *Tp, int g, int lane, d
 __device__ __forceinline__ void plan_tri_solve(const rldl_dev_sym &S, const int *w, const double *Sv, double *xs, int lane) {
   const int ng = S.ngroups;
   const double *Dinv = Sv + S.nS;
-  const int zs = S.ldF + ((S.N + 1) & ~1);                       // per-wave slot holding 0.0 (set by the caller)
+  const int zs = S.ldF - 1;                                      // spare slot of the factor row, always 0.0
   const unsigned short *fsig = reinterpret_cast<const unsigned short *>(w + S.po_fsig);
   const unsigned short *bsig = reinterpret_cast<const unsigned short *>(w + S.po_bsig);
   const unsigned short *fcol = reinterpret_cast<const unsigned short *>(w + S.po_fcol);
@@ -750,19 +750,23 @@ __device__ __forceinline__ void stage_factor_dma(const rldl_dev_sym &S, const do
 }
 __device__ __forceinline__ void wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+// STAGE: the factor row is copied to LDS (small patterns); otherwise the sweeps and gathers read it straight from
+// global memory / L2 (their addresses do not depend on x, so the batched reads still pipeline) and only the
+// plan and x live in LDS -- the variant for patterns whose row would leave one wave per CU.
+template <bool STAGE>
 __global__ __launch_bounds__(1024) void k_plan_solve(rldl_dev_sym S, rldl_dev_num Nn, double *__restrict__ b_all, int per_wave) {
   extern __shared__ __attribute__((aligned(16))) double sh[];
   const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6, wpb = blockDim.x >> 6;
   const int inst = blockIdx.x * wpb + wv;
   int *wl = reinterpret_cast<int *>(sh + (size_t)wpb * per_wave);
-  double *Sv = sh + (size_t)wv * per_wave;                     // [ldF] factor + Dinv (16-byte aligned)
-  double *xs = Sv + S.ldF;                                     // [N]
-  if (lane == 0) Sv[S.ldF + ((S.N + 1) & ~1)] = 0.0;
+  double *Sl = sh + (size_t)wv * per_wave;                     // STAGE: [ldF] factor + Dinv (16-byte aligned), then xs
+  double *xs = STAGE ? Sl + S.ldF : Sl;                        // [N]
   const bool live = inst < Nn.batch;
+  const double *Sv = STAGE ? Sl : Nn.F + (size_t)(live ? inst : 0) * S.ldF;
   double *b = b_all + (size_t)(live ? inst : 0) * S.N;
   stage_plan(S, wl);
   if (live) {
-    stage_factor_dma(S, Nn.F + (size_t)inst * S.ldF, Sv, lane);
+    if (STAGE) stage_factor_dma(S, Nn.F + (size_t)inst * S.ldF, Sl, lane);
     const int *permg = S.plan + S.po_perm;                     // global copy: lets the rhs gather start before the barrier
     for (int j0 = 0; j0 < S.N; j0 += 4 * WAVE) {               // permute_x  qdldl_interface.c:538-541
       double v[4];
@@ -806,15 +810,14 @@ __global__ __launch_bounds__(1024) void k_plan_solve(rldl_dev_sym S, rldl_dev_nu
 // One fused ADMM iteration (auxil.c:164-228).  All global loads a wave needs (factor row via LDS-DMA,
 // x/q or z/y/rho_inv/l/u/rho per owned position) are issued before the first wait, so a wave pays about
 // two memory latencies per iteration instead of one per loop trip.
-template <int TMAX>   // positions per lane held in registers: covers N <= 64*TMAX
+template <int TMAX, bool STAGE>   // positions per lane held in registers: covers N <= 64*TMAX
 __global__ __launch_bounds__(1024) void k_plan_admm(rldl_dev_sym S, rldl_dev_num Nn, rldl_dev_admm W, int per_wave) {
   extern __shared__ __attribute__((aligned(16))) double sh[];
   const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6, wpb = blockDim.x >> 6;
   const int inst = blockIdx.x * wpb + wv;
   int *wl = reinterpret_cast<int *>(sh + (size_t)wpb * per_wave);
-  double *Sv = sh + (size_t)wv * per_wave;
-  double *xs = Sv + S.ldF;
-  if (lane == 0) Sv[S.ldF + ((S.N + 1) & ~1)] = 0.0;
+  double *Sl = sh + (size_t)wv * per_wave;
+  double *xs = STAGE ? Sl + S.ldF : Sl;
   const int st = inst < Nn.batch ? W.status[inst] : 0;          // latency overlaps with the plan / perm loads below
   stage_plan(S, wl);
   const int *permg = S.plan + S.po_perm;
@@ -829,8 +832,9 @@ __global__ __launch_bounds__(1024) void k_plan_admm(rldl_dev_sym S, rldl_dev_num
   const double *q = W.q + io * n, *l = W.l + io * m, *u = W.u + io * m, *rv = W.rho_vec + io * m;
   // per owned permuted position: o = perm[j]; variables carry (x_prev, q), constraints (z_prev, y, rho_inv, l, u, rho)
   double va[TMAX], vb[TMAX], vr[TMAX], vl[TMAX], vu[TMAX], vrho[TMAX];
+  const double *Sv = STAGE ? Sl : Nn.F + io * S.ldF;
   if (live) {
-    if (!(S.dbg & 16)) stage_factor_dma(S, Nn.F + io * S.ldF, Sv, lane);
+    if (STAGE && !(S.dbg & 16)) stage_factor_dma(S, Nn.F + io * S.ldF, Sl, lane);
 #pragma unroll
     for (int t = 0; t < TMAX; t++) {
       // branch-free: every lane loads from a valid address chosen by pointer select, so all loads of all
@@ -885,6 +889,95 @@ __global__ __launch_bounds__(1024) void k_plan_admm(rldl_dev_sym S, rldl_dev_num
   }
 }
 
+
+// Large-N variant of the fused iteration: the per-position vectors do not fit in registers, so the right-hand side is
+// built and the x/z/y update applied in batches of four positions per lane (two extra memory latencies per batch).
+template <bool STAGE>
+__global__ __launch_bounds__(1024) void k_plan_admm_loop(rldl_dev_sym S, rldl_dev_num Nn, rldl_dev_admm W, int per_wave) {
+  extern __shared__ __attribute__((aligned(16))) double sh[];
+  const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+  const int inst = blockIdx.x * wpb + wv;
+  int *wl = reinterpret_cast<int *>(sh + (size_t)wpb * per_wave);
+  double *Sl = sh + (size_t)wv * per_wave;
+  double *xs = STAGE ? Sl + S.ldF : Sl;
+  const int st = inst < Nn.batch ? W.status[inst] : 0;
+  stage_plan(S, wl);
+  const bool live = inst < Nn.batch && st == ST_UNSOLVED;
+  const int n = S.n, m = S.m;
+  const size_t io = (size_t)(live ? inst : 0);
+  const double *ri = Nn.rho_inv + io * m;
+  double *x = W.x + io * n, *z = W.z + io * m, *y = W.y + io * m;
+  const double *q = W.q + io * n, *l = W.l + io * m, *u = W.u + io * m, *rv = W.rho_vec + io * m;
+  const double *Sv = STAGE ? Sl : Nn.F + io * S.ldF;
+  const int *permg = S.plan + S.po_perm;
+  if (live) {
+    if (STAGE) stage_factor_dma(S, Nn.F + io * S.ldF, Sl, lane);
+    for (int j0 = 0; j0 < S.N; j0 += 4 * WAVE) {               // compute_rhs (auxil.c:164-178) in permuted order
+      int oo[4];
+      double va[4], vb[4], vr[4];
+#pragma unroll
+      for (int t = 0; t < 4; t++) { const int j = j0 + t * WAVE + lane; oo[t] = j < S.N ? permg[j] : -1; }
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        const int o = oo[t];
+        const bool con = o >= n;
+        const int iv = con || o < 0 ? 0 : o, ic = con ? o - n : 0;
+        const double *pa = con ? z + ic : x + iv;
+        const double *pb = con ? y + ic : q + iv;
+        va[t] = *pa; vb[t] = *pb; vr[t] = ri[ic];
+      }
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        const int j = j0 + t * WAVE + lane;
+        if (oo[t] >= 0) xs[j] = oo[t] < n ? W.sigma * va[t] - vb[t] : va[t] - vr[t] * vb[t];
+      }
+    }
+  }
+  wait_dma();
+  __syncthreads();
+  if (!live) return;
+  plan_tri_solve(S, wl, Sv, xs, lane);
+  const double alpha = W.alpha;
+  double *dx = W.delta_x + io * n, *dy = W.delta_y + io * m;
+  const int *perm = wl + S.po_perm;
+  for (int j0 = 0; j0 < S.N; j0 += 4 * WAVE) {
+    int oo[4];
+    double va[4], vb[4], vr[4], vl[4], vu[4], vrho[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      const int j = j0 + t * WAVE + lane;
+      const int o = j < S.N ? perm[j] : -1;
+      oo[t] = o;
+      const bool con = o >= n;
+      const int iv = con || o < 0 ? 0 : o, ic = con ? o - n : 0;
+      const double *pa = con ? z + ic : x + iv;
+      va[t] = *pa; vb[t] = y[ic]; vr[t] = ri[ic]; vl[t] = l[ic]; vu[t] = u[ic]; vrho[t] = rv[ic];
+    }
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      const int o = oo[t];
+      if (o < 0) continue;
+      const double s = xs[j0 + t * WAVE + lane];
+      if (o < n) {
+        const double xp = va[t];
+        const double xn = alpha * s + (1.0 - alpha) * xp;     // update_x :188-201
+        x[o] = xn;
+        if (W.write_delta) dx[o] = xn - xp;
+      } else {
+        const int i = o - n;
+        const double zp = va[t], yi = vb[t], r = vr[t];
+        const double zt = (zp - r * yi) + r * s;               // z_tilde, qdldl_interface.c:577-579
+        const double mix = alpha * zt + (1.0 - alpha) * zp;
+        double zn = mix + r * yi;                              // update_z :203-215
+        zn = fmin(fmax(zn, vl[t]), vu[t]);                     // project, proj.c:4-14
+        const double d = vrho[t] * (mix - zn);                 // update_y :217-228
+        z[i] = zn;
+        if (W.write_delta) dy[i] = d;
+        y[i] = yi + d;
+      }
+    }
+  }
+}
 
 // ================================================================================================
 // Arrowhead specialisation (plan->arrow_ok): all out-of-group entries feed ONE dense group (the Schur
@@ -1121,20 +1214,17 @@ static inline int launch_status() { return hipGetLastError() == hipSuccess ? 0 :
 
 // ---- plan kernels: geometry ----
 #define LDS_PER_CU (160 * 1024)
-static int plan_per_wave_doubles(const rldl_dev_sym *S) { return S->ldF + ((S->N + 1) & ~1) + 2; }  // factor+Dinv | xs | zero slot
-static size_t plan_lds_bytes(const rldl_dev_sym *S, int wpb) {
-  return sizeof(double) * (size_t)wpb * (size_t)plan_per_wave_doubles(S) + sizeof(int) * (size_t)((S->plan_words + 3) & ~3);
+static int plan_per_wave_doubles(const rldl_dev_sym *S, bool stage) { return (stage ? S->ldF : 0) + ((S->N + 1) & ~1); }
+static size_t plan_lds_bytes(const rldl_dev_sym *S, int wpb, bool stage) {
+  return sizeof(double) * (size_t)wpb * (size_t)plan_per_wave_doubles(S, stage) + sizeof(int) * (size_t)((S->plan_words + 3) & ~3);
 }
 // waves per workgroup (1..16) that maximise resident waves per CU; asks the runtime what actually fits
 // (the usable LDS per CU is below the nominal 160 KiB).  RLDL_WPB forces a value for experiments.
-static int plan_pick_wpb_for(const rldl_dev_sym *S, const void *kernel) {
-  static int cache_words = -1, cache_ldf = -1, cache_best = 0;
-  static const void *cache_kernel = 0;
-  if (cache_kernel == kernel && cache_words == S->plan_words && cache_ldf == S->ldF) return cache_best;
+static int plan_pick_wpb_for(const rldl_dev_sym *S, const void *kernel, bool stage, int *waves_out) {
   int best = 0, best_waves = 0;
   const char *force = getenv("RLDL_WPB");
   for (int wpb = 1; wpb <= 16; wpb *= 2) {
-    const size_t b = plan_lds_bytes(S, wpb);
+    const size_t b = plan_lds_bytes(S, wpb, stage);
     if (b > (size_t)LDS_PER_CU) continue;
     if (force && atoi(force) != wpb) continue;
     if (b > 64 * 1024 && hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b) != hipSuccess) continue;
@@ -1144,43 +1234,71 @@ static int plan_pick_wpb_for(const rldl_dev_sym *S, const void *kernel) {
     if (waves > best_waves) { best = wpb; best_waves = waves; }
   }
   (void)hipGetLastError();
-  cache_kernel = kernel; cache_words = S->plan_words; cache_ldf = S->ldF; cache_best = best;
-  if (getenv("RLDL_VERBOSE")) fprintf(stderr, "[rldl] plan kernel: wpb=%d, %d waves/CU, %zu B LDS per workgroup\n", best, best_waves, plan_lds_bytes(S, best ? best : 1));
+  if (waves_out) *waves_out = best_waves;
   return best;
 }
-static int plan_pick_wpb(const rldl_dev_sym *S) {   // feasibility only (any kernel): LDS budget
+// staged (factor row in LDS) when that still leaves >= 4 waves per CU, streamed from global memory otherwise
+struct PlanGeom { int wpb; bool stage; size_t lds; };
+static PlanGeom plan_geometry(const rldl_dev_sym *S, const void *k_staged, const void *k_stream) {
+  static const void *ck = 0; static int cw = -1, cl = -1; static PlanGeom cg = {0, false, 0};
+  if (ck == k_staged && cw == S->plan_words && cl == S->ldF) return cg;
+  int ws = 0, wg = 0;
+  const int wpb_s = plan_pick_wpb_for(S, k_staged, true, &ws), wpb_g = plan_pick_wpb_for(S, k_stream, false, &wg);
+  PlanGeom g;
+  if (wpb_s > 0 && (ws >= 4 || wpb_g <= 0) && !getenv("RLDL_NO_STAGE")) { g.wpb = wpb_s; g.stage = true; }
+  else { g.wpb = wpb_g; g.stage = false; }
+  g.lds = g.wpb > 0 ? plan_lds_bytes(S, g.wpb, g.stage) : 0;
+  if (getenv("RLDL_VERBOSE"))
+    fprintf(stderr, "[rldl] plan kernel: %s, wpb=%d, %d waves/CU, %zu B LDS per workgroup\n", g.stage ? "factor staged in LDS" : "factor read from global",
+            g.wpb, g.stage ? ws : wg, g.lds);
+  ck = k_staged; cw = S->plan_words; cl = S->ldF; cg = g;
+  return g;
+}
+static int plan_pick_wpb(const rldl_dev_sym *S) {   // feasibility only: the global-memory variant needs plan + x in LDS
   for (int wpb = 1; wpb <= 16; wpb *= 2)
-    if (plan_lds_bytes(S, wpb) <= (size_t)LDS_PER_CU) return wpb;
+    if (plan_lds_bytes(S, wpb, false) <= (size_t)LDS_PER_CU) return wpb;
   return 0;
 }
 static bool plan_usable(const rldl_dev_sym *S) { return S->plan_ok && S->ngroups > 0 && plan_pick_wpb(S) > 0; }
-static bool plan_admm_usable(const rldl_dev_sym *S) { return plan_usable(S) && S->N <= 8 * WAVE; }
+static bool plan_admm_usable(const rldl_dev_sym *S) { return plan_usable(S); }
 
 static int launch_plan_solve(const rldl_dev_sym *S, const rldl_dev_num *Nn, double *d_b, void *stream) {
-  const int wpb = plan_pick_wpb_for(S, (const void *)k_plan_solve);
-  if (wpb <= 0) return -1;
-  const size_t lds = plan_lds_bytes(S, wpb);
-  if (lds > 64 * 1024 && hipFuncSetAttribute((const void *)k_plan_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
-  const int grid = (Nn->batch + wpb - 1) / wpb;
-  hipLaunchKernelGGL(k_plan_solve, dim3(grid), dim3(wpb * WAVE), lds, (hipStream_t)stream, *S, *Nn, d_b, plan_per_wave_doubles(S));
+  const PlanGeom g = plan_geometry(S, (const void *)k_plan_solve<true>, (const void *)k_plan_solve<false>);
+  if (g.wpb <= 0) return -1;
+  const void *k = g.stage ? (const void *)k_plan_solve<true> : (const void *)k_plan_solve<false>;
+  if (g.lds > 64 * 1024 && hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds) != hipSuccess) return -1;
+  const int grid = (Nn->batch + g.wpb - 1) / g.wpb, pw = plan_per_wave_doubles(S, g.stage);
+  if (g.stage) hipLaunchKernelGGL(k_plan_solve<true>, dim3(grid), dim3(g.wpb * WAVE), g.lds, (hipStream_t)stream, *S, *Nn, d_b, pw);
+  else hipLaunchKernelGGL(k_plan_solve<false>, dim3(grid), dim3(g.wpb * WAVE), g.lds, (hipStream_t)stream, *S, *Nn, d_b, pw);
   return launch_status();
 }
 template <int TMAX>
 static int launch_plan_admm_t(const rldl_dev_sym *S, const rldl_dev_num *Nn, const rldl_dev_admm *W, void *stream) {
-  const int wpb = plan_pick_wpb_for(S, (const void *)k_plan_admm<TMAX>);
-  if (wpb <= 0) return -1;
-  const size_t lds = plan_lds_bytes(S, wpb);
-  if (lds > 64 * 1024 && hipFuncSetAttribute((const void *)k_plan_admm<TMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
-  const int grid = (Nn->batch + wpb - 1) / wpb;
-  hipLaunchKernelGGL(k_plan_admm<TMAX>, dim3(grid), dim3(wpb * WAVE), lds, (hipStream_t)stream, *S, *Nn, *W, plan_per_wave_doubles(S));
+  const PlanGeom g = plan_geometry(S, (const void *)k_plan_admm<TMAX, true>, (const void *)k_plan_admm<TMAX, false>);
+  if (g.wpb <= 0) return -1;
+  const void *k = g.stage ? (const void *)k_plan_admm<TMAX, true> : (const void *)k_plan_admm<TMAX, false>;
+  if (g.lds > 64 * 1024 && hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds) != hipSuccess) return -1;
+  const int grid = (Nn->batch + g.wpb - 1) / g.wpb, pw = plan_per_wave_doubles(S, g.stage);
+  if (g.stage) hipLaunchKernelGGL((k_plan_admm<TMAX, true>), dim3(grid), dim3(g.wpb * WAVE), g.lds, (hipStream_t)stream, *S, *Nn, *W, pw);
+  else hipLaunchKernelGGL((k_plan_admm<TMAX, false>), dim3(grid), dim3(g.wpb * WAVE), g.lds, (hipStream_t)stream, *S, *Nn, *W, pw);
+  return launch_status();
+}
+static int launch_plan_admm_loop(const rldl_dev_sym *S, const rldl_dev_num *Nn, const rldl_dev_admm *W, void *stream) {
+  const PlanGeom g = plan_geometry(S, (const void *)k_plan_admm_loop<true>, (const void *)k_plan_admm_loop<false>);
+  if (g.wpb <= 0) return -1;
+  const void *k = g.stage ? (const void *)k_plan_admm_loop<true> : (const void *)k_plan_admm_loop<false>;
+  if (g.lds > 64 * 1024 && hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds) != hipSuccess) return -1;
+  const int grid = (Nn->batch + g.wpb - 1) / g.wpb, pw = plan_per_wave_doubles(S, g.stage);
+  if (g.stage) hipLaunchKernelGGL(k_plan_admm_loop<true>, dim3(grid), dim3(g.wpb * WAVE), g.lds, (hipStream_t)stream, *S, *Nn, *W, pw);
+  else hipLaunchKernelGGL(k_plan_admm_loop<false>, dim3(grid), dim3(g.wpb * WAVE), g.lds, (hipStream_t)stream, *S, *Nn, *W, pw);
   return launch_status();
 }
 static int launch_plan_admm(const rldl_dev_sym *S, const rldl_dev_num *Nn, const rldl_dev_admm *W, void *stream) {
   if (S->N <= 2 * WAVE) return launch_plan_admm_t<2>(S, Nn, W, stream);
   if (S->N <= 4 * WAVE) return launch_plan_admm_t<4>(S, Nn, W, stream);
-  return launch_plan_admm_t<8>(S, Nn, W, stream);
+  if (S->N <= 8 * WAVE) return launch_plan_admm_t<8>(S, Nn, W, stream);
+  return launch_plan_admm_loop(S, Nn, W, stream);
 }
-
 
 // ---- arrowhead kernels: geometry ----
 static int arrow_per_wave_doubles(const rldl_dev_sym *S) {

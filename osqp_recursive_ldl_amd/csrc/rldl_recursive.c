@@ -55,3 +55,81 @@ c_int rldl_batch_update_from_stage(rldl_batch *h, c_int first_stage, const c_flo
   if (rldl_launch_factor_from(&h->dsym, &h->num, (int)col0, h->stream)) return 1;
   return rldl_batch_check_status(h);
 }
+
+/* =====================================================================================
+ * Assembling the big P (upper triangular) and A from the seven stage blocks: the layout of
+ * setup_AP_matrices (src/recursive_ldl.c:1873-1970).  Variables [u0 | x1,u1 | ... | x_{N-1},u_{N-1} | x_N],
+ * row block k = [ny inequality rows ; nx dynamics rows], terminal block of nt rows.  Column block k >= 1
+ * holds Aij (coupling into the dynamics rows of row block k-1) stacked over Ai (row block k); the last
+ * column block (x_N, nx columns) holds the first nx columns of Aij over AN.
+ * Besides the matrices the function reports, per stored value, which stage block it came from, so a caller
+ * can rebuild the value arrays of a whole batch from per-stage data (update_AP_matrices, :1675-1778).
+ * ===================================================================================== */
+static csc *csc_new(c_int m, c_int n, c_int nz) {
+  csc *M = (csc *)calloc(1, sizeof(csc));
+  if (!M) return 0;
+  M->m = m; M->n = n; M->nzmax = nz > 0 ? nz : 1; M->nz = -1;
+  M->p = (c_int *)calloc((size_t)n + 1, sizeof(c_int));
+  M->i = (c_int *)malloc(sizeof(c_int) * (size_t)M->nzmax);
+  M->x = (c_float *)malloc(sizeof(c_float) * (size_t)M->nzmax);
+  if (!M->p || !M->i || !M->x) { free(M->p); free(M->i); free(M->x); free(M); return 0; }
+  return M;
+}
+
+void rldl_csc_free(csc *M) {
+  if (!M) return;
+  free(M->p); free(M->i); free(M->x); free(M);
+}
+
+static void put_col(csc *dst, c_int *nz, const csc *blk, c_int col, c_int row_off, c_int kind, c_int stage, c_int *src_kind,
+                    c_int *src_stage, c_int *src_entry) {
+  c_int j;
+  for (j = blk->p[col]; j < blk->p[col + 1]; j++) {
+    dst->i[*nz] = row_off + blk->i[j];
+    dst->x[*nz] = blk->x[j];
+    if (src_kind) { src_kind[*nz] = kind; src_stage[*nz] = stage; src_entry[*nz] = j; }
+    (*nz)++;
+  }
+}
+
+c_int rldl_setup_AP_matrices(const rldl_stage_dims *d, const csc *Q0, const csc *Qi, const csc *QN, const csc *A0, const csc *Ai,
+                             const csc *Aij, const csc *AN, csc **P_out, csc **A_out, c_int *P_kind, c_int *P_stage,
+                             c_int *P_entry, c_int *A_kind, c_int *A_stage, c_int *A_entry) {
+  c_int N, nvar, ncon, nzP = 0, nzA = 0, col = 0, prow = 0, arow = 0, k, i, capP, capA;
+  csc *P, *A;
+  if (!d || !Q0 || !Qi || !QN || !A0 || !Ai || !Aij || !AN || !P_out || !A_out) return 1;
+  N = d->N;
+  if (N < 1 || Q0->n != d->nu || Qi->n != d->nx + d->nu || QN->n != d->nx || A0->m != d->nx + d->ny || A0->n != d->nu ||
+      Ai->m != d->nx + d->ny || Ai->n != d->nx + d->nu || Aij->m != d->nx + d->ny || Aij->n != d->nx + d->nu ||
+      AN->m != d->nt || AN->n != d->nx)
+    return 1;
+  nvar = N * (d->nx + d->nu); ncon = N * (d->nx + d->ny) + d->nt;
+  capP = (N - 1) * Qi->p[Qi->n] + Q0->p[Q0->n] + QN->p[QN->n];
+  capA = N * (Ai->p[Ai->n] + Aij->p[Aij->n]) + A0->p[A0->n] + AN->p[AN->n];
+  P = csc_new(nvar, nvar, capP); A = csc_new(ncon, nvar, capA);
+  if (!P || !A) { rldl_csc_free(P); rldl_csc_free(A); return RLDL_MEM_ALLOC_ERROR; }
+  /* kinds: P 0=Q0 1=Qi 2=QN ; A 0=A0 1=Ai 2=Aij 3=AN */
+  for (i = 0; i < Q0->n; i++, col++) {
+    P->p[col] = nzP; put_col(P, &nzP, Q0, i, 0, 0, 0, P_kind, P_stage, P_entry);
+    A->p[col] = nzA; put_col(A, &nzA, A0, i, 0, 0, 0, A_kind, A_stage, A_entry);
+  }
+  prow = Q0->m;
+  for (k = 1; k < N; k++) {
+    for (i = 0; i < Qi->n; i++, col++) {
+      P->p[col] = nzP; put_col(P, &nzP, Qi, i, prow, 1, k, P_kind, P_stage, P_entry);
+      A->p[col] = nzA;
+      put_col(A, &nzA, Aij, i, arow, 2, k, A_kind, A_stage, A_entry);
+      put_col(A, &nzA, Ai, i, arow + Aij->m, 1, k, A_kind, A_stage, A_entry);
+    }
+    prow += Qi->m; arow += Aij->m;
+  }
+  for (i = 0; i < QN->n; i++, col++) {
+    P->p[col] = nzP; put_col(P, &nzP, QN, i, prow, 2, N, P_kind, P_stage, P_entry);
+    A->p[col] = nzA;
+    put_col(A, &nzA, Aij, i, arow, 2, N, A_kind, A_stage, A_entry);
+    put_col(A, &nzA, AN, i, arow + Aij->m, 3, N, A_kind, A_stage, A_entry);
+  }
+  P->p[col] = nzP; A->p[col] = nzA;
+  *P_out = P; *A_out = A;
+  return 0;
+}

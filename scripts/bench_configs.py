@@ -1,0 +1,111 @@
+#!/usr/bin/env python3
+"""Secondary measurements for the BASELINE.json configs that are not the headline bench line
+(run on the GPU box; prints one JSON object per measurement):
+
+  solve_kernel   standalone batched `solve` (the plugin call) at batch 4096, metric shape, vs its roofline
+  config2        batch 1024 metric shape: numeric factor + 200 ADMM iterations
+  config3        MPC stage blocks N=20 nx=12 nu=4 ny=10 nt=12, batch 4096: full stage factorisation,
+                 refactor on a rho change, restart from stage k, tri-solve
+  config5        update_matrices on the metric shape (full numeric refactor) and, on the MPC shape,
+                 restart-from-first-modified-stage vs full refactor
+"""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+import osqp_recursive_ldl_amd as R
+
+PEAK = 8000.0
+dev = torch.device("cuda:0")
+t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def timed(fn, reps=5, warm=1):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def emit(**kw):
+    print(json.dumps(kw), flush=True)
+
+
+def metric_shape():
+    wl = R.workloads.SharedPatternQPs()
+    B = 4096
+    Px, Ax, q, l, u = wl.values(B)
+    dPx, dAx = t(Px), t(Ax)
+    rho = t(np.full((B, wl.m), 0.1))
+    ls = R.BatchLinsys(wl.P_pattern, wl.A_pattern, dPx, dAx, 1e-6, rho)
+    d = ls.dims()
+    N = d["n"] + d["m"]
+    b = torch.randn((B, N), dtype=torch.float64, device=dev)
+    ms = ls.time_solve(b, reps=200)
+    by = 8 * (d["nnzL"] + 3 * N + d["m"])
+    emit(name="solve_kernel", batch=B, n=d["n"], m=d["m"], nnzL=d["nnzL"], us_per_launch=1e3 * ms, bytes_per_instance=by,
+         achieved_GBs=by * B / (ms * 1e-3) / 1e9, frac=by * B / (ms * 1e-3) / 1e9 / PEAK)
+    ms = timed(lambda: ls.update_matrices(dPx, dAx))
+    fb = 8 * (d["nnzKKT"] + d["nnzL"]) + 16 * N
+    emit(name="config5_update_matrices_full_refactor", batch=B, ms=ms, bytes_per_instance=fb,
+         achieved_GBs=fb * B / (ms * 1e-3) / 1e9, refactors_per_sec=B / (ms * 1e-3))
+    ms = timed(lambda: ls.update_rho_vec(rho))
+    emit(name="update_rho_vec_full_refactor", batch=B, ms=ms, refactors_per_sec=B / (ms * 1e-3))
+    ls.free()
+    # config 2: batch 1024
+    B2 = 1024
+    kw = dict(rho=0.1, sigma=1e-6, alpha=1.6, max_iter=200, check_termination=0, adaptive_rho=0, warm_start=0, scaling=0)
+    w = R.OSQPBatch(wl.P_pattern, wl.A_pattern, dPx[:B2].contiguous(), dAx[:B2].contiguous(), t(q[:B2]), t(l[:B2]), t(u[:B2]), **kw)
+
+    def step():
+        w.update_P_A(dPx[:B2].contiguous(), dAx[:B2].contiguous())
+        w.solve()
+    ms = timed(step, reps=5)
+    emit(name="config2_batch1024_factor_plus_200_iters", batch=B2, ms_per_step=ms, qp_solves_per_sec=B2 / (ms * 1e-3),
+         iter_kernel_us=1e3 * w.time_iteration(0))
+    w.cleanup()
+
+
+def mpc_shape():
+    wl = R.workloads.MPCStageQPs(N=20)
+    B = 4096
+    Px, Ax, q, l, u = wl.values(B)
+    dPx, dAx = t(Px), t(Ax)
+    rho = t(np.full((B, wl.m), 0.1))
+    ls = R.BatchLinsys.recursive(wl.dims, wl.P_pattern, wl.A_pattern, dPx, dAx, 1e-6, rho)
+    assert ls.status == 0
+    d = ls.dims()
+    N = d["n"] + d["m"]
+    emit(name="config3_dims", batch=B, n=d["n"], m=d["m"], nnzKKT=d["nnzKKT"], nnzL=d["nnzL"])
+    full = timed(lambda: ls.update_from_stage(0, dPx, dAx, None), reps=3)
+    emit(name="config3_full_stage_factorisation", batch=B, ms=full, factorisations_per_sec=B / (full * 1e-3))
+    rho2 = t(np.full((B, wl.m), 0.4))
+    ms = timed(lambda: ls.update_from_stage(0, None, None, rho2), reps=3)
+    emit(name="config3_refactor_on_rho_change", batch=B, ms=ms, refactors_per_sec=B / (ms * 1e-3))
+    for k in (5, 10, 15, 19):
+        ms = timed(lambda: ls.update_from_stage(k, dPx, dAx, None), reps=3)
+        emit(name="config5_restart_from_stage", stage=k, batch=B, ms=ms, speedup_vs_full=full / ms)
+    b = torch.randn((B, N), dtype=torch.float64, device=dev)
+    ms = ls.time_solve(b, reps=50)
+    by = 8 * (d["nnzL"] + 3 * N + d["m"])
+    emit(name="config3_solve_kernel", batch=B, us_per_launch=1e3 * ms, bytes_per_instance=by,
+         achieved_GBs=by * B / (ms * 1e-3) / 1e9, frac=by * B / (ms * 1e-3) / 1e9 / PEAK)
+    ls.free()
+
+
+if __name__ == "__main__":
+    which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if which in ("all", "metric"):
+        metric_shape()
+    if which in ("all", "mpc"):
+        mpc_shape()
