@@ -1038,6 +1038,7 @@ __device__ __forceinline__ void arrow_tri_solve(const rldl_dev_sym &S, const Arr
       }
   }
   if (act) xs[jr] = ga;
+  wait_dma();                                                    // triangle + Dinv (second DMA phase) streamed in behind the gather
   wave_sync();
   double acc = act ? xs[g0 + lane] : 0.0;
   if (S.arrow_tb >= 0 && nst > 0) acc = sweep_fwd(Tv + S.arrow_tb, g, lane, acc);
@@ -1102,8 +1103,7 @@ __global__ __launch_bounds__(256, 3) void k_arrow_solve(rldl_dev_sym S, rldl_dev
 #pragma unroll
     for (int t = 0; t < 4; t++) { const int j = j0 + t * WAVE + lane; if (j < S.N) xs[j] = v[t]; }
   }
-  wait_dma();
-  wave_sync();
+  wave_sync();                                                  // (the triangle DMA is awaited inside, behind the gather)
   arrow_tri_solve<TG>(S, R, Tv, xs, g0, g, jr, lane);
   if (S.polish) {
     for (int j = lane; j < S.N; j += WAVE) b[permg[j]] = xs[j];
@@ -1175,9 +1175,9 @@ __global__ __launch_bounds__(256, 3) void k_arrow_admm(rldl_dev_sym S, rldl_dev_
     const int j = t * WAVE + lane;
     if (oo[t] >= 0) xs[j] = oo[t] < n ? W.sigma * va[t] - vb[t] : va[t] - vr[t] * vb[t];
   }
-  wait_dma();
-  wave_sync();
+  wave_sync();                                                  // (the triangle DMA is awaited inside, behind the gather)
   if (!(S.dbg & 32)) arrow_tri_solve<TG>(S, R, Tv, xs, g0, g, jr, lane);
+  else wait_dma();
   const double alpha = W.alpha;
   double *dx = W.delta_x + io * n, *dy = W.delta_y + io * m;
 #pragma unroll
