@@ -150,9 +150,15 @@ c_int osqp_batch_update_bounds(osqp_batch *w, const c_float *d_l, const c_float 
 c_int osqp_batch_update_rho(osqp_batch *w, c_float rho_new);           /* osqp.c:1268-1319 */
 c_int osqp_batch_update_P_A(osqp_batch *w, const c_float *d_Px, const c_float *d_Ax); /* osqp.c:1158-1266 */
 c_int osqp_batch_warm_start(osqp_batch *w, const c_float *d_x, const c_float *d_y);   /* osqp.c:929-948 */
-/* results: device pointers owned by the workspace (valid until cleanup) */
+/* results: device pointers owned by the workspace (valid until cleanup).  x, y are the OSQPSolution of
+ * store_solution (auxil.c:527-565: unscaled, NaN when the instance is infeasible / non-convex); z is work->z. */
 c_int osqp_batch_get(osqp_batch *w, c_float **d_x, c_float **d_y, c_float **d_z, int **d_status,
                      int **d_iter, c_float **d_obj, c_float **d_pri_res, c_float **d_dua_res);
+/* work->x, y, z (scaled iterates) and work->delta_x, delta_y (the infeasibility certificates after a solve) */
+c_int osqp_batch_get_iterates(osqp_batch *w, c_float **d_x, c_float **d_y, c_float **d_z, c_float **d_delta_x,
+                              c_float **d_delta_y);
+/* OSQPScaling (include/types.h:43-48): D[batch][n], E[batch][m], c[batch]; returns 1 when scaling is off */
+c_int osqp_batch_get_scaling(osqp_batch *w, c_float **d_D, c_float **d_E, c_float **d_c);
 rldl_batch *osqp_batch_linsys(osqp_batch *w);
 /* timing of the fused ADMM-iteration kernel (HIP events on the workspace stream), for the roofline */
 c_int osqp_batch_time_iteration(osqp_batch *w, c_int reps, c_float *ms_per_launch);

@@ -565,6 +565,11 @@ orc_float *orc_ws_sol_x(orc_workspace *w) { return w->sol_x; }
 orc_float *orc_ws_sol_y(orc_workspace *w) { return w->sol_y; }
 orc_info  *orc_ws_info(orc_workspace *w) { return &w->info; }
 orc_linsys *orc_ws_linsys(orc_workspace *w) { return w->linsys; }
+orc_float *orc_ws_delta_x(orc_workspace *w) { return w->delta_x; }
+orc_float *orc_ws_delta_y(orc_workspace *w) { return w->delta_y; }
+orc_float *orc_ws_D(orc_workspace *w) { return w->D; }
+orc_float *orc_ws_E(orc_workspace *w) { return w->E; }
+orc_float  orc_ws_c(orc_workspace *w) { return w->c; }
 
 /* ------------------------------------------------------------ CPU baseline ---- */
 static double now_s(void) {

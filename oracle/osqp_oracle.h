@@ -159,6 +159,11 @@ orc_float *orc_ws_sol_x(orc_workspace *w);
 orc_float *orc_ws_sol_y(orc_workspace *w);
 orc_info  *orc_ws_info(orc_workspace *w);
 orc_linsys *orc_ws_linsys(orc_workspace *w);
+orc_float *orc_ws_delta_x(orc_workspace *w);   /* infeasibility certificates after a solve */
+orc_float *orc_ws_delta_y(orc_workspace *w);
+orc_float *orc_ws_D(orc_workspace *w);         /* OSQPScaling */
+orc_float *orc_ws_E(orc_workspace *w);
+orc_float  orc_ws_c(orc_workspace *w);
 orc_int    orc_linsys_nnzL(orc_linsys *s);
 void       orc_linsys_export(orc_linsys *s, orc_int *P, orc_int *etree, orc_int *Lnz, orc_int *Lp,
                              orc_int *Li, orc_float *Lx, orc_float *D, orc_float *Dinv);

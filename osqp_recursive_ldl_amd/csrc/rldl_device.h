@@ -58,6 +58,10 @@ typedef struct {
   int *refactor;                                       /* [batch] mask written by the adapt-rho step */
   int *n_active;                                       /* [1] instances still iterating */
   int write_delta;                                     /* 1: this iteration also stores delta_x / delta_y (a check follows) */
+  /* Ruiz equilibration (src/scaling.c): per-instance D[n], E[m], their inverses, cost scaling c; 0 iterations = off */
+  int scaling, scaled_termination;
+  double *sD, *sDinv, *sE, *sEinv, *sc, *scinv;
+  double *sol_x, *sol_y;                               /* unscaled solution (store_solution, auxil.c:527-565) */
 } rldl_dev_admm;
 
 /* shared-memory footprint (bytes) of the LDS-resident variants; the launchers pick the global-memory
@@ -75,6 +79,13 @@ int rldl_launch_admm_check(const rldl_dev_sym *S, const rldl_dev_admm *W, int it
 int rldl_launch_admm_adapt_rho(const rldl_dev_sym *S, const rldl_dev_admm *W, void *stream);
 int rldl_launch_set_rho_vec(const rldl_dev_sym *S, const rldl_dev_admm *W, int init, void *stream);
 int rldl_launch_finalize(const rldl_dev_sym *S, const rldl_dev_admm *W, int max_iter, void *stream);
+/* scale_data / unscale_data (src/scaling.c:44-173) on the workspace's own copies of P, A, q, l, u */
+int rldl_launch_scale_data(const rldl_dev_sym *S, const rldl_dev_admm *W, double *Px, double *Ax, double *q, double *l, double *u,
+                           int iters, void *stream);
+int rldl_launch_unscale_data(const rldl_dev_sym *S, const rldl_dev_admm *W, double *Px, double *Ax, double *q, double *l, double *u,
+                             void *stream);
+/* dst[b][i] = src[b][i] * s[b][i] * (c ? c[b] : 1) */
+int rldl_launch_ew_scale(int batch, int len, double *dst, const double *src, const double *s, const double *c, void *stream);
 int rldl_launch_matvec_A(const rldl_dev_sym *S, const rldl_dev_admm *W, const double *d_x, double *d_out, void *stream);
 const char *rldl_kernel_arch(void);
 

@@ -318,9 +318,18 @@ __device__ __forceinline__ double norm_inf_lds(const double *v, int len, int lan
   return wave_max(mx);
 }
 
-// is_primal_infeasible (auxil.c:364-424); dyp = projected delta_y (LDS scratch), tmp[n] scratch
+// scaled infinity norm max_i |s_i v_i| (s == nullptr: plain norm)
+__device__ __forceinline__ double norm_inf_s(const double *s, const double *v, int len, int lane) {
+  double mx = 0.0;
+  for (int i = lane; i < len; i += WAVE) { const double a = fabs(s ? s[i] * v[i] : v[i]); mx = a > mx ? a : mx; }
+  return wave_max(mx);
+}
+
+// is_primal_infeasible (auxil.c:364-424); dyp = projected delta_y (LDS scratch), tmp[n] scratch.
+// E / Dinv: per-instance scaling vectors, or nullptr when the termination test runs on scaled quantities.
 __device__ __forceinline__ int primal_infeasible(const rldl_dev_sym &S, const double *Av, const double *l, const double *u,
-                                                 const double *dy, double *dyp, double *tmp, double eps, int lane) {
+                                                 const double *dy, double *dyp, double *tmp, double eps, const double *E,
+                                                 const double *Dinv, int lane) {
   for (int i = lane; i < S.m; i += WAVE) {
     double d = dy[i];
     if (u[i] > OSQP_INFTY * MIN_SCALING) {
@@ -329,7 +338,7 @@ __device__ __forceinline__ int primal_infeasible(const rldl_dev_sym &S, const do
     dyp[i] = d;
   }
   __syncthreads();
-  const double nd = norm_inf_lds(dyp, S.m, lane);
+  const double nd = norm_inf_s(E, dyp, S.m, lane);              // ||E delta_y|| when unscaling (:394-400)
   if (!(nd > eps)) return 0;
   double lhs = 0.0;
   for (int i = lane; i < S.m; i += WAVE) lhs += u[i] * fmax(dyp[i], 0.0) + l[i] * fmin(dyp[i], 0.0);
@@ -337,28 +346,30 @@ __device__ __forceinline__ int primal_infeasible(const rldl_dev_sym &S, const do
   if (!(lhs < -eps * nd)) return 0;
   spmv_At(S, Av, dyp, tmp, lane);
   __syncthreads();
-  return norm_inf_lds(tmp, S.n, lane) < eps * nd;
+  return norm_inf_s(Dinv, tmp, S.n, lane) < eps * nd;           // Dinv A' delta_y (:412-418)
 }
 
-// is_dual_infeasible (auxil.c:426-515); tmpn[n], tmpm[m] scratch
+// is_dual_infeasible (auxil.c:426-515); tmpn[n], tmpm[m] scratch; D/Dinv/Einv/c as above (c = 1 when scaled)
 __device__ __forceinline__ int dual_infeasible(const rldl_dev_sym &S, const double *Pv, const double *Av, const double *q,
                                                const double *l, const double *u, const double *dx, double *tmpn,
-                                               double *tmpm, double eps, int lane) {
-  const double nd = norm_inf_lds(dx, S.n, lane);
+                                               double *tmpm, double eps, const double *D, const double *Dinv,
+                                               const double *Einv, double c, int lane) {
+  const double nd = norm_inf_s(D, dx, S.n, lane);
   if (!(nd > eps)) return 0;
   double qd = 0.0;
   for (int i = lane; i < S.n; i += WAVE) qd += q[i] * dx[i];
   qd = wave_sum(qd);
-  if (!(qd < -eps * nd)) return 0;
+  if (!(qd < -c * eps * nd)) return 0;
   spmv_Psym(S, Pv, dx, tmpn, lane);
   __syncthreads();
-  if (!(norm_inf_lds(tmpn, S.n, lane) < eps * nd)) return 0;
+  if (!(norm_inf_s(Dinv, tmpn, S.n, lane) < c * eps * nd)) return 0;
   spmv_A(S, Av, dx, tmpm, lane);
   __syncthreads();
   int viol = 0;
-  for (int i = lane; i < S.m; i += WAVE)
-    if ((u[i] < OSQP_INFTY * MIN_SCALING && tmpm[i] > eps * nd) || (l[i] > -OSQP_INFTY * MIN_SCALING && tmpm[i] < -eps * nd))
-      viol = 1;
+  for (int i = lane; i < S.m; i += WAVE) {
+    const double adx = Einv ? Einv[i] * tmpm[i] : tmpm[i];
+    if ((u[i] < OSQP_INFTY * MIN_SCALING && adx > eps * nd) || (l[i] > -OSQP_INFTY * MIN_SCALING && adx < -eps * nd)) viol = 1;
+  }
   return !wave_any(viol);
 }
 
@@ -382,6 +393,11 @@ __global__ __launch_bounds__(WAVE) void k_admm_check(rldl_dev_sym S, rldl_dev_ad
   const double *q = W.q + (size_t)inst * n, *l = W.l + (size_t)inst * m, *u = W.u + (size_t)inst * m;
   double *x = W.x + (size_t)inst * n, *z = W.z + (size_t)inst * m, *y = W.y + (size_t)inst * m;
   double *dxg = W.delta_x + (size_t)inst * n, *dyg = W.delta_y + (size_t)inst * m;
+  // termination on unscaled quantities when the data was equilibrated (settings->scaling && !scaled_termination)
+  const bool uns = W.scaling && !W.scaled_termination;
+  const double *sD = uns ? W.sD + (size_t)inst * n : nullptr, *sDinv = uns ? W.sDinv + (size_t)inst * n : nullptr;
+  const double *sE = uns ? W.sE + (size_t)inst * m : nullptr, *sEinv = uns ? W.sEinv + (size_t)inst * m : nullptr;
+  const double sc = uns ? W.sc[inst] : 1.0, scinv = uns ? W.scinv[inst] : 1.0;
 
   for (int i = lane; i < n; i += WAVE) { vx[i] = x[i]; vdx[i] = dxg[i]; }
   for (int i = lane; i < m; i += WAVE) { vy[i] = y[i]; vz[i] = z[i]; vdy[i] = dyg[i]; }
@@ -392,16 +408,23 @@ __global__ __launch_bounds__(WAVE) void k_admm_check(rldl_dev_sym S, rldl_dev_ad
   spmv_Psym(S, Pv, vx, vPx, lane);
   spmv_At(S, Av, vy, vAty, lane);
   __syncthreads();
-  double pr = 0.0, dr = 0.0;
-  for (int i = lane; i < m; i += WAVE) { const double a = fabs(vAx[i] - vz[i]); pr = a > pr ? a : pr; }
-  for (int i = lane; i < n; i += WAVE) { const double a = fabs(q[i] + vPx[i] + vAty[i]); dr = a > dr ? a : dr; }
-  pr = m ? wave_max(pr) : 0.0;
-  dr = wave_max(dr);
-  const double nz = norm_inf_lds(vz, m, lane), nAx = norm_inf_lds(vAx, m, lane);
-  double nq = 0.0;
-  for (int i = lane; i < n; i += WAVE) { const double a = fabs(q[i]); nq = a > nq ? a : nq; }
-  nq = wave_max(nq);
-  const double nAty = norm_inf_lds(vAty, n, lane), nPx = norm_inf_lds(vPx, n, lane);
+  for (int i = lane; i < m; i += WAVE) t_m[i] = vAx[i] - vz[i];                     // primal residual vector (z_prev in the reference)
+  for (int i = lane; i < n; i += WAVE) t_n[i] = q[i] + vPx[i] + vAty[i];            // dual residual vector (x_prev in the reference)
+  __syncthreads();
+  // raw (scaled-problem) norms: what compute_rho_estimate uses (auxil.c:13-55)
+  const double prr = m ? norm_inf_s(nullptr, t_m, m, lane) : 0.0, drr = norm_inf_s(nullptr, t_n, n, lane);
+  const double nzr = norm_inf_s(nullptr, vz, m, lane), nAxr = norm_inf_s(nullptr, vAx, m, lane);
+  const double nqr = norm_inf_s(nullptr, q, n, lane), nAtyr = norm_inf_s(nullptr, vAty, n, lane), nPxr = norm_inf_s(nullptr, vPx, n, lane);
+  // norms of the termination test (auxil.c:243-362)
+  double pr = prr, dr = drr, nz = nzr, nAx = nAxr, nq = nqr, nAty = nAtyr, nPx = nPxr;
+  if (uns) {
+    pr = m ? norm_inf_s(sEinv, t_m, m, lane) : 0.0;
+    dr = scinv * norm_inf_s(sDinv, t_n, n, lane);
+    nz = norm_inf_s(sEinv, vz, m, lane); nAx = norm_inf_s(sEinv, vAx, m, lane);
+    nq = scinv * norm_inf_s(sDinv, q, n, lane); nAty = scinv * norm_inf_s(sDinv, vAty, n, lane);
+    nPx = scinv * norm_inf_s(sDinv, vPx, n, lane);
+  }
+  __syncthreads();
 
   const int do_info = active && (!(mode & CHK_FINAL) || (mode & CHK_FINAL_NEEDS_INFO));
   if (do_info && lane == 0) { W.pri_res[inst] = pr; W.dua_res[inst] = dr; W.iter[inst] = iter; }
@@ -420,17 +443,19 @@ __global__ __launch_bounds__(WAVE) void k_admm_check(rldl_dev_sym S, rldl_dev_ad
     int prc = 0, drc = 0, pic = 0, dic = 0;
     if (m == 0) prc = 1;
     else if (pr < ea + er * fmax(nz, nAx)) prc = 1;
-    else pic = primal_infeasible(S, Av, l, u, vdy, dyp, t_n, epi, lane);
+    else pic = primal_infeasible(S, Av, l, u, vdy, dyp, t_n, epi, sE, sDinv, lane);
     if (dr < ea + er * fmax(fmax(nq, nAty), nPx)) drc = 1;
-    else dic = dual_infeasible(S, Pv, Av, q, l, u, vdx, t_n, t_m, edi, lane);
+    else dic = dual_infeasible(S, Pv, Av, q, l, u, vdx, t_n, t_m, edi, sD, sDinv, sEinv, sc, lane);
     if (prc && drc) st = approx ? ST_SOLVED_INACCURATE : ST_SOLVED;
     else if (pic) {
       st = approx ? ST_PRIMAL_INFEASIBLE_INACCURATE : ST_PRIMAL_INFEASIBLE;
       obj_special = OSQP_INFTY; have_special = 1;
-      for (int i = lane; i < m; i += WAVE) dyg[i] = dyp[i];     // keep the projected certificate
+      for (int i = lane; i < m; i += WAVE) dyg[i] = sE ? sE[i] * dyp[i] : dyp[i];   // certificate, unscaled (:757-760)
     } else if (dic) {
       st = approx ? ST_DUAL_INFEASIBLE_INACCURATE : ST_DUAL_INFEASIBLE;
       obj_special = -OSQP_INFTY; have_special = 1;
+      if (sD) for (int i = lane; i < n; i += WAVE) { vdx[i] *= sD[i]; }              // (:772-775)
+      __syncthreads();
     }
   }
   if ((mode & CHK_FINAL) && st == ST_UNSOLVED) st = ST_MAX_ITER_REACHED;   // osqp.c:567-571
@@ -440,11 +465,13 @@ __global__ __launch_bounds__(WAVE) void k_admm_check(rldl_dev_sym S, rldl_dev_ad
     if (have_special) W.obj[inst] = obj_special;
     atomicSub(W.n_active, 1);
   }
+  if (active && (st == ST_DUAL_INFEASIBLE || st == ST_DUAL_INFEASIBLE_INACCURATE))
+    for (int i = lane; i < n; i += WAVE) dxg[i] = vdx[i];
 
   // adapt_rho (auxil.c:13-77); only for instances that keep iterating
   if ((mode & CHK_ADAPT) && st == ST_UNSOLVED) {
-    double prn = pr / (fmax(nz, nAx) + 1e-10);
-    double drn = dr / (fmax(fmax(nq, nAty), nPx) + 1e-10);
+    double prn = prr / (fmax(nzr, nAxr) + 1e-10);
+    double drn = drr / (fmax(fmax(nqr, nAtyr), nPxr) + 1e-10);
     const double rho = W.rho_cur[inst];
     double est = rho * sqrt(prn / (drn + 1e-10));
     est = fmin(fmax(est, RHO_MIN), RHO_MAX);
@@ -466,18 +493,27 @@ __global__ __launch_bounds__(WAVE) void k_admm_check(rldl_dev_sym S, rldl_dev_ad
   if (mode & CHK_FINAL) {
     const int has_sol = st != ST_PRIMAL_INFEASIBLE && st != ST_PRIMAL_INFEASIBLE_INACCURATE && st != ST_DUAL_INFEASIBLE &&
                         st != ST_DUAL_INFEASIBLE_INACCURATE && st != ST_NON_CVX;
+    double *sx = W.sol_x + (size_t)inst * n, *sy = W.sol_y + (size_t)inst * m;
     if (has_sol) {
       double o = 0.0;
       for (int i = lane; i < n; i += WAVE) o += (0.5 * vPx[i] + q[i]) * vx[i];   // 1/2 x'Px + q'x (auxil.c:230-241)
       o = wave_sum(o);
+      if (W.scaling) o *= W.scinv[inst];
       if (lane == 0) W.obj[inst] = o;
+      // unscale_solution (scaling.c:175-192)
+      const double *D = W.scaling ? W.sD + (size_t)inst * n : nullptr, *E = W.scaling ? W.sE + (size_t)inst * m : nullptr;
+      const double ci = W.scaling ? W.scinv[inst] : 1.0;
+      for (int i = lane; i < n; i += WAVE) sx[i] = D ? D[i] * vx[i] : vx[i];
+      for (int i = lane; i < m; i += WAVE) sy[i] = E ? E[i] * vy[i] * ci : vy[i];
     }
     {
-      double prn = pr / (fmax(nz, nAx) + 1e-10), drn = dr / (fmax(fmax(nq, nAty), nPx) + 1e-10);
+      double prn = prr / (fmax(nzr, nAxr) + 1e-10), drn = drr / (fmax(fmax(nqr, nAtyr), nPxr) + 1e-10);
       double est = W.rho_cur[inst] * sqrt(prn / (drn + 1e-10));
       if (lane == 0) W.rho_est[inst] = fmin(fmax(est, RHO_MIN), RHO_MAX);
     }
     if (!has_sol) {
+      for (int i = lane; i < n; i += WAVE) sx[i] = OSQP_NAN_VALUE;
+      for (int i = lane; i < m; i += WAVE) sy[i] = OSQP_NAN_VALUE;
       // normalised certificates (auxil.c:543-557), iterates cold-started (:560-562)
       if (st == ST_PRIMAL_INFEASIBLE || st == ST_PRIMAL_INFEASIBLE_INACCURATE) {
         __syncthreads();
@@ -487,11 +523,103 @@ __global__ __launch_bounds__(WAVE) void k_admm_check(rldl_dev_sym S, rldl_dev_ad
         for (int i = lane; i < m; i += WAVE) dyg[i] *= 1.0 / nv;
       }
       if (st == ST_DUAL_INFEASIBLE || st == ST_DUAL_INFEASIBLE_INACCURATE) {
-        const double nv = norm_inf_lds(vdx, n, lane);
-        for (int i = lane; i < n; i += WAVE) dxg[i] = vdx[i] * (1.0 / nv);
+        __syncthreads();
+        double nv = 0.0;
+        for (int i = lane; i < n; i += WAVE) { const double a = fabs(dxg[i]); nv = a > nv ? a : nv; }
+        nv = wave_max(nv);
+        for (int i = lane; i < n; i += WAVE) dxg[i] *= 1.0 / nv;
       }
+      for (int i = lane; i < n; i += WAVE) x[i] = 0.0;
+      for (int i = lane; i < m; i += WAVE) { z[i] = 0.0; y[i] = 0.0; }
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Ruiz equilibration of one instance per wave (scale_data, src/scaling.c:44-156): `iters` passes of
+// D, E <- 1/sqrt(inf-norm of the KKT columns) applied to P, A, q, followed by the cost normalisation
+// step; ends with Dinv, Einv, cinv and the scaling of l, u.  Works in place on the workspace's own
+// copies; column norms use the CSC and row-order maps of the shared pattern, so there are no atomics.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double limit_scaling(double v) {      // scaling.c:7-14
+  v = v < MIN_SCALING ? 1.0 : v;
+  return v > 1e4 ? 1e4 : v;
+}
+__device__ __forceinline__ double colnorm_P_sym(const rldl_dev_sym &S, const double *P, int j) {   // mat_inf_norm_cols_sym_triu
+  double d = 0.0;
+  for (int p = S.Pp[j]; p < S.Pp[j + 1]; p++) d = fmax(d, fabs(P[p]));
+  for (int p = S.Prp[j]; p < S.Prp[j + 1]; p++) d = fmax(d, fabs(P[S.Prpos[p]]));
+  return d;
+}
+
+__global__ __launch_bounds__(WAVE) void k_scale_data(rldl_dev_sym S, rldl_dev_admm W, double *Px_all, double *Ax_all, double *q_all,
+                                                     double *l_all, double *u_all, int iters) {
+  const int inst = blockIdx.x, lane = threadIdx.x, n = S.n, m = S.m;
+  extern __shared__ double sh[];
+  double *Dt = sh, *Et = Dt + n;
+  double *P = Px_all + (size_t)inst * S.nnzP, *A = Ax_all + (size_t)inst * S.nnzA, *q = q_all + (size_t)inst * n;
+  double *l = l_all + (size_t)inst * m, *u = u_all + (size_t)inst * m;
+  double *D = W.sD + (size_t)inst * n, *Dinv = W.sDinv + (size_t)inst * n, *E = W.sE + (size_t)inst * m, *Einv = W.sEinv + (size_t)inst * m;
+  for (int j = lane; j < n; j += WAVE) D[j] = 1.0;
+  for (int i = lane; i < m; i += WAVE) E[i] = 1.0;
+  double c = 1.0;
+  __syncthreads();
+  for (int it = 0; it < iters; it++) {
+    for (int j = lane; j < n; j += WAVE) {                       // norms of the columns of [P A'; A 0] (scaling.c:27-42)
+      double d = colnorm_P_sym(S, P, j);
+      for (int p = S.Ap[j]; p < S.Ap[j + 1]; p++) d = fmax(d, fabs(A[p]));
+      Dt[j] = 1.0 / sqrt(limit_scaling(d));
+    }
+    for (int i = lane; i < m; i += WAVE) {
+      double e = 0.0;
+      for (int p = S.Arp[i]; p < S.Arp[i + 1]; p++) e = fmax(e, fabs(A[S.Arpos[p]]));
+      Et[i] = 1.0 / sqrt(limit_scaling(e));
+    }
+    __syncthreads();
+    for (int j = lane; j < n; j += WAVE) {                       // P <- D P D, A <- E A D, q <- D q (scaling.c:91-101)
+      for (int p = S.Pp[j]; p < S.Pp[j + 1]; p++) P[p] = (P[p] * Dt[S.Pi[p]]) * Dt[j];
+      for (int p = S.Ap[j]; p < S.Ap[j + 1]; p++) A[p] = (A[p] * Et[S.Ai[p]]) * Dt[j];
+      q[j] *= Dt[j];
+      D[j] *= Dt[j];
+    }
+    for (int i = lane; i < m; i += WAVE) E[i] *= Et[i];
+    __syncthreads();
+    double sum = 0.0, nq = 0.0;                                  // cost normalisation (scaling.c:110-141)
+    for (int j = lane; j < n; j += WAVE) { sum += colnorm_P_sym(S, P, j); nq = fmax(nq, fabs(q[j])); }
+    sum = wave_sum(sum); nq = wave_max(nq);
+    double ct = fmax(sum / (double)n, limit_scaling(nq));
+    ct = 1.0 / limit_scaling(ct);
+    __syncthreads();
+    for (int p = lane; p < S.nnzP; p += WAVE) P[p] *= ct;
+    for (int j = lane; j < n; j += WAVE) q[j] *= ct;
+    c *= ct;
+    __syncthreads();
+  }
+  for (int j = lane; j < n; j += WAVE) Dinv[j] = 1.0 / D[j];
+  for (int i = lane; i < m; i += WAVE) { const double e = E[i]; Einv[i] = 1.0 / e; l[i] *= e; u[i] *= e; }
+  if (lane == 0) { W.sc[inst] = c; W.scinv[inst] = 1.0 / c; }
+}
+
+// unscale_data (scaling.c:160-173)
+__global__ __launch_bounds__(WAVE) void k_unscale_data(rldl_dev_sym S, rldl_dev_admm W, double *Px_all, double *Ax_all, double *q_all,
+                                                       double *l_all, double *u_all) {
+  const int inst = blockIdx.x, lane = threadIdx.x, n = S.n, m = S.m;
+  double *P = Px_all + (size_t)inst * S.nnzP, *A = Ax_all + (size_t)inst * S.nnzA, *q = q_all + (size_t)inst * n;
+  double *l = l_all + (size_t)inst * m, *u = u_all + (size_t)inst * m;
+  const double *Dinv = W.sDinv + (size_t)inst * n, *Einv = W.sEinv + (size_t)inst * m;
+  const double cinv = W.scinv[inst];
+  for (int j = lane; j < n; j += WAVE) {
+    for (int p = S.Pp[j]; p < S.Pp[j + 1]; p++) P[p] = ((P[p] * cinv) * Dinv[S.Pi[p]]) * Dinv[j];
+    for (int p = S.Ap[j]; p < S.Ap[j + 1]; p++) A[p] = (A[p] * Einv[S.Ai[p]]) * Dinv[j];
+    q[j] = (q[j] * cinv) * Dinv[j];
+  }
+  for (int i = lane; i < m; i += WAVE) { l[i] *= Einv[i]; u[i] *= Einv[i]; }
+}
+
+__global__ __launch_bounds__(256) void k_ew_scale(int len, double *dst, const double *src, const double *s, const double *c) {
+  const int inst = blockIdx.x;
+  const double cc = c ? c[inst] : 1.0;
+  for (int i = threadIdx.x; i < len; i += blockDim.x) dst[(size_t)inst * len + i] = src[(size_t)inst * len + i] * s[(size_t)inst * len + i] * cc;
 }
 
 // set_rho_vec (auxil.c:79-101) when init != 0, update_rho_vec (auxil.c:103-145) otherwise:
@@ -1452,6 +1580,25 @@ extern "C" int rldl_launch_set_rho_vec(const rldl_dev_sym *S, const rldl_dev_adm
 extern "C" int rldl_launch_finalize(const rldl_dev_sym *S, const rldl_dev_admm *W, int max_iter, void *stream) {
   (void)S; (void)W; (void)max_iter; (void)stream;
   return 0; /* folded into k_admm_check (mode bit CHK_FINAL) */
+}
+
+extern "C" int rldl_launch_scale_data(const rldl_dev_sym *S, const rldl_dev_admm *W, double *Px, double *Ax, double *q, double *l,
+                                      double *u, int iters, void *stream) {
+  if (W->batch <= 0) return 0;
+  hipLaunchKernelGGL(k_scale_data, dim3(W->batch), dim3(WAVE), sizeof(double) * (size_t)(S->n + S->m + 2), (hipStream_t)stream, *S, *W, Px,
+                     Ax, q, l, u, iters);
+  return launch_status();
+}
+extern "C" int rldl_launch_unscale_data(const rldl_dev_sym *S, const rldl_dev_admm *W, double *Px, double *Ax, double *q, double *l,
+                                        double *u, void *stream) {
+  if (W->batch <= 0) return 0;
+  hipLaunchKernelGGL(k_unscale_data, dim3(W->batch), dim3(WAVE), 0, (hipStream_t)stream, *S, *W, Px, Ax, q, l, u);
+  return launch_status();
+}
+extern "C" int rldl_launch_ew_scale(int batch, int len, double *dst, const double *src, const double *s, const double *c, void *stream) {
+  if (batch <= 0 || len <= 0) return 0;
+  hipLaunchKernelGGL(k_ew_scale, dim3(batch), dim3(256), 0, (hipStream_t)stream, len, dst, src, s, c);
+  return launch_status();
 }
 
 extern "C" int rldl_launch_matvec_A(const rldl_dev_sym *S, const rldl_dev_admm *W, const double *d_x, double *d_out,

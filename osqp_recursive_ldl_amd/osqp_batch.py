@@ -76,9 +76,23 @@ class OSQPBatch:
                    z=self._view(p[2].value, (B, m), torch.float64), status=self._view(p[3].value, (B,), torch.int32),
                    iter=self._view(p[4].value, (B,), torch.int32), obj=self._view(p[5].value, (B,), torch.float64),
                    pri_res=self._view(p[6].value, (B,), torch.float64), dua_res=self._view(p[7].value, (B,), torch.float64))
+        it = [C.c_void_p() for _ in range(5)]
+        _lib.lib().osqp_batch_get_iterates(self.h, *[C.byref(t) for t in it])
+        out.update(x_iter=self._view(it[0].value, (B, n), torch.float64), y_iter=self._view(it[1].value, (B, m), torch.float64),
+                   delta_x=self._view(it[3].value, (B, n), torch.float64), delta_y=self._view(it[4].value, (B, m), torch.float64))
         if clone:
             out = {k: v.clone() for k, v in out.items()}
         return out
+
+    def scaling_vectors(self):
+        """(D, E, c) of the Ruiz equilibration (OSQPScaling), or None when settings.scaling == 0."""
+        import torch
+        p = [C.c_void_p() for _ in range(3)]
+        if _lib.lib().osqp_batch_get_scaling(self.h, *[C.byref(t) for t in p]):
+            return None
+        return (self._view(p[0].value, (self.batch, self.n), torch.float64).clone(),
+                self._view(p[1].value, (self.batch, self.m), torch.float64).clone(),
+                self._view(p[2].value, (self.batch,), torch.float64).clone())
 
     def update_lin_cost(self, q):
         return int(_lib.lib().osqp_batch_update_lin_cost(self.h, _dptr(_dev_f64(q, (self.batch, self.n), "q"))))

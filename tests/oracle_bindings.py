@@ -90,7 +90,8 @@ def lib():
         L.orc_update_P_A.argtypes = [VP, FP, FP]
         L.orc_update_P_A.restype = c_int
         L.orc_warm_start.argtypes = [VP, FP, FP]
-        for nm in ("orc_ws_x", "orc_ws_y", "orc_ws_z", "orc_ws_sol_x", "orc_ws_sol_y"):
+        for nm in ("orc_ws_x", "orc_ws_y", "orc_ws_z", "orc_ws_sol_x", "orc_ws_sol_y", "orc_ws_delta_x", "orc_ws_delta_y",
+                   "orc_ws_D", "orc_ws_E"):
             getattr(L, nm).argtypes = [VP]
             getattr(L, nm).restype = FP
         L.orc_ws_info.argtypes = [VP]
@@ -224,7 +225,13 @@ class OracleOSQP:
                     iter=info.iter, status=info.status_val, obj=info.obj_val, pri_res=info.pri_res,
                     dua_res=info.dua_res, rho_updates=info.rho_updates,
                     x_iter=self._vec(lib().orc_ws_x, self.n), y_iter=self._vec(lib().orc_ws_y, self.m),
-                    z_iter=self._vec(lib().orc_ws_z, self.m))
+                    z_iter=self._vec(lib().orc_ws_z, self.m), delta_x=self._vec(lib().orc_ws_delta_x, self.n),
+                    delta_y=self._vec(lib().orc_ws_delta_y, self.m))
+
+    def scaling_vectors(self):
+        lib().orc_ws_c.restype = C.c_double
+        lib().orc_ws_c.argtypes = [C.c_void_p]
+        return self._vec(lib().orc_ws_D, self.n), self._vec(lib().orc_ws_E, self.m), float(lib().orc_ws_c(self.h))
 
     def update_lin_cost(self, q):
         q = np.ascontiguousarray(q, dtype=np.float64)
