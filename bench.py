@@ -49,6 +49,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    settings = dict(rho=0.1, sigma=1e-6, alpha=1.6, max_iter=args.iters, check_termination=0, adaptive_rho=0,
+                    warm_start=0, scaling=0)
+    if torch.cuda.device_count() == 0:                       # (does not initialise the GPU)
+        raise SystemExit("bench.py needs a GPU: the backend has no CPU fallback")
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # timed BEFORE the GPU is initialised: the all-core leg forks worker processes, which must not inherit a
+        # live HIP context.  Same workload, same permutation (host-side symbolic analysis, no device needed).
+        import osqp_recursive_ldl_amd as R0
+        wl0 = R0.workloads.SharedPatternQPs(n=50, m=100, density=0.15, pattern_seed=1000)
+        perm0 = R0.symbolic_analyze(wl0.P_pattern, wl0.A_pattern)["perm"]
+        cpu = cpu_baseline(wl0, settings, perm0, args.cpu_seconds)
+        cpu["all_cores"] = cpu_baseline_all_cores(wl0, settings, perm0, args.cpu_seconds)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the backend has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -65,8 +78,6 @@ def main():
     Px, Ax, q, l, u = wl.values(B, seed0=rank * B)          # this rank's shard of the global batch
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     dPx, dAx, dq, dl, du = t(Px), t(Ax), t(q), t(l), t(u)
-    settings = dict(rho=0.1, sigma=1e-6, alpha=1.6, max_iter=args.iters, check_termination=0, adaptive_rho=0,
-                    warm_start=0, scaling=0)
     w = R.OSQPBatch(wl.P_pattern, wl.A_pattern, dPx, dAx, dq, dl, du, **settings)
     assert w.status == 0, "setup failed: %s" % w.status
     dims = w.linsys().dims()
@@ -135,8 +146,9 @@ def main():
     status = res["status"]
     out["config"]["status_counts"] = {str(int(k)): int((status == k).sum()) for k in torch.unique(status)}
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(wl, settings, w.linsys().export_symbolic()["perm"], args.cpu_seconds)
+    if cpu is not None:
+        assert np.array_equal(perm0, w.linsys().export_symbolic()["perm"])
+        out["cpu_baseline"] = cpu
     if rank == 0:
         print(json.dumps(out))
     w.cleanup()
@@ -173,6 +185,44 @@ def cpu_baseline(wl, settings, perm, budget_s):
             "sample": "%d instances of the bench workload (setup incl. symbolic+factor, then %d ADMM iterations), "
                       "CPU oracle built -O2, single thread" % (count, settings["max_iter"]),
             "host_cores_available": os.cpu_count(), "seconds": tot, "setup_seconds": tf, "solve_seconds": ts}
+
+
+def _cpu_worker(job):
+    wl, settings, perm, count, seed0 = job
+    return _oracle_run(wl, settings, perm, count, seed0)
+
+
+def _oracle_run(wl, settings, perm, count, seed0):
+    import ctypes as C
+    import numpy as np
+    import oracle_bindings as ob
+    L = ob.lib()
+    st = ob.settings(**settings)
+    P, A = wl.P_pattern, wl.A_pattern
+    Pp = np.ascontiguousarray(P.indptr, np.int64); Pi = np.ascontiguousarray(P.indices, np.int64)
+    Ap = np.ascontiguousarray(A.indptr, np.int64); Ai = np.ascontiguousarray(A.indices, np.int64)
+    pm = np.ascontiguousarray(perm, np.int64)
+    Px, Ax, q, l, u = wl.values(count, seed0=seed0)
+    tf, ts = C.c_double(0), C.c_double(0)
+    tot = L.orc_bench_shared_pattern(count, wl.n, wl.m, ob.ip(Pp), ob.ip(Pi), ob.fp(Px), ob.ip(Ap), ob.ip(Ai), ob.fp(Ax),
+                                     ob.fp(q), ob.fp(l), ob.fp(u), C.byref(st), ob.ip(pm), None, None, C.byref(tf), C.byref(ts))
+    return tot
+
+
+def cpu_baseline_all_cores(wl, settings, perm, budget_s):
+    """Same oracle, one instance per task over all host cores of the box's share (the reference is single-threaded
+    per instance, qdldl_interface.c:208-209): forked workers, each timing only its oracle calls."""
+    import multiprocessing as mp
+    cores = max(1, min(16, os.cpu_count() or 1))
+    per = _oracle_run(wl, settings, perm, 8, 0) / 8
+    count = int(max(16, min(4000, 0.5 * budget_s / max(per, 1e-6))))
+    with mp.get_context("fork").Pool(cores) as pool:
+        t0 = time.perf_counter()
+        times = pool.map(_cpu_worker, [(wl, settings, perm, count, 100000 + k * count) for k in range(cores)])
+        wall = time.perf_counter() - t0
+    return {"value": cores * count / max(times), "unit": "QP solves/s", "cores": cores,
+            "sample": "%d instances per worker, %d forked workers" % (count, cores), "slowest_worker_seconds": max(times),
+            "wall_seconds_incl_data_generation": wall}
 
 
 if __name__ == "__main__":

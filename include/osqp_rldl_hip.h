@@ -162,6 +162,9 @@ c_int osqp_batch_get_scaling(osqp_batch *w, c_float **d_D, c_float **d_E, c_floa
 rldl_batch *osqp_batch_linsys(osqp_batch *w);
 /* timing of the fused ADMM-iteration kernel (HIP events on the workspace stream), for the roofline */
 c_int osqp_batch_time_iteration(osqp_batch *w, c_int reps, c_float *ms_per_launch);
+/* wave timeline of one fused-iteration launch: host_out[batch][8] int64 ticks of the 100 MHz device clock
+ * (start, inputs arrived, rhs built, gather done, sweeps done, substitution done, end, CU id) */
+c_int osqp_batch_trace_iteration(osqp_batch *w, long long *host_out);
 void  osqp_batch_cleanup(osqp_batch *w);                                /* osqp.c:646-744 */
 
 /* =====================================================================================

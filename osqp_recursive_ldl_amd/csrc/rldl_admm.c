@@ -371,6 +371,28 @@ c_int osqp_batch_get_scaling(osqp_batch *w, c_float **d_D, c_float **d_E, c_floa
 
 rldl_batch *osqp_batch_linsys(osqp_batch *w) { return w ? w->ls : 0; }
 
+/* Wave timeline of ONE fused-iteration launch (tracing aid for the roofline work): for every instance 8 int64
+ * s_memrealtime ticks (100 MHz) -- [0] wave start, [1] coupling values + vectors arrived, [2] rhs built,
+ * [3] forward gather done and triangle arrived, [4] sweeps done, [5] substitution done, [6] wave end, [7] CU id.
+ * Only the arrowhead kernel is instrumented; other kernels leave the buffer zero.  Advances the iterates. */
+c_int osqp_batch_trace_iteration(osqp_batch *w, long long *host_out) {
+  long long *d = 0;
+  size_t bytes;
+  c_int rc = 1;
+  if (!w || !host_out) return 1;
+  bytes = sizeof(long long) * 8 * (size_t)w->batch;
+  if (!HIP_OK(hipMalloc((void **)&d, bytes))) return RLDL_MEM_ALLOC_ERROR;
+  if (HIP_OK(hipMemsetAsync(d, 0, bytes, (hipStream_t)w->stream)) && !fill_int(w, w->W.status, ST_UNSOLVED)) {
+    w->W.trace = d; w->W.write_delta = 0;
+    rc = rldl_launch_admm_iter(&w->ls->dsym, &w->ls->num, &w->W, w->stream) ? 1 : 0;
+    w->W.trace = 0;
+    if (!rc && !(HIP_OK(hipMemcpyAsync(host_out, d, bytes, hipMemcpyDeviceToHost, (hipStream_t)w->stream)) &&
+                 HIP_OK(hipStreamSynchronize((hipStream_t)w->stream)))) rc = 1;
+  }
+  (void)hipFree(d);
+  return rc;
+}
+
 /* Average device time of the fused ADMM-iteration kernel over the last osqp_batch_solve loop when
  * reps == 0 (valid when no check kernels were interleaved: check_termination = adaptive_rho = 0),
  * otherwise time `reps` extra launches now (this advances the iterates). */

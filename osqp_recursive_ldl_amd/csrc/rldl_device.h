@@ -58,6 +58,7 @@ typedef struct {
   int *refactor;                                       /* [batch] mask written by the adapt-rho step */
   int *n_active;                                       /* [1] instances still iterating */
   int write_delta;                                     /* 1: this iteration also stores delta_x / delta_y (a check follows) */
+  long long *trace;                                    /* wave timeline [batch][8] (s_memrealtime ticks) or NULL; osqp_batch_trace_iteration */
   /* Ruiz equilibration (src/scaling.c): per-instance D[n], E[m], their inverses, cost scaling c; 0 iterations = off */
   int scaling, scaled_termination;
   double *sD, *sDinv, *sE, *sEinv, *sc, *scinv;

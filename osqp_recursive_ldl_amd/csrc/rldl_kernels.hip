@@ -679,27 +679,30 @@ __device__ __forceinline__ double readlane_f64(double v, int src) {   // src mus
 }
 
 
-#define SU 8   // sweep steps whose L reads are kept in flight (two batches, ping-pong)
-
 // In-group sweeps over a row-major packed triangle T (base pointer Tp, group size g); one lane per index.
-// Branch-free inside a batch: the lane predicate and the step-range predicate select the MULTIPLIER (which is
-// off the dependency chain), so the chain per step is v_readlane x2 -> v_fma_f64 only.
+// U = sweep steps whose L reads are kept in flight per batch (two batches, ping-pong).
+// Branch-free inside a batch: the step's lane mask is a SCALAR (s_lshl_b64, no v_cmp) that selects the MULTIPLIER,
+// which is off the dependency chain, so the chain per step is v_readlane x2 -> v_fma_f64 only.
 //   forward : step a eliminates local column a; lane i > a reads L(i, a) = rowp[a], rowp = Tp + i (i-1)/2
 //   backward: step s uses local row il = g-1-s; lane j < il reads L(il, j) = Tp[il (il-1)/2 + j]
+// Lanes >= g are never touched (they may carry live values of rows handled elsewhere).
+template <int U>
 __device__ __forceinline__ double sweep_fwd(const double *Tp, int g, int lane, double acc) {
-  const int nst = g - 1, nb = (nst + SU - 1) / SU;
+  const int nst = g - 1, nb = (nst + U - 1) / U;
   const int lc = lane < g ? lane : g - 1;
   const double *rowp = Tp + ((lc * (lc - 1)) >> 1);
-  double tA[SU], tB[SU];
-  auto load = [&](int s0, double (&tb)[SU]) {
+  const unsigned long long live = g >= 64 ? ~0ull : ((1ull << g) - 1ull);
+  double tA[U], tB[U];
+  auto load = [&](int s0, double (&tb)[U]) {
 #pragma unroll
-    for (int u = 0; u < SU; u++) tb[u] = rowp[s0 + u];         // reads past the row / the triangle are masked below
+    for (int u = 0; u < U; u++) tb[u] = rowp[s0 + u];          // reads past the row / the triangle are masked below
   };
-  auto proc = [&](int s0, const double (&tb)[SU]) {
+  auto proc = [&](int s0, const double (&tb)[U]) {
 #pragma unroll
-    for (int u = 0; u < SU; u++) {
+    for (int u = 0; u < U; u++) {
       const int a = s0 + u;
-      const double tm = (lane > a && a < nst) ? tb[u] : 0.0;
+      const unsigned long long mk = a < nst ? ((~1ull << a) & live) : 0ull;   // lanes (a, g)
+      const double tm = __builtin_amdgcn_inverse_ballot_w64(mk) ? tb[u] : 0.0;
       const double xj = readlane_f64(acc, a & 63);
       acc = fma(-tm, xj, acc);
     }
@@ -707,32 +710,34 @@ __device__ __forceinline__ double sweep_fwd(const double *Tp, int g, int lane, d
   int b = 0;
   if (nb > 0) load(0, tA);
   while (b + 2 <= nb) {
-    load((b + 1) * SU, tB);
-    proc(b * SU, tA);
-    if (b + 2 < nb) load((b + 2) * SU, tA);
-    proc((b + 1) * SU, tB);
+    load((b + 1) * U, tB);
+    proc(b * U, tA);
+    if (b + 2 < nb) load((b + 2) * U, tA);
+    proc((b + 1) * U, tB);
     b += 2;
   }
-  if (b < nb) proc(b * SU, tA);
+  if (b < nb) proc(b * U, tA);
   return acc;
 }
+template <int U>
 __device__ __forceinline__ double sweep_bwd(const double *Tp, int g, int lane, double acc) {
-  const int nst = g - 1, nb = (nst + SU - 1) / SU;
+  const int nst = g - 1, nb = (nst + U - 1) / U;
   const double *lanep = Tp + lane;
-  double tA[SU], tB[SU];
-  auto load = [&](int s0, double (&tb)[SU]) {
+  double tA[U], tB[U];
+  auto load = [&](int s0, double (&tb)[U]) {
 #pragma unroll
-    for (int u = 0; u < SU; u++) {
+    for (int u = 0; u < U; u++) {
       int il = g - 1 - (s0 + u);
       il = il > 0 ? il : 0;
       tb[u] = lanep[(il * (il - 1)) >> 1];
     }
   };
-  auto proc = [&](int s0, const double (&tb)[SU]) {
+  auto proc = [&](int s0, const double (&tb)[U]) {
 #pragma unroll
-    for (int u = 0; u < SU; u++) {
+    for (int u = 0; u < U; u++) {
       const int il = g - 1 - (s0 + u);
-      const double tm = (il > 0 && lane < il) ? tb[u] : 0.0;
+      const unsigned long long mk = il > 0 ? ((1ull << il) - 1ull) : 0ull;     // lanes [0, il)
+      const double tm = __builtin_amdgcn_inverse_ballot_w64(mk) ? tb[u] : 0.0;
       const double xi = readlane_f64(acc, il > 0 ? il : 0);
       acc = fma(-tm, xi, acc);
     }
@@ -740,15 +745,17 @@ __device__ __forceinline__ double sweep_bwd(const double *Tp, int g, int lane, d
   int b = 0;
   if (nb > 0) load(0, tA);
   while (b + 2 <= nb) {
-    load((b + 1) * SU, tB);
-    proc(b * SU, tA);
-    if (b + 2 < nb) load((b + 2) * SU, tA);
-    proc((b + 1) * SU, tB);
+    load((b + 1) * U, tB);
+    proc(b * U, tA);
+    if (b + 2 < nb) load((b + 2) * U, tA);
+    proc((b + 1) * U, tB);
     b += 2;
   }
-  if (b < nb) proc(b * SU, tA);
+  if (b < nb) proc(b * U, tA);
   return acc;
 }
+
+#define SU 8   // sweep depth of the plan kernels
 
 #define GU 4   // gather steps per batch
 // w: plan blob (LDS), Sv: [nS factor slots | N Dinv] (LDS), xs: [N] permuted rhs in / solution out (LDS)
@@ -798,7 +805,7 @@ __device__ __forceinline__ void plan_tri_solve(const rldl_dev_sym &S, const int 
     }
     if (na > 0) {
       double acc = act ? xs[r] : 0.0;
-      acc = sweep_fwd(Sv + __builtin_amdgcn_readfirstlane(w[S.po_gToff + k]), g, lane, acc);
+      acc = sweep_fwd<SU>(Sv + __builtin_amdgcn_readfirstlane(w[S.po_gToff + k]), g, lane, acc);
       if (act) xs[r] = acc;
       wave_sync();
     }
@@ -845,7 +852,7 @@ __device__ __forceinline__ void plan_tri_solve(const rldl_dev_sym &S, const int 
     }
     if (nr > 0) {
       double acc = act ? (nbs > 0 ? xs[c] : xs[c] * Dinv[c]) : 0.0;
-      acc = sweep_bwd(Sv + __builtin_amdgcn_readfirstlane(w[S.po_gToff + k]), g, lane, acc);
+      acc = sweep_bwd<SU>(Sv + __builtin_amdgcn_readfirstlane(w[S.po_gToff + k]), g, lane, acc);
       if (act) xs[c] = acc;
       wave_sync();
     }
@@ -884,7 +891,7 @@ __device__ __forceinline__ void wait_dma() { asm volatile("s_waitcnt vmcnt(0)" :
 template <bool STAGE>
 __global__ __launch_bounds__(1024) void k_plan_solve(rldl_dev_sym S, rldl_dev_num Nn, double *__restrict__ b_all, int per_wave) {
   extern __shared__ __attribute__((aligned(16))) double sh[];
-  const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+  const int lane = threadIdx.x & (WAVE - 1), wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wpb = blockDim.x >> 6;
   const int inst = blockIdx.x * wpb + wv;
   int *wl = reinterpret_cast<int *>(sh + (size_t)wpb * per_wave);
   double *Sl = sh + (size_t)wv * per_wave;                     // STAGE: [ldF] factor + Dinv (16-byte aligned), then xs
@@ -941,7 +948,7 @@ __global__ __launch_bounds__(1024) void k_plan_solve(rldl_dev_sym S, rldl_dev_nu
 template <int TMAX, bool STAGE>   // positions per lane held in registers: covers N <= 64*TMAX
 __global__ __launch_bounds__(1024) void k_plan_admm(rldl_dev_sym S, rldl_dev_num Nn, rldl_dev_admm W, int per_wave) {
   extern __shared__ __attribute__((aligned(16))) double sh[];
-  const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+  const int lane = threadIdx.x & (WAVE - 1), wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wpb = blockDim.x >> 6;
   const int inst = blockIdx.x * wpb + wv;
   int *wl = reinterpret_cast<int *>(sh + (size_t)wpb * per_wave);
   double *Sl = sh + (size_t)wv * per_wave;
@@ -1023,7 +1030,7 @@ __global__ __launch_bounds__(1024) void k_plan_admm(rldl_dev_sym S, rldl_dev_num
 template <bool STAGE>
 __global__ __launch_bounds__(1024) void k_plan_admm_loop(rldl_dev_sym S, rldl_dev_num Nn, rldl_dev_admm W, int per_wave) {
   extern __shared__ __attribute__((aligned(16))) double sh[];
-  const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+  const int lane = threadIdx.x & (WAVE - 1), wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wpb = blockDim.x >> 6;
   const int inst = blockIdx.x * wpb + wv;
   int *wl = reinterpret_cast<int *>(sh + (size_t)wpb * per_wave);
   double *Sl = sh + (size_t)wv * per_wave;
@@ -1110,20 +1117,30 @@ __global__ __launch_bounds__(1024) void k_plan_admm_loop(rldl_dev_sym S, rldl_de
 // ================================================================================================
 // Arrowhead specialisation (plan->arrow_ok): all out-of-group entries feed ONE dense group (the Schur
 // tail of a KKT matrix ordered by minimum degree) and no other group has a triangle.  Then
-//   * the coupling values (jagged-diagonal order, one row per lane) are loaded STRAIGHT from HBM into
-//     registers -- fully coalesced, never staged in LDS -- together with their column indices from a
-//     padded [step][64] table;
+//   * the coupling values (jagged-diagonal order, one row per lane) are staged by LDS-DMA, moved to
+//     REGISTERS, and the same LDS bytes are overwritten by the second DMA phase (the packed triangle);
+//     their column indices come from a padded [step][64] table;
 //   * forward: the tail rows gather from the (already final) head entries out of registers, then the
 //     packed triangle is swept forward and -- without leaving registers -- scaled by Dinv and swept back;
+//   * the last `rr` rows of the triangle and Dinv never touch LDS: lane a holds L(i, a) of such a row, so
+//     the forward step of row i is a wave reduction and its backward step a plain fma;
 //   * backward for the head columns is the transposed gather: every tail lane scatters L(r,c) x_r into
 //     x_c with LDS double atomics (ds_add_f64) from the same registers.
-// LDS per wave is only the triangle + Dinv + x (12.2 KB at the metric shape -> 12 waves per CU), there is
-// no shared plan copy and therefore no workgroup barrier.
+// LDS per wave is the triangle without its last rr rows + x (10 224 B at the metric shape with rr = 2, which
+// is what lets 16 waves = 16 instances share a CU: the whole 4096-instance batch is resident at once), there
+// is no shared plan copy and therefore no workgroup barrier.
 // ================================================================================================
+#define ARROW_RR_MAX 2
+#define SA 4   // sweep depth of the arrow kernels (register budget: 128 VGPRs for 4 waves per SIMD)
+
 template <int TG>
 struct ArrowRegs {
   double v[TG];            // coupling values of this lane's row, step-major
   unsigned ix[(TG + 1) / 2];  // packed column indices: step 2k in the low half, 2k+1 in the high half
+};
+struct ArrowDiag {
+  double dtail;            // Dinv[g0 + lane]
+  double row[ARROW_RR_MAX];   // L(g - rr + k, lane) for lane < g - rr + k, else 0
 };
 
 // loads issued by every live wave before its first wait
@@ -1132,6 +1149,21 @@ __device__ __forceinline__ void arrow_load_idx(const rldl_dev_sym &S, int lane, 
   const unsigned *ap = reinterpret_cast<const unsigned *>(S.plan + S.po_apad);
 #pragma unroll
   for (int t2 = 0; t2 < (TG + 1) / 2; t2++) R.ix[t2] = 2 * t2 < S.arrow_steps ? ap[t2 * 64 + lane] : 0u;
+}
+// Dinv of the tail and the register-resident triangle rows: straight from the factor row in HBM (coalesced)
+__device__ __forceinline__ void arrow_load_diag(const rldl_dev_sym &S, const double *Fg, int g0, int g, int rr, int lane, ArrowDiag &Dg) {
+  const double *Dinv = Fg + S.nS;
+  Dg.dtail = Dinv[g0 + (lane < g ? lane : 0)];
+#pragma unroll
+  for (int k = 0; k < ARROW_RR_MAX; k++) {
+    const int i = g - rr + k;                                    // local row index
+    double v = 0.0;
+    if (k < rr) {                                                // uniform
+      v = Fg[S.nOp + ((i * (i - 1)) >> 1) + (lane < i ? lane : 0)];
+      v = lane < i ? v : 0.0;
+    }
+    Dg.row[k] = v;
+  }
 }
 // coupling values: LDS (slots [0, nOp) staged by LDS-DMA at the start of the wave's buffer) -> registers
 template <int TG>
@@ -1148,13 +1180,14 @@ __device__ __forceinline__ void arrow_load_val(const rldl_dev_sym &S, const doub
   }
 }
 
-// Tv: LDS [triangle | Dinv] = factor slots [nOp, ldF); xs: LDS permuted rhs in / solution out
+// Tv: LDS triangle rows [0, g - rr); xs: LDS permuted rhs in / solution out.  Part 1: forward gather, both sweeps;
+// leaves the solution of the tail group in xs and ZERO in every head slot.  Part 2 (arrow_scatter) accumulates
+// -sum_r L(r,c) x_r into the head slots; the caller adds y_c Dinv_c (it still holds y_c in registers).
 template <int TG>
-__device__ __forceinline__ void arrow_tri_solve(const rldl_dev_sym &S, const ArrowRegs<TG> &R, const double *Tv, double *xs,
-                                                int g0, int g, int jr, int lane) {
-  const double *Dinv = Tv + (S.nS - S.nOp);
+__device__ __forceinline__ void arrow_tri_solve(const rldl_dev_sym &S, const ArrowRegs<TG> &R, const ArrowDiag &Dg, const double *Tv,
+                                                double *xs, int g0, int g, int rr, int jr, int lane, long long *tr = nullptr) {
   const bool act = lane < g;
-  const int nst = (S.dbg & 2) ? 0 : g - 1;
+  const int gp = g - rr;                                         // rows whose L entries live in LDS
   // ---- forward gather of the tail rows out of registers ----
   double ga = act ? xs[jr] : 0.0;
   if (!(S.dbg & 1)) {
@@ -1166,24 +1199,53 @@ __device__ __forceinline__ void arrow_tri_solve(const rldl_dev_sym &S, const Arr
       }
   }
   if (act) xs[jr] = ga;
-  wait_dma();                                                    // triangle + Dinv (second DMA phase) streamed in behind the gather
+  wait_dma();                                                    // triangle (second DMA phase) streamed in behind the gather
   wave_sync();
+  if (tr && lane == 0) tr[3] = wall_clock64();                   // gather done, triangle has arrived
   double acc = act ? xs[g0 + lane] : 0.0;
-  if (S.arrow_tb >= 0 && nst > 0) acc = sweep_fwd(Tv + S.arrow_tb, g, lane, acc);
-  if (act) acc *= Dinv[g0 + lane];                               // D^-1 without leaving registers
-  if (S.arrow_tb >= 0 && !(S.dbg & 8)) acc = sweep_bwd(Tv + S.arrow_tb, g, lane, acc);
+  for (int j = lane; j < S.N; j += WAVE)                         // head slots become scatter accumulators
+    if (j < g0 || j >= g0 + g) xs[j] = 0.0;
+  const bool tri = S.arrow_tb >= 0 && g > 1;
+  if (tri && !(S.dbg & 2)) {
+    if (gp > 1) acc = sweep_fwd<SA>(Tv, gp, lane, acc);
+    if (rr > 0) {                                                // rows gp.. : y_i = b_i - sum_a L(i,a) y_a as wave reductions
+      const double y = lane < gp ? acc : 0.0;
+      const double s0 = wave_sum(Dg.row[0] * y);
+      if (lane == gp) acc -= s0;
+      if (rr > 1) {
+        const double s1 = wave_sum(Dg.row[1] * y);
+        const double l10 = readlane_f64(Dg.row[1], gp), y0 = readlane_f64(acc, gp);
+        if (lane == gp + 1) acc = (acc - s1) - l10 * y0;
+      }
+    }
+  }
+  if (act) acc *= Dg.dtail;                                      // D^-1 without leaving registers
+  if (tri && !(S.dbg & 8)) {
+#pragma unroll
+    for (int k = ARROW_RR_MAX - 1; k >= 0; k--)
+      if (k < rr) {                                              // x_j -= L(i, j) x_i, i = gp + k; row[k] is 0 on lanes >= i
+        const double xi = readlane_f64(acc, gp + k);
+        acc = fma(-Dg.row[k], xi, acc);
+      }
+    if (gp > 1) acc = sweep_bwd<SA>(Tv, gp, lane, acc);
+  }
   if (act) xs[g0 + lane] = acc;
-  // every index outside the tail group: x = y * Dinv (its forward step was the identity)
-  for (int j = lane; j < S.N; j += WAVE)
-    if (j < g0 || j >= g0 + g) xs[j] *= Dinv[j];
+  if (tr && lane == 0) tr[4] = wall_clock64();                   // both sweeps done
   wave_sync();
-  // ---- transposed gather: scatter L(r, c) x_r into the head columns with LDS double atomics ----
+}
+// ---- transposed gather: scatter L(r, c) x_r into the head columns with LDS double atomics ----
+template <int TG>
+__device__ __forceinline__ void arrow_scatter(const rldl_dev_sym &S, const ArrowRegs<TG> &R, double *xs, int g, int jr, int lane) {
   if (!(S.dbg & 4)) {
-    const double xr = act ? xs[jr] : 0.0;
+    const double xr = lane < g ? xs[jr] : 0.0;
+    const unsigned *ap = reinterpret_cast<const unsigned *>(S.plan + S.po_apad);   // re-read (L2) rather than held across the sweeps
+    unsigned ix[(TG + 1) / 2];
+#pragma unroll
+    for (int t2 = 0; t2 < (TG + 1) / 2; t2++) ix[t2] = 2 * t2 < S.arrow_steps ? ap[t2 * 64 + lane] : 0u;
 #pragma unroll
     for (int t = 0; t < TG; t++)
       if (t < S.arrow_steps) {
-        const unsigned col = (t & 1) ? R.ix[t >> 1] >> 16 : R.ix[t >> 1] & 0xffffu;
+        const unsigned col = (t & 1) ? ix[t >> 1] >> 16 : ix[t >> 1] & 0xffffu;
         const double pr = R.v[t] * xr;
         if (R.v[t] != 0.0) unsafeAtomicAdd(&xs[col], -pr);
       }
@@ -1191,12 +1253,12 @@ __device__ __forceinline__ void arrow_tri_solve(const rldl_dev_sym &S, const Arr
   wave_sync();
 }
 
-// triangle + Dinv part of the factor row -> LDS by LDS-DMA (slots [nOp, ldF), 16-byte aligned since nOp is even)
-__device__ __forceinline__ void arrow_stage(const rldl_dev_sym &S, const double *Fg, double *Tv, int lane, int first) {
+// LDS-DMA of one part of the factor row into the wave's staging buffer (16-byte pieces; both parts start at an
+// even slot).  first != 0: coupling values, slots [0, nOp); else the triangle rows kept in LDS, `cnt2` pieces.
+__device__ __forceinline__ void arrow_stage(const rldl_dev_sym &S, const double *Fg, double *Tv, int lane, int first, int cnt2) {
   typedef __attribute__((address_space(1))) const void *gptr_t;
   typedef __attribute__((address_space(3))) void *lptr_t;
-  // first != 0: coupling values, slots [0, nOp); else triangle + Dinv, slots [nOp, ldF).  Both land at Tv.
-  const int n2 = first ? S.nOp >> 1 : (S.ldF - S.nOp) >> 1;
+  const int n2 = first ? S.nOp >> 1 : cnt2;
   const double *src = first ? Fg : Fg + S.nOp;
   for (int base = 0; base < n2; base += WAVE) {
     const int i = base + lane;
@@ -1204,77 +1266,85 @@ __device__ __forceinline__ void arrow_stage(const rldl_dev_sym &S, const double 
   }
 }
 
-template <int TG>
-__global__ __launch_bounds__(256, 3) void k_arrow_solve(rldl_dev_sym S, rldl_dev_num Nn, double *__restrict__ b_all, int per_wave) {
+// doubles per wave, offset of x, 16-B pieces of the LDS triangle, register rows, cohort staggering on/off
+struct ArrowGeom { int per_wave, xoff, tri2, rr, stagger; };
+
+template <int TMAX, int TG>
+__global__ __launch_bounds__(256, 4) void k_arrow_solve(rldl_dev_sym S, rldl_dev_num Nn, double *__restrict__ b_all, ArrowGeom G) {
   extern __shared__ __attribute__((aligned(16))) double sh[];
-  const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+  const int lane = threadIdx.x & (WAVE - 1), wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wpb = blockDim.x >> 6;
   const int inst = blockIdx.x * wpb + wv;
   if (inst >= Nn.batch) return;
-  double *Tv = sh + (size_t)wv * per_wave;
-  double *xs = Tv + (per_wave - ((S.N + 1) & ~1) - 2);
+  double *Tv = sh + (size_t)wv * G.per_wave;
+  double *xs = Tv + G.xoff;
   const double *Fg = Nn.F + (size_t)inst * S.ldF;
   double *b = b_all + (size_t)inst * S.N;
   const int *permg = S.plan + S.po_perm;
   const int g0 = S.arrow_g0, g = S.arrow_g;
   ArrowRegs<TG> R;
-  arrow_stage(S, Fg, Tv, lane, 1);                              // coupling values first ...
+  ArrowDiag Dg;
+  arrow_stage(S, Fg, Tv, lane, 1, 0);                           // coupling values first ...
   arrow_load_idx<TG>(S, lane, R);
   const int jr = lane < g ? reinterpret_cast<const unsigned short *>(S.plan + S.po_fsig)[g0 + lane] : 0;
+  int oo[TMAX];
+  double vb[TMAX];
+#pragma unroll
+  for (int t = 0; t < TMAX; t++) { const int j = t * WAVE + lane; oo[t] = j < S.N ? permg[j] : -1; }
+#pragma unroll
+  for (int t = 0; t < TMAX; t++) vb[t] = b[oo[t] >= 0 ? oo[t] : 0];   // permute_x  qdldl_interface.c:538-541
+  arrow_load_diag(S, Fg, g0, g, G.rr, lane, Dg);
   wait_dma();
   arrow_load_val<TG>(S, Tv, lane, R);                           // ... into registers ...
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  arrow_stage(S, Fg, Tv, lane, 0);                              // ... then the triangle + Dinv over the same LDS
-  for (int j0 = 0; j0 < S.N; j0 += 4 * WAVE) {                 // permute_x  qdldl_interface.c:538-541
-    double v[4];
+  arrow_stage(S, Fg, Tv, lane, 0, G.tri2);                      // ... then the triangle over the same LDS
 #pragma unroll
-    for (int t = 0; t < 4; t++) { const int j = j0 + t * WAVE + lane; v[t] = j < S.N ? b[permg[j]] : 0.0; }
-#pragma unroll
-    for (int t = 0; t < 4; t++) { const int j = j0 + t * WAVE + lane; if (j < S.N) xs[j] = v[t]; }
-  }
+  for (int t = 0; t < TMAX; t++) { const int j = t * WAVE + lane; if (oo[t] >= 0) xs[j] = vb[t]; }
   wave_sync();                                                  // (the triangle DMA is awaited inside, behind the gather)
-  arrow_tri_solve<TG>(S, R, Tv, xs, g0, g, jr, lane);
-  if (S.polish) {
-    for (int j = lane; j < S.N; j += WAVE) b[permg[j]] = xs[j];
-  } else {
-    const double *ri = Nn.rho_inv + (size_t)inst * S.m;
-    for (int j0 = 0; j0 < S.N; j0 += 4 * WAVE) {
-      double bo[4], rr[4];
-      int oo[4];
+  arrow_tri_solve<TG>(S, R, Dg, Tv, xs, g0, g, G.rr, jr, lane);
+  double dv[TMAX], rr_[TMAX];                                   // head Dinv and rho_inv: fetched under the scatter
+  const double *ri = Nn.rho_inv + (size_t)inst * S.m;
 #pragma unroll
-      for (int t = 0; t < 4; t++) {
-        const int j = j0 + t * WAVE + lane;
-        oo[t] = j < S.N ? permg[j] : -1;
-        const int ic = oo[t] >= S.n ? oo[t] - S.n : 0;
-        bo[t] = b[oo[t] >= S.n ? oo[t] : 0];
-        rr[t] = ri[ic];
-      }
+  for (int t = 0; t < TMAX; t++) {
+    const int j = t * WAVE + lane;
+    dv[t] = Fg[S.nS + (j < S.N ? j : 0)];
+    rr_[t] = S.polish ? 0.0 : ri[oo[t] >= S.n ? oo[t] - S.n : 0];
+  }
+  arrow_scatter<TG>(S, R, xs, g, jr, lane);
 #pragma unroll
-      for (int t = 0; t < 4; t++) {
-        const int j = j0 + t * WAVE + lane;
-        if (oo[t] < 0) continue;
-        if (oo[t] < S.n) b[oo[t]] = xs[j];
-        else b[oo[t]] = bo[t] + rr[t] * xs[j];
-      }
-    }
+  for (int t = 0; t < TMAX; t++) {
+    if (oo[t] < 0) continue;
+    const int j = t * WAVE + lane;
+    const bool head = j < g0 || j >= g0 + g;
+    const double xv = head ? fma(vb[t], dv[t], xs[j]) : xs[j];  // x_c = y_c Dinv_c - sum_r L(r,c) x_r
+    if (S.polish || oo[t] < S.n) b[oo[t]] = xv;
+    else b[oo[t]] = vb[t] + rr_[t] * xv;                        // qdldl_interface.c:568-579
   }
 }
 
+// Cohort staggering (G.stagger, workgroups of 8 waves = two per SIMD): with the whole batch resident every wave would
+// load at the same time and then compute at the same time.  The second half of each workgroup therefore issues its
+// loads only once the first half has all of its own in flight (one s_barrier, no memory fence), so one cohort's
+// substitution runs under the other cohort's factor stream.
 template <int TMAX, int TG>
-__global__ __launch_bounds__(256, 3) void k_arrow_admm(rldl_dev_sym S, rldl_dev_num Nn, rldl_dev_admm W, int per_wave) {
+__global__ __launch_bounds__(512, 4) void k_arrow_admm(rldl_dev_sym S, rldl_dev_num Nn, rldl_dev_admm W, ArrowGeom G) {
   extern __shared__ __attribute__((aligned(16))) double sh[];
-  const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+  const int lane = threadIdx.x & (WAVE - 1), wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wpb = blockDim.x >> 6;
   const int inst = blockIdx.x * wpb + wv;
-  if (inst >= Nn.batch) return;
+  const bool late = G.stagger && wv >= (wpb >> 1);
+  if (inst >= Nn.batch) { if (G.stagger) __builtin_amdgcn_s_barrier(); return; }
   const int st = W.status[inst];                                // latency overlaps with the index loads below
-  double *Tv = sh + (size_t)wv * per_wave;
-  double *xs = Tv + (per_wave - ((S.N + 1) & ~1) - 2);
+  long long *tr = W.trace ? W.trace + 8 * (size_t)inst : nullptr;
+  if (tr && lane == 0) { tr[0] = wall_clock64(); tr[7] = (long long)__smid(); }
+  double *Tv = sh + (size_t)wv * G.per_wave;
+  double *xs = Tv + G.xoff;
   const int *permg = S.plan + S.po_perm;
   int oo[TMAX];
 #pragma unroll
   for (int t = 0; t < TMAX; t++) { const int j = t * WAVE + lane; oo[t] = j < S.N ? permg[j] : -1; }
   const int g0 = S.arrow_g0, g = S.arrow_g;
   const int jr = lane < g ? reinterpret_cast<const unsigned short *>(S.plan + S.po_fsig)[g0 + lane] : 0;
-  if (st != ST_UNSOLVED) return;
+  if (st != ST_UNSOLVED) { if (G.stagger) __builtin_amdgcn_s_barrier(); return; }
+  if (late) __builtin_amdgcn_s_barrier();                       // second cohort: hold the loads back
   const int n = S.n, m = S.m;
   const size_t io = (size_t)inst;
   const double *Fg = Nn.F + io * S.ldF;
@@ -1282,9 +1352,10 @@ __global__ __launch_bounds__(256, 3) void k_arrow_admm(rldl_dev_sym S, rldl_dev_
   double *x = W.x + io * n, *z = W.z + io * m, *y = W.y + io * m;
   const double *q = W.q + io * n, *l = W.l + io * m, *u = W.u + io * m, *rv = W.rho_vec + io * m;
   ArrowRegs<TG> R;
-  arrow_stage(S, Fg, Tv, lane, 1);                              // coupling values first ...
+  ArrowDiag Dg;
+  arrow_stage(S, Fg, Tv, lane, 1, 0);                           // coupling values first ...
   arrow_load_idx<TG>(S, lane, R);
-  double va[TMAX], vb[TMAX], vr[TMAX], vl[TMAX], vu[TMAX], vrho[TMAX];
+  double va[TMAX], vb[TMAX], vr[TMAX];
 #pragma unroll
   for (int t = 0; t < TMAX; t++) {
     const int o = oo[t];
@@ -1292,27 +1363,46 @@ __global__ __launch_bounds__(256, 3) void k_arrow_admm(rldl_dev_sym S, rldl_dev_
     const int iv = con || o < 0 ? 0 : o, ic = con ? o - n : 0;
     const double *pa = con ? z + ic : x + iv;
     const double *pb = con ? y + ic : q + iv;
-    va[t] = *pa; vb[t] = *pb; vr[t] = ri[ic]; vl[t] = l[ic]; vu[t] = u[ic]; vrho[t] = rv[ic];
+    va[t] = *pa; vb[t] = *pb; vr[t] = ri[ic];
   }
+  arrow_load_diag(S, Fg, g0, g, G.rr, lane, Dg);
+  if (G.stagger == 2 && !late) __builtin_amdgcn_s_barrier();    // (variant 2) first-phase requests queued: the second cohort queues behind them
   wait_dma();
+  if (tr && lane == 0) tr[1] = wall_clock64();                  // coupling values + vectors have arrived
   arrow_load_val<TG>(S, Tv, lane, R);                           // ... into registers ...
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  if (!(S.dbg & 16)) arrow_stage(S, Fg, Tv, lane, 0);           // ... then the triangle + Dinv over the same LDS
+  if (!(S.dbg & 16)) arrow_stage(S, Fg, Tv, lane, 0, G.tri2);   // ... then the triangle over the same LDS
+  if (G.stagger == 1 && !late) __builtin_amdgcn_s_barrier();    // (variant 1) release the second cohort once everything is in flight
 #pragma unroll
   for (int t = 0; t < TMAX; t++) {                              // compute_rhs (auxil.c:164-178) in permuted order
     const int j = t * WAVE + lane;
     if (oo[t] >= 0) xs[j] = oo[t] < n ? W.sigma * va[t] - vb[t] : va[t] - vr[t] * vb[t];
   }
   wave_sync();                                                  // (the triangle DMA is awaited inside, behind the gather)
-  if (!(S.dbg & 32)) arrow_tri_solve<TG>(S, R, Tv, xs, g0, g, jr, lane);
+  if (tr && lane == 0) tr[2] = wall_clock64();
+  if (!(S.dbg & 32)) arrow_tri_solve<TG>(S, R, Dg, Tv, xs, g0, g, G.rr, jr, lane, tr);
   else wait_dma();
+  // bounds, rho and the head's Dinv are needed only from here on: fetched behind the sweeps, under the scatter
+  double vl[TMAX], vu[TMAX], vrho[TMAX], dv[TMAX];
+#pragma unroll
+  for (int t = 0; t < TMAX; t++) {
+    const int ic = oo[t] >= n ? oo[t] - n : 0, j = t * WAVE + lane;
+    vl[t] = l[ic]; vu[t] = u[ic]; vrho[t] = rv[ic];
+    dv[t] = Fg[S.nS + (j < S.N ? j : 0)];
+  }
+  if (!(S.dbg & 32)) arrow_scatter<TG>(S, R, xs, g, jr, lane);
+  if (tr && lane == 0) tr[5] = wall_clock64();
   const double alpha = W.alpha;
   double *dx = W.delta_x + io * n, *dy = W.delta_y + io * m;
 #pragma unroll
   for (int t = 0; t < TMAX; t++) {
-    const int o = oo[t];
+    const int o = oo[t], j = t * WAVE + lane;
     if (o < 0) continue;
-    const double s = xs[t * WAVE + lane];
+    double s = xs[j];
+    if (j < g0 || j >= g0 + g) {                               // head: x_c = y_c Dinv_c - sum_r L(r,c) x_r, y_c = rhs_c
+      const double rhs = o < n ? W.sigma * va[t] - vb[t] : va[t] - vr[t] * vb[t];
+      s = fma(rhs, dv[t], s);
+    }
     if (o < n) {
       const double xp = va[t];
       const double xn = alpha * s + (1.0 - alpha) * xp;       // update_x :188-201
@@ -1331,6 +1421,7 @@ __global__ __launch_bounds__(256, 3) void k_arrow_admm(rldl_dev_sym S, rldl_dev_
       y[i] = yi + d;
     }
   }
+  if (tr && lane == 0) tr[6] = wall_clock64();
 }
 
 }  // namespace
@@ -1429,17 +1520,35 @@ static int launch_plan_admm(const rldl_dev_sym *S, const rldl_dev_num *Nn, const
 }
 
 // ---- arrowhead kernels: geometry ----
-static int arrow_per_wave_doubles(const rldl_dev_sym *S) {
-  const int stage = S->ldF - S->nOp > S->nOp ? S->ldF - S->nOp : S->nOp;   // the two halves of the row share this buffer
-  return stage + ((S->N + 1) & ~1) + 2;
+// Per wave: staging buffer (coupling values, then the LDS part of the triangle; even length) followed by x.
+// rr = triangle rows kept in registers: the smallest count (<= ARROW_RR_MAX) that lets 16 waves share a CU's LDS,
+// else 0.  RLDL_ARROW_RR overrides (timing experiments).
+static ArrowGeom arrow_geometry_rr(const rldl_dev_sym *S, int rr) {
+  const int g = S->arrow_tb >= 0 ? S->arrow_g : 1;
+  rr = rr < 0 ? 0 : (rr > ARROW_RR_MAX ? ARROW_RR_MAX : rr);
+  if (rr > g - 1) rr = g - 1 > 0 ? g - 1 : 0;
+  const int gp = g - rr, tri = (gp * (gp - 1)) / 2, trip = (tri + 1) & ~1;
+  const int stage = trip > S->nOp ? trip : S->nOp;
+  ArrowGeom G;
+  G.rr = rr; G.tri2 = trip >> 1; G.xoff = stage; G.per_wave = stage + ((S->N + 1) & ~1); G.stagger = 0;
+  return G;
 }
-static int arrow_pick_wpb(const rldl_dev_sym *S, const void *kernel, size_t *lds_out) {
-  static const void *ck = 0; static int cl = -1, cn = -1, cbest = 0; static size_t clds = 0;
-  if (ck == kernel && cl == S->ldF && cn == S->nOp) { *lds_out = clds; return cbest; }
+static ArrowGeom arrow_geometry(const rldl_dev_sym *S) {
+  const char *force = getenv("RLDL_ARROW_RR");
+  if (force) return arrow_geometry_rr(S, atoi(force));
+  for (int rr = 0; rr <= ARROW_RR_MAX; rr++) {
+    const ArrowGeom G = arrow_geometry_rr(S, rr);
+    if (sizeof(double) * (size_t)G.per_wave * 16 <= (size_t)LDS_PER_CU) return G;
+  }
+  return arrow_geometry_rr(S, 0);
+}
+static int arrow_pick_wpb(const rldl_dev_sym *S, const void *kernel, const ArrowGeom &G, size_t *lds_out, int max_wpb = 4) {
+  static const void *ck = 0; static int cpw = -1, cbest = 0, cmax = 0; static size_t clds = 0;
+  if (ck == kernel && cpw == G.per_wave && cmax == max_wpb) { *lds_out = clds; return cbest; }
   int best = 0, best_waves = 0; size_t best_lds = 0;
   const char *force = getenv("RLDL_WPB");
-  for (int wpb = 1; wpb <= 4; wpb *= 2) {                      // kernels are compiled for at most 256 threads
-    const size_t b = sizeof(double) * (size_t)wpb * (size_t)arrow_per_wave_doubles(S);
+  for (int wpb = max_wpb == 8 ? 8 : 1; wpb <= max_wpb; wpb *= 2) {   // max_wpb == 8: the staggered launch needs exactly 8
+    const size_t b = sizeof(double) * (size_t)wpb * (size_t)G.per_wave;
     if (b > (size_t)LDS_PER_CU) continue;
     if (force && atoi(force) != wpb) continue;
     if (b > 64 * 1024 && hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b) != hipSuccess) continue;
@@ -1448,39 +1557,55 @@ static int arrow_pick_wpb(const rldl_dev_sym *S, const void *kernel, size_t *lds
     if (nb * wpb > best_waves) { best = wpb; best_waves = nb * wpb; best_lds = b; }
   }
   (void)hipGetLastError();
-  ck = kernel; cl = S->ldF; cn = S->nOp; cbest = best; clds = best_lds;
-  if (getenv("RLDL_VERBOSE")) fprintf(stderr, "[rldl] arrow kernel: wpb=%d, %d waves/CU, %zu B LDS per workgroup\n", best, best_waves, best_lds);
+  ck = kernel; cpw = G.per_wave; cbest = best; clds = best_lds; cmax = max_wpb;
+  if (getenv("RLDL_VERBOSE"))
+    fprintf(stderr, "[rldl] arrow kernel: wpb=%d, %d waves/CU, %zu B LDS per workgroup, %d triangle rows in registers\n", best, best_waves,
+            best_lds, G.rr);
   *lds_out = best_lds;
   return best;
 }
 static bool arrow_usable(const rldl_dev_sym *S) {
-  return S->plan_ok && S->arrow_ok && S->arrow_steps <= 32 && !getenv("RLDL_NO_ARROW") &&
-         sizeof(double) * (size_t)arrow_per_wave_doubles(S) <= (size_t)LDS_PER_CU;
+  return S->plan_ok && S->arrow_ok && S->arrow_steps <= 32 && S->arrow_tb <= 0 && S->arrow_g <= WAVE && S->N <= 8 * WAVE &&
+         !getenv("RLDL_NO_ARROW") && sizeof(double) * (size_t)arrow_geometry(S).per_wave <= (size_t)LDS_PER_CU;
 }
-template <int TG>
+template <int TMAX, int TG>
 static int launch_arrow_solve_t(const rldl_dev_sym *S, const rldl_dev_num *Nn, double *d_b, void *stream) {
   size_t lds = 0;
-  const int wpb = arrow_pick_wpb(S, (const void *)k_arrow_solve<TG>, &lds);
+  const ArrowGeom G = arrow_geometry(S);
+  const int wpb = arrow_pick_wpb(S, (const void *)k_arrow_solve<TMAX, TG>, G, &lds);
   if (wpb <= 0) return -1;
-  if (lds > 64 * 1024 && hipFuncSetAttribute((const void *)k_arrow_solve<TG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
-  hipLaunchKernelGGL(k_arrow_solve<TG>, dim3((Nn->batch + wpb - 1) / wpb), dim3(wpb * WAVE), lds, (hipStream_t)stream, *S, *Nn, d_b,
-                     arrow_per_wave_doubles(S));
+  if (lds > 64 * 1024 && hipFuncSetAttribute((const void *)k_arrow_solve<TMAX, TG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+  hipLaunchKernelGGL((k_arrow_solve<TMAX, TG>), dim3((Nn->batch + wpb - 1) / wpb), dim3(wpb * WAVE), lds, (hipStream_t)stream, *S, *Nn, d_b, G);
   return launch_status();
 }
+template <int TMAX>
+static int launch_arrow_solve_g(const rldl_dev_sym *S, const rldl_dev_num *Nn, double *d_b, void *stream) {
+  if (S->arrow_steps <= 8) return launch_arrow_solve_t<TMAX, 8>(S, Nn, d_b, stream);
+  if (S->arrow_steps <= 16) return launch_arrow_solve_t<TMAX, 16>(S, Nn, d_b, stream);
+  if (S->arrow_steps <= 24) return launch_arrow_solve_t<TMAX, 24>(S, Nn, d_b, stream);
+  return launch_arrow_solve_t<TMAX, 32>(S, Nn, d_b, stream);
+}
 static int launch_arrow_solve(const rldl_dev_sym *S, const rldl_dev_num *Nn, double *d_b, void *stream) {
-  if (S->arrow_steps <= 8) return launch_arrow_solve_t<8>(S, Nn, d_b, stream);
-  if (S->arrow_steps <= 16) return launch_arrow_solve_t<16>(S, Nn, d_b, stream);
-  if (S->arrow_steps <= 24) return launch_arrow_solve_t<24>(S, Nn, d_b, stream);
-  return launch_arrow_solve_t<32>(S, Nn, d_b, stream);
+  if (S->N <= 2 * WAVE) return launch_arrow_solve_g<2>(S, Nn, d_b, stream);
+  if (S->N <= 3 * WAVE) return launch_arrow_solve_g<3>(S, Nn, d_b, stream);
+  if (S->N <= 4 * WAVE) return launch_arrow_solve_g<4>(S, Nn, d_b, stream);
+  return launch_arrow_solve_g<8>(S, Nn, d_b, stream);
 }
 template <int TMAX, int TG>
 static int launch_arrow_admm_t(const rldl_dev_sym *S, const rldl_dev_num *Nn, const rldl_dev_admm *W, void *stream) {
   size_t lds = 0;
-  const int wpb = arrow_pick_wpb(S, (const void *)k_arrow_admm<TMAX, TG>, &lds);
+  ArrowGeom G = arrow_geometry(S);
+  // staggering pays when the batch fills the resident slots of the chip more than half (otherwise nothing contends)
+  static const int stagger_env = getenv("RLDL_STAGGER") ? atoi(getenv("RLDL_STAGGER")) : 0;
+  int wpb = 0;
+  if (stagger_env && Nn->batch >= 2048) {
+    wpb = arrow_pick_wpb(S, (const void *)k_arrow_admm<TMAX, TG>, G, &lds, 8);
+    if (wpb == 8) G.stagger = stagger_env;
+  }
+  if (!G.stagger) wpb = arrow_pick_wpb(S, (const void *)k_arrow_admm<TMAX, TG>, G, &lds);
   if (wpb <= 0) return -1;
   if (lds > 64 * 1024 && hipFuncSetAttribute((const void *)k_arrow_admm<TMAX, TG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
-  hipLaunchKernelGGL((k_arrow_admm<TMAX, TG>), dim3((Nn->batch + wpb - 1) / wpb), dim3(wpb * WAVE), lds, (hipStream_t)stream, *S, *Nn, *W,
-                     arrow_per_wave_doubles(S));
+  hipLaunchKernelGGL((k_arrow_admm<TMAX, TG>), dim3((Nn->batch + wpb - 1) / wpb), dim3(wpb * WAVE), lds, (hipStream_t)stream, *S, *Nn, *W, G);
   return launch_status();
 }
 template <int TMAX>

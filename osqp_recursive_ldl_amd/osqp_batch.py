@@ -118,6 +118,13 @@ class OSQPBatch:
             raise RuntimeError("time_iteration failed")
         return ms.value
 
+    def trace_iteration(self):
+        """Wave timeline of one fused-iteration launch: int64 array [batch, 8] (see include/osqp_rldl_hip.h)."""
+        out = np.zeros((self.batch, 8), np.int64)
+        if _lib.lib().osqp_batch_trace_iteration(self.h, out.ctypes.data_as(C.c_void_p)):
+            raise RuntimeError("trace_iteration failed")
+        return out
+
     def cleanup(self):
         if getattr(self, "h", None):
             _lib.lib().osqp_batch_cleanup(self.h)
