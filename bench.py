@@ -99,10 +99,10 @@ def main():
         step()
     sync()
     t0 = time.perf_counter()
-    iter_ms = []
+    loops = []
     for _ in range(args.steps):
         res = step()
-        iter_ms.append(w.time_iteration(0))                  # HIP-event average over the step's 200 launches
+        loops.append(w.last_loop())                          # HIP events around the step's ADMM loop: (ms, iterations, launches)
     sync()
     elapsed = time.perf_counter() - t0
     tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -116,8 +116,11 @@ def main():
     # algorithmic bytes per instance of one fused ADMM iteration: tri-solve + vector state
     tri_bytes = 8 * (dims["nnzL"] + 3 * N + m)
     iter_bytes = tri_bytes + 8 * (3 * n + 8 * m)
-    k_ms = float(np.mean(iter_ms))
-    achieved = iter_bytes * B / (k_ms * 1e-3) / 1e9
+    loop_ms = float(np.mean([l[0] for l in loops]))
+    n_iters, n_launches = loops[-1][1], loops[-1][2]
+    k_ms = loop_ms / n_launches                              # average duration of one launch of the dominant kernel
+    iters_per_launch = n_iters / n_launches
+    achieved = iter_bytes * B * iters_per_launch / (k_ms * 1e-3) / 1e9
     out = {
         "metric": "QP solves/sec (batch) + ADMM iters/sec, n=50 m=100 fp64 batch=4096",
         "value": value, "unit": "QP solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -129,18 +132,22 @@ def main():
                                "adaptive_rho=0, check_termination=0, scaling=0)" % (B, args.iters),
                    "batch_per_gpu": B, "n": n, "m": m, "nnzKKT": dims["nnzKKT"], "nnzL": dims["nnzL"],
                    "admm_iters": args.iters, "parallelism": "batch-sharded x%d, all-gather of results" % world},
-        "roofline": {"bound": "hbm", "kernel": "fused ADMM iteration: rhs + permuted tri-solve + x/z/y update (k_arrow_admm on arrowhead patterns, else k_plan_admm)",
+        "roofline": {"bound": "hbm", "kernel": "fused ADMM iterations: rhs + permuted tri-solve + x/z/y update (k_arrow_admm on arrowhead patterns, else k_plan_admm)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None, "bytes_per_instance": iter_bytes, "tri_solve_bytes_per_instance": tri_bytes,
-                     "kernel_ms": k_ms},
+                     "traffic": None, "bytes_per_instance_per_iteration": iter_bytes, "tri_solve_bytes_per_instance": tri_bytes,
+                     "iterations_per_launch": iters_per_launch, "kernel_ms": k_ms,
+                     "note": "achieved = SURVEY 8d algorithmic bytes of one fused iteration (which assume the factor is re-streamed "
+                             "every iteration) x instances x iterations per launch / launch duration; k_arrow_admm keeps the "
+                             "instance's factor in registers + LDS across the iterations of a launch, so a frac above what "
+                             "HBM can deliver means that re-stream is gone (see traffic)"},
     }
     # HBM traffic of the same kernel comes from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE cannot
     # be read from inside the process); it is reported only when it was measured on this very configuration
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_v4_pmc_traffic.json")))
-        if B == 4096 and pmc.get("algorithmic_bytes_per_launch") == iter_bytes * B:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_v6_pmc_traffic.json")))
+        if B == 4096 and pmc.get("algorithmic_bytes_per_launch") == iter_bytes * B * iters_per_launch:
             out["roofline"]["traffic"] = pmc["traffic_bytes_per_launch"]
-            out["roofline"]["traffic_source"] = "profiles/r1_v4_pmc_traffic.json (rocprofv3 --pmc, separate passes)"
+            out["roofline"]["traffic_source"] = "profiles/r1_v6_pmc_traffic.json (rocprofv3 --pmc, separate passes)"
     except (OSError, ValueError):
         pass
     status = res["status"]
@@ -178,8 +185,9 @@ def cpu_baseline(wl, settings, perm, budget_s):
                                          C.byref(ts))
         return tot, tf.value, ts.value
 
-    tot, _, _ = run(16, 0)                                   # calibration
-    count = int(max(64, min(20000, budget_s / max(tot / 16, 1e-6))))
+    run(16, 0)                                               # warm-up (page faults, caches)
+    tot, _, _ = run(64, 0)                                   # calibration
+    count = int(max(64, min(100000, budget_s / max(tot / 64, 1e-6))))
     tot, tf, ts = run(count, 0)
     return {"value": count / tot, "unit": "QP solves/s", "cores": 1, "kind": "port",
             "sample": "%d instances of the bench workload (setup incl. symbolic+factor, then %d ADMM iterations), "

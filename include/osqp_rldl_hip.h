@@ -160,8 +160,12 @@ c_int osqp_batch_get_iterates(osqp_batch *w, c_float **d_x, c_float **d_y, c_flo
 /* OSQPScaling (include/types.h:43-48): D[batch][n], E[batch][m], c[batch]; returns 1 when scaling is off */
 c_int osqp_batch_get_scaling(osqp_batch *w, c_float **d_D, c_float **d_E, c_float **d_c);
 rldl_batch *osqp_batch_linsys(osqp_batch *w);
-/* timing of the fused ADMM-iteration kernel (HIP events on the workspace stream), for the roofline */
+/* timing of the fused ADMM-iteration kernel (HIP events on the workspace stream), for the roofline:
+ * reps == 0: device time per ITERATION of the last solve loop; reps > 0: time `reps` single-iteration launches now */
 c_int osqp_batch_time_iteration(osqp_batch *w, c_int reps, c_float *ms_per_launch);
+/* device time of the last solve loop, the iterations it ran and in how many launch groups (one kernel launch runs a
+ * whole group of iterations when the factor can stay on chip) */
+c_int osqp_batch_last_loop(osqp_batch *w, c_float *ms, c_int *iterations, c_int *launch_groups);
 /* wave timeline of one fused-iteration launch: host_out[batch][8] int64 ticks of the 100 MHz device clock
  * (start, inputs arrived, rhs built, gather done, sweeps done, substitution done, end, CU id) */
 c_int osqp_batch_trace_iteration(osqp_batch *w, long long *host_out);

@@ -41,7 +41,8 @@ struct osqp_batch {
   int *h_tmp_i;                  /* [batch] host scratch */
   double *h_tmp_d;               /* [batch] host scratch */
   float last_loop_ms;
-  c_int last_loop_launches;
+  c_int last_loop_launches;     /* ADMM iterations run by the last solve loop ... */
+  c_int last_loop_groups;       /* ... in this many launch groups (one kernel launch each on the arrowhead path) */
 };
 
 void osqp_batch_set_default_settings(OSQPBatchSettings *s) {
@@ -217,7 +218,7 @@ static int read_active(osqp_batch *w) {
 }
 
 c_int osqp_batch_solve(osqp_batch *w) {
-  c_int iter, last_iter = 0, launches = 0;
+  c_int iter, last_iter = 0, launches = 0, groups = 0;
   int can_check = 0, nact;
   size_t B;
   hipStream_t st;
@@ -234,15 +235,25 @@ c_int osqp_batch_solve(osqp_batch *w) {
   if (!HIP_OK(hipStreamSynchronize(st))) return 1;
 
   (void)hipEventRecord((hipEvent_t)w->ev0, st);
-  for (iter = 1; iter <= w->st.max_iter; iter++) {
+  iter = 0;
+  while (iter < w->st.max_iter) {
     int do_adapt;
+    /* run straight through to the next iteration that is followed by a check, a rho adaptation or the end of the
+     * solve: nothing on the host looks at the iterates in between (osqp.c:354-519) */
+    c_int next = w->st.max_iter, k;
+    if (w->st.check_termination) { k = (iter / w->st.check_termination + 1) * w->st.check_termination; if (k < next) next = k; }
+    if (w->st.adaptive_rho && w->st.adaptive_rho_interval) {
+      k = (iter / w->st.adaptive_rho_interval + 1) * w->st.adaptive_rho_interval;
+      if (k < next) next = k;
+    }
+    /* delta_x / delta_y feed only the infeasibility tests of a check: stored by the last iteration of the group */
+    w->W.write_delta = 1;
+    if (rldl_launch_admm_iters(&w->ls->dsym, &w->ls->num, &w->W, (int)(next - iter), w->stream)) return 1;
+    launches += next - iter;
+    groups++;
+    iter = next;
     can_check = w->st.check_termination && (iter % w->st.check_termination == 0);
     do_adapt = w->st.adaptive_rho && w->st.adaptive_rho_interval && (iter % w->st.adaptive_rho_interval == 0);
-    /* delta_x / delta_y feed only the infeasibility tests of a check: store them just on those iterations
-     * (and on the last one, whose check is the tail of osqp_solve) */
-    w->W.write_delta = (can_check || do_adapt || iter == w->st.max_iter) ? 1 : 0;
-    if (rldl_launch_admm_iter(&w->ls->dsym, &w->ls->num, &w->W, w->stream)) return 1;
-    launches++;
     last_iter = iter;
     if (can_check || do_adapt) {
       if (rldl_launch_admm_check(&w->ls->dsym, &w->W, (int)iter, (can_check ? 1 : 0) | (do_adapt ? 2 : 0), 0, w->stream)) return 1;
@@ -263,6 +274,7 @@ c_int osqp_batch_solve(osqp_batch *w) {
   if (!HIP_OK(hipStreamSynchronize(st))) return 1;
   (void)hipEventElapsedTime(&w->last_loop_ms, (hipEvent_t)w->ev0, (hipEvent_t)w->ev1);
   w->last_loop_launches = launches;
+  w->last_loop_groups = groups;
   return 0;
 }
 
@@ -370,6 +382,16 @@ c_int osqp_batch_get_scaling(osqp_batch *w, c_float **d_D, c_float **d_E, c_floa
 }
 
 rldl_batch *osqp_batch_linsys(osqp_batch *w) { return w ? w->ls : 0; }
+
+/* Device time of the last solve loop (HIP events on the workspace stream around it), the ADMM iterations it ran and
+ * the number of launch groups (= kernel launches of the fused iteration kernel on the arrowhead path). */
+c_int osqp_batch_last_loop(osqp_batch *w, c_float *ms, c_int *iterations, c_int *launch_groups) {
+  if (!w || !w->last_loop_launches) return 1;
+  if (ms) *ms = (c_float)w->last_loop_ms;
+  if (iterations) *iterations = w->last_loop_launches;
+  if (launch_groups) *launch_groups = w->last_loop_groups;
+  return 0;
+}
 
 /* Wave timeline of ONE fused-iteration launch (tracing aid for the roofline work): for every instance 8 int64
  * s_memrealtime ticks (100 MHz) -- [0] wave start, [1] coupling values + vectors arrived, [2] rhs built,

@@ -1135,20 +1135,25 @@ __global__ __launch_bounds__(1024) void k_plan_admm_loop(rldl_dev_sym S, rldl_de
 
 template <int TG>
 struct ArrowRegs {
-  double v[TG];            // coupling values of this lane's row, step-major
-  unsigned ix[(TG + 1) / 2];  // packed column indices: step 2k in the low half, 2k+1 in the high half
+  double v[TG];            // coupling values of this lane's row, step-major (steps >= arrow_steps hold 0)
+};
+template <int TG>
+struct ArrowIdx {
+  unsigned ix[(TG + 1) / 2];  // packed column indices: step 2k in the low half, 2k+1 in the high half (padding: column 0)
 };
 struct ArrowDiag {
   double dtail;            // Dinv[g0 + lane]
   double row[ARROW_RR_MAX];   // L(g - rr + k, lane) for lane < g - rr + k, else 0
 };
 
-// loads issued by every live wave before its first wait
+// The index table is shared by all instances (L2-resident): it is re-read by the gather and by the scatter of every
+// iteration instead of living in 12 VGPRs across the sweeps.  `ap` is made opaque so the loads stay where they are.
 template <int TG>
-__device__ __forceinline__ void arrow_load_idx(const rldl_dev_sym &S, int lane, ArrowRegs<TG> &R) {
+__device__ __forceinline__ void arrow_load_idx(const rldl_dev_sym &S, int lane, ArrowIdx<TG> &I) {
   const unsigned *ap = reinterpret_cast<const unsigned *>(S.plan + S.po_apad);
+  asm volatile("" : "+s"(ap));
 #pragma unroll
-  for (int t2 = 0; t2 < (TG + 1) / 2; t2++) R.ix[t2] = 2 * t2 < S.arrow_steps ? ap[t2 * 64 + lane] : 0u;
+  for (int t2 = 0; t2 < (TG + 1) / 2; t2++) I.ix[t2] = 2 * t2 < S.arrow_steps ? ap[t2 * 64 + lane] : 0u;
 }
 // Dinv of the tail and the register-resident triangle rows: straight from the factor row in HBM (coalesced)
 __device__ __forceinline__ void arrow_load_diag(const rldl_dev_sym &S, const double *Fg, int g0, int g, int rr, int lane, ArrowDiag &Dg) {
@@ -1190,23 +1195,25 @@ __device__ __forceinline__ void arrow_tri_solve(const rldl_dev_sym &S, const Arr
   const int gp = g - rr;                                         // rows whose L entries live in LDS
   // ---- forward gather of the tail rows out of registers ----
   double ga = act ? xs[jr] : 0.0;
-  if (!(S.dbg & 1)) {
+  {
+    ArrowIdx<TG> I;
+    arrow_load_idx<TG>(S, lane, I);
 #pragma unroll
-    for (int t = 0; t < TG; t++)
-      if (t < S.arrow_steps) {
-        const unsigned col = (t & 1) ? R.ix[t >> 1] >> 16 : R.ix[t >> 1] & 0xffffu;
-        ga = fma(-R.v[t], xs[col], ga);
-      }
+    for (int t = 0; t < TG; t++) {                               // steps >= arrow_steps carry value 0 and column 0
+      const unsigned col = (t & 1) ? I.ix[t >> 1] >> 16 : I.ix[t >> 1] & 0xffffu;
+      ga = fma(-R.v[t], xs[col], ga);
+    }
   }
   if (act) xs[jr] = ga;
   wait_dma();                                                    // triangle (second DMA phase) streamed in behind the gather
   wave_sync();
   if (tr && lane == 0) tr[3] = wall_clock64();                   // gather done, triangle has arrived
+  const long long c0 = tr ? clock64() : 0;
   double acc = act ? xs[g0 + lane] : 0.0;
   for (int j = lane; j < S.N; j += WAVE)                         // head slots become scatter accumulators
     if (j < g0 || j >= g0 + g) xs[j] = 0.0;
   const bool tri = S.arrow_tb >= 0 && g > 1;
-  if (tri && !(S.dbg & 2)) {
+  if (tri) {
     if (gp > 1) acc = sweep_fwd<SA>(Tv, gp, lane, acc);
     if (rr > 0) {                                                // rows gp.. : y_i = b_i - sum_a L(i,a) y_a as wave reductions
       const double y = lane < gp ? acc : 0.0;
@@ -1220,7 +1227,7 @@ __device__ __forceinline__ void arrow_tri_solve(const rldl_dev_sym &S, const Arr
     }
   }
   if (act) acc *= Dg.dtail;                                      // D^-1 without leaving registers
-  if (tri && !(S.dbg & 8)) {
+  if (tri) {
 #pragma unroll
     for (int k = ARROW_RR_MAX - 1; k >= 0; k--)
       if (k < rr) {                                              // x_j -= L(i, j) x_i, i = gp + k; row[k] is 0 on lanes >= i
@@ -1230,25 +1237,20 @@ __device__ __forceinline__ void arrow_tri_solve(const rldl_dev_sym &S, const Arr
     if (gp > 1) acc = sweep_bwd<SA>(Tv, gp, lane, acc);
   }
   if (act) xs[g0 + lane] = acc;
-  if (tr && lane == 0) tr[4] = wall_clock64();                   // both sweeps done
+  if (tr && lane == 0) { tr[4] = wall_clock64(); tr[7] = (tr[7] & 0xffff) | ((clock64() - c0) << 16); }   // both sweeps done (+ shader cycles)
   wave_sync();
 }
 // ---- transposed gather: scatter L(r, c) x_r into the head columns with LDS double atomics ----
 template <int TG>
 __device__ __forceinline__ void arrow_scatter(const rldl_dev_sym &S, const ArrowRegs<TG> &R, double *xs, int g, int jr, int lane) {
-  if (!(S.dbg & 4)) {
-    const double xr = lane < g ? xs[jr] : 0.0;
-    const unsigned *ap = reinterpret_cast<const unsigned *>(S.plan + S.po_apad);   // re-read (L2) rather than held across the sweeps
-    unsigned ix[(TG + 1) / 2];
+  const double xr = lane < g ? xs[jr] : 0.0;
+  ArrowIdx<TG> I;
+  arrow_load_idx<TG>(S, lane, I);
 #pragma unroll
-    for (int t2 = 0; t2 < (TG + 1) / 2; t2++) ix[t2] = 2 * t2 < S.arrow_steps ? ap[t2 * 64 + lane] : 0u;
-#pragma unroll
-    for (int t = 0; t < TG; t++)
-      if (t < S.arrow_steps) {
-        const unsigned col = (t & 1) ? ix[t >> 1] >> 16 : ix[t >> 1] & 0xffffu;
-        const double pr = R.v[t] * xr;
-        if (R.v[t] != 0.0) unsafeAtomicAdd(&xs[col], -pr);
-      }
+  for (int t = 0; t < TG; t++) {
+    const unsigned col = (t & 1) ? I.ix[t >> 1] >> 16 : I.ix[t >> 1] & 0xffffu;
+    const double pr = R.v[t] * xr;
+    if (R.v[t] != 0.0) unsafeAtomicAdd(&xs[col], -pr);           // padding steps and lanes beyond a step's count hold 0
   }
   wave_sync();
 }
@@ -1284,7 +1286,6 @@ __global__ __launch_bounds__(256, 4) void k_arrow_solve(rldl_dev_sym S, rldl_dev
   ArrowRegs<TG> R;
   ArrowDiag Dg;
   arrow_stage(S, Fg, Tv, lane, 1, 0);                           // coupling values first ...
-  arrow_load_idx<TG>(S, lane, R);
   const int jr = lane < g ? reinterpret_cast<const unsigned short *>(S.plan + S.po_fsig)[g0 + lane] : 0;
   int oo[TMAX];
   double vb[TMAX];
@@ -1325,8 +1326,14 @@ __global__ __launch_bounds__(256, 4) void k_arrow_solve(rldl_dev_sym S, rldl_dev
 // load at the same time and then compute at the same time.  The second half of each workgroup therefore issues its
 // loads only once the first half has all of its own in flight (one s_barrier, no memory fence), so one cohort's
 // substitution runs under the other cohort's factor stream.
+//
+// `iters` ADMM iterations per launch: an instance belongs to one wave, nothing couples instances, and the whole
+// factor row of the instance sits in that wave's registers + LDS -- so the wave simply keeps going.  The factor, q
+// and the iterates are read from HBM once per launch instead of once per iteration; only l, u, rho and the head's
+// Dinv (3.2 KB, L2-resident) are re-fetched per iteration because the register file has no room for them during
+// the sweeps.  x, z, y (and delta_x / delta_y when a check follows) are stored after the last iteration.
 template <int TMAX, int TG>
-__global__ __launch_bounds__(512, 4) void k_arrow_admm(rldl_dev_sym S, rldl_dev_num Nn, rldl_dev_admm W, ArrowGeom G) {
+__global__ __launch_bounds__(512, 4) void k_arrow_admm(rldl_dev_sym S, rldl_dev_num Nn, rldl_dev_admm W, ArrowGeom G, int iters) {
   extern __shared__ __attribute__((aligned(16))) double sh[];
   const int lane = threadIdx.x & (WAVE - 1), wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wpb = blockDim.x >> 6;
   const int inst = blockIdx.x * wpb + wv;
@@ -1354,8 +1361,7 @@ __global__ __launch_bounds__(512, 4) void k_arrow_admm(rldl_dev_sym S, rldl_dev_
   ArrowRegs<TG> R;
   ArrowDiag Dg;
   arrow_stage(S, Fg, Tv, lane, 1, 0);                           // coupling values first ...
-  arrow_load_idx<TG>(S, lane, R);
-  double va[TMAX], vb[TMAX], vr[TMAX];
+  double va[TMAX], vb[TMAX];
 #pragma unroll
   for (int t = 0; t < TMAX; t++) {
     const int o = oo[t];
@@ -1363,7 +1369,7 @@ __global__ __launch_bounds__(512, 4) void k_arrow_admm(rldl_dev_sym S, rldl_dev_
     const int iv = con || o < 0 ? 0 : o, ic = con ? o - n : 0;
     const double *pa = con ? z + ic : x + iv;
     const double *pb = con ? y + ic : q + iv;
-    va[t] = *pa; vb[t] = *pb; vr[t] = ri[ic];
+    va[t] = *pa; vb[t] = *pb;
   }
   arrow_load_diag(S, Fg, g0, g, G.rr, lane, Dg);
   if (G.stagger == 2 && !late) __builtin_amdgcn_s_barrier();    // (variant 2) first-phase requests queued: the second cohort queues behind them
@@ -1371,54 +1377,80 @@ __global__ __launch_bounds__(512, 4) void k_arrow_admm(rldl_dev_sym S, rldl_dev_
   if (tr && lane == 0) tr[1] = wall_clock64();                  // coupling values + vectors have arrived
   arrow_load_val<TG>(S, Tv, lane, R);                           // ... into registers ...
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  if (!(S.dbg & 16)) arrow_stage(S, Fg, Tv, lane, 0, G.tri2);   // ... then the triangle over the same LDS
+  arrow_stage(S, Fg, Tv, lane, 0, G.tri2);                      // ... then the triangle over the same LDS
   if (G.stagger == 1 && !late) __builtin_amdgcn_s_barrier();    // (variant 1) release the second cohort once everything is in flight
-#pragma unroll
-  for (int t = 0; t < TMAX; t++) {                              // compute_rhs (auxil.c:164-178) in permuted order
-    const int j = t * WAVE + lane;
-    if (oo[t] >= 0) xs[j] = oo[t] < n ? W.sigma * va[t] - vb[t] : va[t] - vr[t] * vb[t];
-  }
-  wave_sync();                                                  // (the triangle DMA is awaited inside, behind the gather)
-  if (tr && lane == 0) tr[2] = wall_clock64();
-  if (!(S.dbg & 32)) arrow_tri_solve<TG>(S, R, Dg, Tv, xs, g0, g, G.rr, jr, lane, tr);
-  else wait_dma();
-  // bounds, rho and the head's Dinv are needed only from here on: fetched behind the sweeps, under the scatter
-  double vl[TMAX], vu[TMAX], vrho[TMAX], dv[TMAX];
-#pragma unroll
-  for (int t = 0; t < TMAX; t++) {
-    const int ic = oo[t] >= n ? oo[t] - n : 0, j = t * WAVE + lane;
-    vl[t] = l[ic]; vu[t] = u[ic]; vrho[t] = rv[ic];
-    dv[t] = Fg[S.nS + (j < S.N ? j : 0)];
-  }
-  if (!(S.dbg & 32)) arrow_scatter<TG>(S, R, xs, g, jr, lane);
-  if (tr && lane == 0) tr[5] = wall_clock64();
   const double alpha = W.alpha;
   double *dx = W.delta_x + io * n, *dy = W.delta_y + io * m;
+#pragma clang loop unroll(disable)
+  for (int it = 0; it < iters; it++) {
+    const bool last = it + 1 == iters;
+    // keep the per-lane index data opaque per iteration: otherwise every LDS / global address derived from it is
+    // hoisted out of the loop and the 24 gather addresses alone cost 24 VGPRs of the 128 a wave may hold
+    int ln = lane;                                              // (same for everything derived from the lane id)
+    asm volatile("" : "+v"(ln));
 #pragma unroll
-  for (int t = 0; t < TMAX; t++) {
-    const int o = oo[t], j = t * WAVE + lane;
-    if (o < 0) continue;
-    double s = xs[j];
-    if (j < g0 || j >= g0 + g) {                               // head: x_c = y_c Dinv_c - sum_r L(r,c) x_r, y_c = rhs_c
-      const double rhs = o < n ? W.sigma * va[t] - vb[t] : va[t] - vr[t] * vb[t];
-      s = fma(rhs, dv[t], s);
+    for (int t = 0; t < TMAX; t++) asm volatile("" : "+v"(oo[t]));
+#pragma unroll
+    for (int t = 0; t < TG; t++) asm volatile("" : "+v"(R.v[t]));
+    {
+      // rho_inv, l, u, rho and the head's Dinv are constant over the launch but are re-read (L2) where they are used:
+      // the 128 registers of a wave cannot hold them across the sweeps next to the coupling values
+      const double *rip = ri;
+      asm volatile("" : "+s"(rip));
+      double vr[TMAX];
+#pragma unroll
+      for (int t = 0; t < TMAX; t++) vr[t] = rip[oo[t] >= n ? oo[t] - n : 0];
+#pragma unroll
+      for (int t = 0; t < TMAX; t++) {                          // compute_rhs (auxil.c:164-178) in permuted order
+        const int j = t * WAVE + ln;
+        if (oo[t] >= 0) xs[j] = oo[t] < n ? W.sigma * va[t] - vb[t] : va[t] - vr[t] * vb[t];
+      }
     }
-    if (o < n) {
-      const double xp = va[t];
-      const double xn = alpha * s + (1.0 - alpha) * xp;       // update_x :188-201
-      x[o] = xn;
-      if (W.write_delta) dx[o] = xn - xp;
-    } else {
-      const int i = o - n;
-      const double zp = va[t], yi = vb[t], r = vr[t];
-      const double zt = (zp - r * yi) + r * s;                 // z_tilde, qdldl_interface.c:577-579
-      const double mix = alpha * zt + (1.0 - alpha) * zp;
-      double zn = mix + r * yi;                                // update_z :203-215
-      zn = fmin(fmax(zn, vl[t]), vu[t]);                       // project, proj.c:4-14
-      const double d = vrho[t] * (mix - zn);                   // update_y :217-228
-      z[i] = zn;
-      if (W.write_delta) dy[i] = d;
-      y[i] = yi + d;
+    wave_sync();                                                // (the triangle DMA is awaited inside, behind the gather)
+    if (tr && ln == 0 && it == 0) tr[2] = wall_clock64();
+    arrow_tri_solve<TG>(S, R, Dg, Tv, xs, g0, g, G.rr, jr, ln, it == 0 ? tr : nullptr);
+    // bounds, rho and the head's Dinv are needed only from here on: fetched behind the sweeps, under the scatter
+    double vl[TMAX], vu[TMAX], vrho[TMAX], dv[TMAX], vr[TMAX];
+#pragma unroll
+    for (int t = 0; t < TMAX; t++) {
+      const int ic = oo[t] >= n ? oo[t] - n : 0, j = t * WAVE + ln;
+      vl[t] = l[ic]; vu[t] = u[ic]; vrho[t] = rv[ic]; vr[t] = ri[ic];
+      dv[t] = Fg[S.nS + (j < S.N ? j : 0)];
+    }
+    arrow_scatter<TG>(S, R, xs, g, jr, ln);
+    if (tr && ln == 0 && it == 0) tr[5] = wall_clock64();
+#pragma unroll
+    for (int t = 0; t < TMAX; t++) {
+      const int o = oo[t], j = t * WAVE + ln;
+      if (o < 0) continue;
+      double sv = xs[j];
+      if (j < g0 || j >= g0 + g) {                             // head: x_c = y_c Dinv_c - sum_r L(r,c) x_r, y_c = rhs_c
+        const double rhs = o < n ? W.sigma * va[t] - vb[t] : va[t] - vr[t] * vb[t];
+        sv = fma(rhs, dv[t], sv);
+      }
+      if (o < n) {
+        const double xp = va[t];
+        const double xn = alpha * sv + (1.0 - alpha) * xp;    // update_x :188-201
+        va[t] = xn;
+        if (last) {
+          x[o] = xn;
+          if (W.write_delta) dx[o] = xn - xp;
+        }
+      } else {
+        const int i = o - n;
+        const double zp = va[t], yi = vb[t], r = vr[t];
+        const double zt = (zp - r * yi) + r * sv;              // z_tilde, qdldl_interface.c:577-579
+        const double mix = alpha * zt + (1.0 - alpha) * zp;
+        double zn = mix + r * yi;                              // update_z :203-215
+        zn = fmin(fmax(zn, vl[t]), vu[t]);                     // project, proj.c:4-14
+        const double d = vrho[t] * (mix - zn);                 // update_y :217-228
+        va[t] = zn; vb[t] = yi + d;
+        if (last) {
+          z[i] = zn;
+          if (W.write_delta) dy[i] = d;
+          y[i] = yi + d;
+        }
+      }
     }
   }
   if (tr && lane == 0) tr[6] = wall_clock64();
@@ -1592,7 +1624,7 @@ static int launch_arrow_solve(const rldl_dev_sym *S, const rldl_dev_num *Nn, dou
   return launch_arrow_solve_g<8>(S, Nn, d_b, stream);
 }
 template <int TMAX, int TG>
-static int launch_arrow_admm_t(const rldl_dev_sym *S, const rldl_dev_num *Nn, const rldl_dev_admm *W, void *stream) {
+static int launch_arrow_admm_t(const rldl_dev_sym *S, const rldl_dev_num *Nn, const rldl_dev_admm *W, int iters, void *stream) {
   size_t lds = 0;
   ArrowGeom G = arrow_geometry(S);
   // staggering pays when the batch fills the resident slots of the chip more than half (otherwise nothing contends)
@@ -1605,21 +1637,21 @@ static int launch_arrow_admm_t(const rldl_dev_sym *S, const rldl_dev_num *Nn, co
   if (!G.stagger) wpb = arrow_pick_wpb(S, (const void *)k_arrow_admm<TMAX, TG>, G, &lds);
   if (wpb <= 0) return -1;
   if (lds > 64 * 1024 && hipFuncSetAttribute((const void *)k_arrow_admm<TMAX, TG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
-  hipLaunchKernelGGL((k_arrow_admm<TMAX, TG>), dim3((Nn->batch + wpb - 1) / wpb), dim3(wpb * WAVE), lds, (hipStream_t)stream, *S, *Nn, *W, G);
+  hipLaunchKernelGGL((k_arrow_admm<TMAX, TG>), dim3((Nn->batch + wpb - 1) / wpb), dim3(wpb * WAVE), lds, (hipStream_t)stream, *S, *Nn, *W, G, iters);
   return launch_status();
 }
 template <int TMAX>
-static int launch_arrow_admm_g(const rldl_dev_sym *S, const rldl_dev_num *Nn, const rldl_dev_admm *W, void *stream) {
-  if (S->arrow_steps <= 8) return launch_arrow_admm_t<TMAX, 8>(S, Nn, W, stream);
-  if (S->arrow_steps <= 16) return launch_arrow_admm_t<TMAX, 16>(S, Nn, W, stream);
-  if (S->arrow_steps <= 24) return launch_arrow_admm_t<TMAX, 24>(S, Nn, W, stream);
-  return launch_arrow_admm_t<TMAX, 32>(S, Nn, W, stream);
+static int launch_arrow_admm_g(const rldl_dev_sym *S, const rldl_dev_num *Nn, const rldl_dev_admm *W, int iters, void *stream) {
+  if (S->arrow_steps <= 8) return launch_arrow_admm_t<TMAX, 8>(S, Nn, W, iters, stream);
+  if (S->arrow_steps <= 16) return launch_arrow_admm_t<TMAX, 16>(S, Nn, W, iters, stream);
+  if (S->arrow_steps <= 24) return launch_arrow_admm_t<TMAX, 24>(S, Nn, W, iters, stream);
+  return launch_arrow_admm_t<TMAX, 32>(S, Nn, W, iters, stream);
 }
-static int launch_arrow_admm(const rldl_dev_sym *S, const rldl_dev_num *Nn, const rldl_dev_admm *W, void *stream) {
-  if (S->N <= 2 * WAVE) return launch_arrow_admm_g<2>(S, Nn, W, stream);
-  if (S->N <= 3 * WAVE) return launch_arrow_admm_g<3>(S, Nn, W, stream);
-  if (S->N <= 4 * WAVE) return launch_arrow_admm_g<4>(S, Nn, W, stream);
-  return launch_arrow_admm_g<8>(S, Nn, W, stream);
+static int launch_arrow_admm(const rldl_dev_sym *S, const rldl_dev_num *Nn, const rldl_dev_admm *W, int iters, void *stream) {
+  if (S->N <= 2 * WAVE) return launch_arrow_admm_g<2>(S, Nn, W, iters, stream);
+  if (S->N <= 3 * WAVE) return launch_arrow_admm_g<3>(S, Nn, W, iters, stream);
+  if (S->N <= 4 * WAVE) return launch_arrow_admm_g<4>(S, Nn, W, iters, stream);
+  return launch_arrow_admm_g<8>(S, Nn, W, iters, stream);
 }
 
 extern "C" int rldl_launch_kkt_assemble(const rldl_dev_sym *S, const rldl_dev_num *Nn, const double *d_Px,
@@ -1663,9 +1695,32 @@ extern "C" int rldl_launch_solve(const rldl_dev_sym *S, const rldl_dev_num *Nn, 
   return launch_status();
 }
 
+// `iters` ADMM iterations of every active instance.  The arrowhead kernel runs them inside one launch with the factor
+// kept on chip; the other kernels are launched once per iteration (W->write_delta applies to the last one).
+extern "C" int rldl_launch_admm_iters(const rldl_dev_sym *S, const rldl_dev_num *Nn, const rldl_dev_admm *W, int iters, void *stream) {
+  if (Nn->batch <= 0 || iters <= 0) return 0;
+  static const int one = getenv("RLDL_ITERS_PER_LAUNCH") ? atoi(getenv("RLDL_ITERS_PER_LAUNCH")) : 0;   // timing experiments
+  if (arrow_usable(S) && S->N <= 8 * WAVE) {
+    if (one <= 0) return launch_arrow_admm(S, Nn, W, iters, stream);
+    rldl_dev_admm Wi = *W;
+    for (int done = 0; done < iters; done += one) {
+      const int k = iters - done < one ? iters - done : one;
+      Wi.write_delta = done + k == iters ? W->write_delta : 0;
+      if (launch_arrow_admm(S, Nn, &Wi, k, stream)) return -1;
+    }
+    return 0;
+  }
+  rldl_dev_admm Wi = *W;
+  for (int k = 0; k < iters; k++) {
+    Wi.write_delta = k + 1 == iters ? W->write_delta : 0;
+    if (rldl_launch_admm_iter(S, Nn, &Wi, stream)) return -1;
+  }
+  return 0;
+}
+
 extern "C" int rldl_launch_admm_iter(const rldl_dev_sym *S, const rldl_dev_num *Nn, const rldl_dev_admm *W, void *stream) {
   if (Nn->batch <= 0) return 0;
-  if (arrow_usable(S) && S->N <= 8 * WAVE) return launch_arrow_admm(S, Nn, W, stream);
+  if (arrow_usable(S) && S->N <= 8 * WAVE) return launch_arrow_admm(S, Nn, W, 1, stream);
   if (plan_admm_usable(S)) return launch_plan_admm(S, Nn, W, stream);
   const size_t lds = sizeof(double) * (size_t)(S->nS + S->N);
   if (lds <= RLDL_LDS_LIMIT)

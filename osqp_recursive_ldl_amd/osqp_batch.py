@@ -118,6 +118,13 @@ class OSQPBatch:
             raise RuntimeError("time_iteration failed")
         return ms.value
 
+    def last_loop(self):
+        """(device ms of the last solve loop, ADMM iterations it ran, launch groups)."""
+        ms, it, gr = _lib.c_float(0), _lib.c_int(0), _lib.c_int(0)
+        if _lib.lib().osqp_batch_last_loop(self.h, C.byref(ms), C.byref(it), C.byref(gr)):
+            raise RuntimeError("no solve loop has run")
+        return ms.value, int(it.value), int(gr.value)
+
     def trace_iteration(self):
         """Wave timeline of one fused-iteration launch: int64 array [batch, 8] (see include/osqp_rldl_hip.h)."""
         out = np.zeros((self.batch, 8), np.int64)

@@ -31,13 +31,15 @@ ph = {nm: float(np.mean((tr[:, k + 1] - tr[:, k]) * tk)) for k, nm in enumerate(
 ph_p90 = {nm: float(np.percentile((tr[:, k + 1] - tr[:, k]) * tk, 90)) for k, nm in enumerate(names)}
 life = end - start
 hist, edges = np.histogram(start, bins=12)
-cu = tr[:, 7]
+cu = tr[:, 7] & 0xffff
+sweep_cycles = tr[:, 7] >> 16
 out = dict(batch=B, us_per_launch=1e3 * ms, span_us=float(end.max()), mean_phase_us=ph, p90_phase_us=ph_p90,
            wave_life_us=dict(mean=float(life.mean()), p10=float(np.percentile(life, 10)), p90=float(np.percentile(life, 90))),
            start_hist=dict(counts=hist.tolist(), edges_us=[round(float(e), 2) for e in edges]),
            late_starts=int((start > 0.25 * end.max()).sum()), distinct_cu_ids=int(len(np.unique(cu))),
            waves_per_cu=dict(min=int(np.bincount(cu - cu.min()).min()), max=int(np.bincount(cu - cu.min()).max())),
-           end_hist=np.histogram(end, bins=12)[0].tolist())
+           end_hist=np.histogram(end, bins=12)[0].tolist(),
+           sweep_cycles_mean=float(sweep_cycles.mean()), sweep_clock_GHz=float(sweep_cycles.mean() / (np.mean(tr[:, 4] - tr[:, 3]) * 10.0)))
 if os.environ.get("TRACE_DUMP"):
     np.save(os.environ["TRACE_DUMP"], tr)
 print(json.dumps(out))
