@@ -166,9 +166,9 @@ c_int osqp_batch_time_iteration(osqp_batch *w, c_int reps, c_float *ms_per_launc
 /* device time of the last solve loop, the iterations it ran and in how many launch groups (one kernel launch runs a
  * whole group of iterations when the factor can stay on chip) */
 c_int osqp_batch_last_loop(osqp_batch *w, c_float *ms, c_int *iterations, c_int *launch_groups);
-/* wave timeline of one fused-iteration launch: host_out[batch][8] int64 ticks of the 100 MHz device clock
- * (start, inputs arrived, rhs built, gather done, sweeps done, substitution done, end, CU id) */
-c_int osqp_batch_trace_iteration(osqp_batch *w, long long *host_out);
+/* wave timeline of one launch of `iters` fused iterations: host_out[batch][8] int64 ticks of the 100 MHz device clock;
+ * slots 0..6 = last iteration (start, rhs, gather, forward sweep, backward sweep, scatter, update), slot 7 = wave start */
+c_int osqp_batch_trace_iteration(osqp_batch *w, c_int iters, long long *host_out);
 void  osqp_batch_cleanup(osqp_batch *w);                                /* osqp.c:646-744 */
 
 /* =====================================================================================

@@ -142,7 +142,7 @@ def _declare(L):
     L.osqp_batch_time_iteration.restype = c_int
     L.osqp_batch_last_loop.argtypes = [VP, FP, IP, IP]
     L.osqp_batch_last_loop.restype = c_int
-    L.osqp_batch_trace_iteration.argtypes = [VP, VP]
+    L.osqp_batch_trace_iteration.argtypes = [VP, c_int, VP]
     L.osqp_batch_trace_iteration.restype = c_int
     L.osqp_batch_cleanup.argtypes = [VP]
     L.osqp_batch_cleanup.restype = None

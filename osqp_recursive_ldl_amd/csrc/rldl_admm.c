@@ -393,11 +393,12 @@ c_int osqp_batch_last_loop(osqp_batch *w, c_float *ms, c_int *iterations, c_int 
   return 0;
 }
 
-/* Wave timeline of ONE fused-iteration launch (tracing aid for the roofline work): for every instance 8 int64
- * s_memrealtime ticks (100 MHz) -- [0] wave start, [1] coupling values + vectors arrived, [2] rhs built,
- * [3] forward gather done and triangle arrived, [4] sweeps done, [5] substitution done, [6] wave end, [7] CU id.
- * Only the arrowhead kernel is instrumented; other kernels leave the buffer zero.  Advances the iterates. */
-c_int osqp_batch_trace_iteration(osqp_batch *w, long long *host_out) {
+/* Wave timeline of one launch of `iters` fused iterations (tracing aid for the roofline work): for every instance 8
+ * int64 s_memrealtime ticks (100 MHz).  Slots 0..6 belong to the LAST iteration of the launch: [0] iteration start,
+ * [1] rhs in LDS, [2] forward gather done, [3] forward sweep done, [4] backward sweep done, [5] scatter done,
+ * [6] x/z/y update done; [7] wave start.  Only the arrowhead kernel is instrumented; other kernels leave the buffer
+ * zero.  Advances the iterates. */
+c_int osqp_batch_trace_iteration(osqp_batch *w, c_int iters, long long *host_out) {
   long long *d = 0;
   size_t bytes;
   c_int rc = 1;
@@ -406,7 +407,7 @@ c_int osqp_batch_trace_iteration(osqp_batch *w, long long *host_out) {
   if (!HIP_OK(hipMalloc((void **)&d, bytes))) return RLDL_MEM_ALLOC_ERROR;
   if (HIP_OK(hipMemsetAsync(d, 0, bytes, (hipStream_t)w->stream)) && !fill_int(w, w->W.status, ST_UNSOLVED)) {
     w->W.trace = d; w->W.write_delta = 0;
-    rc = rldl_launch_admm_iter(&w->ls->dsym, &w->ls->num, &w->W, w->stream) ? 1 : 0;
+    rc = rldl_launch_admm_iters(&w->ls->dsym, &w->ls->num, &w->W, (int)(iters > 0 ? iters : 1), w->stream) ? 1 : 0;
     w->W.trace = 0;
     if (!rc && !(HIP_OK(hipMemcpyAsync(host_out, d, bytes, hipMemcpyDeviceToHost, (hipStream_t)w->stream)) &&
                  HIP_OK(hipStreamSynchronize((hipStream_t)w->stream)))) rc = 1;

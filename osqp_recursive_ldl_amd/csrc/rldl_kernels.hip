@@ -1150,8 +1150,9 @@ struct ArrowDiag {
 // iteration instead of living in 12 VGPRs across the sweeps.  `ap` is made opaque so the loads stay where they are.
 template <int TG>
 __device__ __forceinline__ void arrow_load_idx(const rldl_dev_sym &S, int lane, ArrowIdx<TG> &I) {
-  const unsigned *ap = reinterpret_cast<const unsigned *>(S.plan + S.po_apad);
-  asm volatile("" : "+s"(ap));
+  int off = S.po_apad;                                           // (opaque offset, not pointer: the loads stay global_load)
+  asm volatile("" : "+s"(off));
+  const unsigned *ap = reinterpret_cast<const unsigned *>(S.plan + off);
 #pragma unroll
   for (int t2 = 0; t2 < (TG + 1) / 2; t2++) I.ix[t2] = 2 * t2 < S.arrow_steps ? ap[t2 * 64 + lane] : 0u;
 }
@@ -1207,8 +1208,7 @@ __device__ __forceinline__ void arrow_tri_solve(const rldl_dev_sym &S, const Arr
   if (act) xs[jr] = ga;
   wait_dma();                                                    // triangle (second DMA phase) streamed in behind the gather
   wave_sync();
-  if (tr && lane == 0) tr[3] = wall_clock64();                   // gather done, triangle has arrived
-  const long long c0 = tr ? clock64() : 0;
+  if (tr && lane == 0) tr[2] = wall_clock64();                   // gather done (first iteration: triangle has arrived)
   double acc = act ? xs[g0 + lane] : 0.0;
   for (int j = lane; j < S.N; j += WAVE)                         // head slots become scatter accumulators
     if (j < g0 || j >= g0 + g) xs[j] = 0.0;
@@ -1226,6 +1226,7 @@ __device__ __forceinline__ void arrow_tri_solve(const rldl_dev_sym &S, const Arr
       }
     }
   }
+  if (tr && lane == 0) tr[3] = wall_clock64();                   // forward sweep + register rows done
   if (act) acc *= Dg.dtail;                                      // D^-1 without leaving registers
   if (tri) {
 #pragma unroll
@@ -1237,7 +1238,7 @@ __device__ __forceinline__ void arrow_tri_solve(const rldl_dev_sym &S, const Arr
     if (gp > 1) acc = sweep_bwd<SA>(Tv, gp, lane, acc);
   }
   if (act) xs[g0 + lane] = acc;
-  if (tr && lane == 0) { tr[4] = wall_clock64(); tr[7] = (tr[7] & 0xffff) | ((clock64() - c0) << 16); }   // both sweeps done (+ shader cycles)
+  if (tr && lane == 0) tr[4] = wall_clock64();                   // backward sweep done
   wave_sync();
 }
 // ---- transposed gather: scatter L(r, c) x_r into the head columns with LDS double atomics ----
@@ -1341,7 +1342,7 @@ __global__ __launch_bounds__(512, 4) void k_arrow_admm(rldl_dev_sym S, rldl_dev_
   if (inst >= Nn.batch) { if (G.stagger) __builtin_amdgcn_s_barrier(); return; }
   const int st = W.status[inst];                                // latency overlaps with the index loads below
   long long *tr = W.trace ? W.trace + 8 * (size_t)inst : nullptr;
-  if (tr && lane == 0) { tr[0] = wall_clock64(); tr[7] = (long long)__smid(); }
+  if (tr && lane == 0) tr[7] = wall_clock64();                  // wave start; slots 0..6 belong to the LAST iteration of the launch
   double *Tv = sh + (size_t)wv * G.per_wave;
   double *xs = Tv + G.xoff;
   const int *permg = S.plan + S.po_perm;
@@ -1374,7 +1375,6 @@ __global__ __launch_bounds__(512, 4) void k_arrow_admm(rldl_dev_sym S, rldl_dev_
   arrow_load_diag(S, Fg, g0, g, G.rr, lane, Dg);
   if (G.stagger == 2 && !late) __builtin_amdgcn_s_barrier();    // (variant 2) first-phase requests queued: the second cohort queues behind them
   wait_dma();
-  if (tr && lane == 0) tr[1] = wall_clock64();                  // coupling values + vectors have arrived
   arrow_load_val<TG>(S, Tv, lane, R);                           // ... into registers ...
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   arrow_stage(S, Fg, Tv, lane, 0, G.tri2);                      // ... then the triangle over the same LDS
@@ -1384,6 +1384,7 @@ __global__ __launch_bounds__(512, 4) void k_arrow_admm(rldl_dev_sym S, rldl_dev_
 #pragma clang loop unroll(disable)
   for (int it = 0; it < iters; it++) {
     const bool last = it + 1 == iters;
+    if (tr && lane == 0 && last) tr[0] = wall_clock64();
     // keep the per-lane index data opaque per iteration: otherwise every LDS / global address derived from it is
     // hoisted out of the loop and the 24 gather addresses alone cost 24 VGPRs of the 128 a wave may hold
     int ln = lane;                                              // (same for everything derived from the lane id)
@@ -1395,8 +1396,9 @@ __global__ __launch_bounds__(512, 4) void k_arrow_admm(rldl_dev_sym S, rldl_dev_
     {
       // rho_inv, l, u, rho and the head's Dinv are constant over the launch but are re-read (L2) where they are used:
       // the 128 registers of a wave cannot hold them across the sweeps next to the coupling values
-      const double *rip = ri;
-      asm volatile("" : "+s"(rip));
+      int zero = 0;
+      asm volatile("" : "+s"(zero));
+      const double *rip = ri + zero;
       double vr[TMAX];
 #pragma unroll
       for (int t = 0; t < TMAX; t++) vr[t] = rip[oo[t] >= n ? oo[t] - n : 0];
@@ -1407,8 +1409,8 @@ __global__ __launch_bounds__(512, 4) void k_arrow_admm(rldl_dev_sym S, rldl_dev_
       }
     }
     wave_sync();                                                // (the triangle DMA is awaited inside, behind the gather)
-    if (tr && ln == 0 && it == 0) tr[2] = wall_clock64();
-    arrow_tri_solve<TG>(S, R, Dg, Tv, xs, g0, g, G.rr, jr, ln, it == 0 ? tr : nullptr);
+    if (tr && ln == 0 && last) tr[1] = wall_clock64();          // rhs in LDS
+    arrow_tri_solve<TG>(S, R, Dg, Tv, xs, g0, g, G.rr, jr, ln, last ? tr : nullptr);
     // bounds, rho and the head's Dinv are needed only from here on: fetched behind the sweeps, under the scatter
     double vl[TMAX], vu[TMAX], vrho[TMAX], dv[TMAX], vr[TMAX];
 #pragma unroll
@@ -1418,7 +1420,7 @@ __global__ __launch_bounds__(512, 4) void k_arrow_admm(rldl_dev_sym S, rldl_dev_
       dv[t] = Fg[S.nS + (j < S.N ? j : 0)];
     }
     arrow_scatter<TG>(S, R, xs, g, jr, ln);
-    if (tr && ln == 0 && it == 0) tr[5] = wall_clock64();
+    if (tr && ln == 0 && last) tr[5] = wall_clock64();          // scatter done
 #pragma unroll
     for (int t = 0; t < TMAX; t++) {
       const int o = oo[t], j = t * WAVE + ln;

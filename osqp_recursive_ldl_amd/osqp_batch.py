@@ -125,10 +125,10 @@ class OSQPBatch:
             raise RuntimeError("no solve loop has run")
         return ms.value, int(it.value), int(gr.value)
 
-    def trace_iteration(self):
-        """Wave timeline of one fused-iteration launch: int64 array [batch, 8] (see include/osqp_rldl_hip.h)."""
+    def trace_iteration(self, iters=1):
+        """Wave timeline of one launch of `iters` fused iterations: int64 array [batch, 8] (see include/osqp_rldl_hip.h)."""
         out = np.zeros((self.batch, 8), np.int64)
-        if _lib.lib().osqp_batch_trace_iteration(self.h, out.ctypes.data_as(C.c_void_p)):
+        if _lib.lib().osqp_batch_trace_iteration(self.h, int(iters), out.ctypes.data_as(C.c_void_p)):
             raise RuntimeError("trace_iteration failed")
         return out
 
