@@ -407,6 +407,7 @@ c_int osqp_batch_trace_iteration(osqp_batch *w, c_int iters, long long *host_out
   if (!HIP_OK(hipMalloc((void **)&d, bytes))) return RLDL_MEM_ALLOC_ERROR;
   if (HIP_OK(hipMemsetAsync(d, 0, bytes, (hipStream_t)w->stream)) && !fill_int(w, w->W.status, ST_UNSOLVED)) {
     w->W.trace = d; w->W.write_delta = 0;
+    w->W.trace_iter = getenv("RLDL_TRACE_ITER") ? atoi(getenv("RLDL_TRACE_ITER")) : -1;
     rc = rldl_launch_admm_iters(&w->ls->dsym, &w->ls->num, &w->W, (int)(iters > 0 ? iters : 1), w->stream) ? 1 : 0;
     w->W.trace = 0;
     if (!rc && !(HIP_OK(hipMemcpyAsync(host_out, d, bytes, hipMemcpyDeviceToHost, (hipStream_t)w->stream)) &&

@@ -65,14 +65,21 @@ static int upload_symbolic(rldl_batch *h) {
   D->po_gToff = s->po_gToff; D->po_fsp = s->po_fsp; D->po_bsp = s->po_bsp; D->po_acol = s->po_acol; D->po_aoff = s->po_aoff;
   D->po_arow = s->po_arow; D->po_coloff = s->po_coloff; D->po_fsb = s->po_fsb; D->po_fsc = s->po_fsc; D->po_bsb = s->po_bsb;
   D->po_bsc = s->po_bsc; D->po_fsig = s->po_fsig; D->po_bsig = s->po_bsig; D->po_fcol = s->po_fcol; D->po_brs = s->po_brs;
-  D->po_perm = s->po_perm; D->po_apad = s->po_apad; D->nOp = s->nOp;
+  D->po_perm = s->po_perm; D->po_avmap = s->po_avmap; D->po_avcol = s->po_avcol; D->po_avrow = s->po_avrow; D->nOp = s->nOp;
   D->arrow_ok = s->plan_ok ? s->arrow_ok : 0; D->arrow_group = s->arrow_group; D->arrow_steps = s->arrow_steps;
+  D->arrow_vsteps = s->arrow_vsteps; D->arrow_vrows = s->arrow_vrows;
   if (D->arrow_ok) {
-    int t, f0 = s->plan[s->po_fsp + s->arrow_group];
+    int t, l;
     D->arrow_g0 = s->plan[s->po_gstart + s->arrow_group];
     D->arrow_g = s->plan[s->po_gstart + s->arrow_group + 1] - D->arrow_g0;
     D->arrow_tb = s->plan[s->po_gflag + s->arrow_group] ? s->plan[s->po_gToff + s->arrow_group] - s->nOp : -1;
-    for (t = 0; t < s->arrow_steps && t < 32; t++) { D->arrow_base[t] = s->plan[s->po_fsb + f0 + t]; D->arrow_cnt[t] = s->plan[s->po_fsc + f0 + t]; }
+    for (t = 0; t < 32; t++) {                                /* lanes whose virtual row has an entry at step t */
+      const unsigned *vm = (const unsigned *)(s->plan + s->po_avmap);
+      D->arrow_cnt[t] = 0;
+      if (t < s->arrow_vsteps)
+        for (l = 0; l < 64; l++)
+          if (((vm[(t >> 1) * 64 + l] >> (16 * (t & 1))) & 0xffffu) != 0xffffu) D->arrow_cnt[t]++;
+    }
   }
 #undef UP
   return ok ? 0 : -1;
@@ -242,11 +249,13 @@ c_int rldl_plan_export(const csc *P, const csc *A, c_int polish, const c_int *pe
   c_int i;
   if (!P || !A || !meta) return 1;
   if (rldl_symbolic_create(&s, P->n, A->m, P->p, P->i, A->p, A->i, polish != 0, perm_in)) return RLDL_LINSYS_SOLVER_INIT_ERROR;
-  for (i = 0; i < 24; i++) meta[i] = 0;
+  for (i = 0; i < 32; i++) meta[i] = 0;
   meta[0] = s->plan_ok; meta[1] = s->nS; meta[2] = s->nO; meta[3] = s->ngroups; meta[4] = s->plan_ok ? s->plan_words : 0;
   meta[5] = s->po_gstart; meta[6] = s->po_gflag; meta[7] = s->po_gToff; meta[8] = s->po_fsp; meta[9] = s->po_bsp;
   meta[10] = s->po_fsb; meta[11] = s->po_fsc; meta[12] = s->po_bsb; meta[13] = s->po_bsc; meta[14] = s->po_fsig;
   meta[15] = s->po_bsig; meta[16] = s->po_fcol; meta[17] = s->po_brs; meta[18] = s->po_perm; meta[19] = s->N; meta[20] = s->nnzL;
+  meta[21] = s->plan_ok ? s->arrow_ok : 0; meta[22] = s->arrow_group; meta[23] = s->arrow_vsteps; meta[24] = s->arrow_vrows;
+  meta[25] = s->po_avmap; meta[26] = s->po_avcol; meta[27] = s->po_avrow; meta[28] = s->nOp;
   if (blob && s->plan_ok && blob_cap >= s->plan_words) memcpy(blob, s->plan, sizeof(int) * (size_t)s->plan_words);
   if (LtoS) for (i = 0; i < s->nnzL; i++) LtoS[i] = s->LtoS[i];
   rldl_symbolic_free(s);

@@ -27,12 +27,13 @@ typedef struct {
   int dbg;                     /* timing experiments only (env RLDL_DBG): bit mask of phases to skip; 0 in production */
   int ldF;                     /* row stride of rldl_dev_num.F in doubles: nS + N rounded up to even (16-byte rows) */
   int po_gstart, po_gflag, po_gaptr, po_grptr, po_gToff, po_fsp, po_bsp, po_acol, po_aoff, po_arow, po_coloff, po_fsb,
-      po_fsc, po_bsb, po_bsc, po_fsig, po_bsig, po_fcol, po_brs, po_perm, po_apad;
+      po_fsc, po_bsb, po_bsc, po_fsig, po_bsig, po_fcol, po_brs, po_perm, po_avmap, po_avcol, po_avrow;
   int nOp;                     /* nO rounded up to even: first triangle slot */
   int arrow_ok, arrow_group, arrow_steps; /* arrowhead specialisation (see rldl_plan.c) */
+  int arrow_vsteps, arrow_vrows;          /* virtual rows: coupling rows cut into pieces of <= vsteps entries, one piece per lane */
   int arrow_g0, arrow_g;       /* index range of the tail group */
   int arrow_tb;                /* its triangle base relative to slot nOp, or -1 */
-  int arrow_base[32], arrow_cnt[32]; /* per gather step: first slot and lane count (ride in the kernarg segment -> scalar loads) */
+  int arrow_cnt[32];           /* per virtual-row step: number of lanes with an entry (kernarg segment -> scalar loads) */
 } rldl_dev_sym;
 
 /* per-batch numeric state of the linear-system backend (DEVICE pointers, instance-major) */
@@ -58,6 +59,7 @@ typedef struct {
   int *refactor;                                       /* [batch] mask written by the adapt-rho step */
   int *n_active;                                       /* [1] instances still iterating */
   int write_delta;                                     /* 1: this iteration also stores delta_x / delta_y (a check follows) */
+  int trace_iter;                                      /* iteration of the launch whose phases are recorded (-1: the last) */
   long long *trace;                                    /* wave timeline [batch][8] (s_memrealtime ticks) or NULL; osqp_batch_trace_iteration */
   /* Ruiz equilibration (src/scaling.c): per-instance D[n], E[m], their inverses, cost scaling c; 0 iterations = off */
   int scaling, scaled_termination;

@@ -1135,7 +1135,7 @@ __global__ __launch_bounds__(1024) void k_plan_admm_loop(rldl_dev_sym S, rldl_de
 
 template <int TG>
 struct ArrowRegs {
-  double v[TG];            // coupling values of this lane's row, step-major (steps >= arrow_steps hold 0)
+  double v[TG];            // coupling values of this lane's virtual row (piece of a row), step-major; 0 where there is none
 };
 template <int TG>
 struct ArrowIdx {
@@ -1150,11 +1150,11 @@ struct ArrowDiag {
 // iteration instead of living in 12 VGPRs across the sweeps.  `ap` is made opaque so the loads stay where they are.
 template <int TG>
 __device__ __forceinline__ void arrow_load_idx(const rldl_dev_sym &S, int lane, ArrowIdx<TG> &I) {
-  int off = S.po_apad;                                           // (opaque offset, not pointer: the loads stay global_load)
+  int off = S.po_avcol;                                          // (opaque offset, not pointer: the loads stay global_load)
   asm volatile("" : "+s"(off));
   const unsigned *ap = reinterpret_cast<const unsigned *>(S.plan + off);
 #pragma unroll
-  for (int t2 = 0; t2 < (TG + 1) / 2; t2++) I.ix[t2] = 2 * t2 < S.arrow_steps ? ap[t2 * 64 + lane] : 0u;
+  for (int t2 = 0; t2 < (TG + 1) / 2; t2++) I.ix[t2] = 2 * t2 < S.arrow_vsteps ? ap[t2 * 64 + lane] : 0u;
 }
 // Dinv of the tail and the register-resident triangle rows: straight from the factor row in HBM (coalesced)
 __device__ __forceinline__ void arrow_load_diag(const rldl_dev_sym &S, const double *Fg, int g0, int g, int rr, int lane, ArrowDiag &Dg) {
@@ -1171,18 +1171,21 @@ __device__ __forceinline__ void arrow_load_diag(const rldl_dev_sym &S, const dou
     Dg.row[k] = v;
   }
 }
-// coupling values: LDS (slots [0, nOp) staged by LDS-DMA at the start of the wave's buffer) -> registers
+// coupling values: LDS (slots [0, nOp) staged by LDS-DMA at the start of the wave's buffer) -> registers, through the
+// virtual-row slot table (vm: this lane's packed slots, fetched before the DMA wait)
 template <int TG>
-__device__ __forceinline__ void arrow_load_val(const rldl_dev_sym &S, const double *Ov, int lane, ArrowRegs<TG> &R) {
+__device__ __forceinline__ void arrow_load_map(const rldl_dev_sym &S, int lane, ArrowIdx<TG> &M) {
+  const unsigned *vm = reinterpret_cast<const unsigned *>(S.plan + S.po_avmap);
+#pragma unroll
+  for (int t2 = 0; t2 < (TG + 1) / 2; t2++) M.ix[t2] = 2 * t2 < S.arrow_vsteps ? vm[t2 * 64 + lane] : 0xffffffffu;
+}
+template <int TG>
+__device__ __forceinline__ void arrow_load_val(const double *Ov, const ArrowIdx<TG> &M, ArrowRegs<TG> &R) {
 #pragma unroll
   for (int t = 0; t < TG; t++) {
-    double val = 0.0;
-    if (t < S.arrow_steps) {                                    // uniform
-      const int base = S.arrow_base[t], cnt = S.arrow_cnt[t];   // kernarg segment -> scalar loads
-      val = Ov[base + (lane < cnt ? lane : 0)];
-      val = lane < cnt ? val : 0.0;
-    }
-    R.v[t] = val;
+    const unsigned slot = (t & 1) ? M.ix[t >> 1] >> 16 : M.ix[t >> 1] & 0xffffu;
+    const double val = Ov[slot != 0xffffu ? slot : 0u];
+    R.v[t] = slot != 0xffffu ? val : 0.0;
   }
 }
 
@@ -1194,18 +1197,20 @@ __device__ __forceinline__ void arrow_tri_solve(const rldl_dev_sym &S, const Arr
                                                 double *xs, int g0, int g, int rr, int jr, int lane, long long *tr = nullptr) {
   const bool act = lane < g;
   const int gp = g - rr;                                         // rows whose L entries live in LDS
-  // ---- forward gather of the tail rows out of registers ----
-  double ga = act ? xs[jr] : 0.0;
+  // ---- forward gather out of registers: every lane sums its piece of a tail row, the pieces of a row meet in its
+  //      x slot (which holds b) through an LDS atomic add ----
+  double ga = 0.0;
   {
     ArrowIdx<TG> I;
     arrow_load_idx<TG>(S, lane, I);
 #pragma unroll
-    for (int t = 0; t < TG; t++) {                               // steps >= arrow_steps carry value 0 and column 0
+    for (int t = 0; t < TG; t++) {                               // steps without an entry carry value 0 and column 0
       const unsigned col = (t & 1) ? I.ix[t >> 1] >> 16 : I.ix[t >> 1] & 0xffffu;
       ga = fma(-R.v[t], xs[col], ga);
     }
   }
-  if (act) xs[jr] = ga;
+  wave_sync();                                                   // all reads of the head values are done
+  if (lane < S.arrow_vrows) unsafeAtomicAdd(&xs[jr], ga);
   wait_dma();                                                    // triangle (second DMA phase) streamed in behind the gather
   wave_sync();
   if (tr && lane == 0) tr[2] = wall_clock64();                   // gather done (first iteration: triangle has arrived)
@@ -1244,7 +1249,7 @@ __device__ __forceinline__ void arrow_tri_solve(const rldl_dev_sym &S, const Arr
 // ---- transposed gather: scatter L(r, c) x_r into the head columns with LDS double atomics ----
 template <int TG>
 __device__ __forceinline__ void arrow_scatter(const rldl_dev_sym &S, const ArrowRegs<TG> &R, double *xs, int g, int jr, int lane) {
-  const double xr = lane < g ? xs[jr] : 0.0;
+  const double xr = lane < S.arrow_vrows ? xs[jr] : 0.0;
   ArrowIdx<TG> I;
   arrow_load_idx<TG>(S, lane, I);
 #pragma unroll
@@ -1269,8 +1274,8 @@ __device__ __forceinline__ void arrow_stage(const rldl_dev_sym &S, const double 
   }
 }
 
-// doubles per wave, offset of x, 16-B pieces of the LDS triangle, register rows, cohort staggering on/off
-struct ArrowGeom { int per_wave, xoff, tri2, rr, stagger; };
+// doubles per wave, offset of x, 16-B pieces of the LDS triangle, register rows
+struct ArrowGeom { int per_wave, xoff, tri2, rr; };
 
 template <int TMAX, int TG>
 __global__ __launch_bounds__(256, 4) void k_arrow_solve(rldl_dev_sym S, rldl_dev_num Nn, double *__restrict__ b_all, ArrowGeom G) {
@@ -1287,7 +1292,9 @@ __global__ __launch_bounds__(256, 4) void k_arrow_solve(rldl_dev_sym S, rldl_dev
   ArrowRegs<TG> R;
   ArrowDiag Dg;
   arrow_stage(S, Fg, Tv, lane, 1, 0);                           // coupling values first ...
-  const int jr = lane < g ? reinterpret_cast<const unsigned short *>(S.plan + S.po_fsig)[g0 + lane] : 0;
+  const int jr = (S.plan + S.po_avrow)[lane];                   // row of this lane's piece (lanes >= arrow_vrows: unused)
+  ArrowIdx<TG> M;
+  arrow_load_map<TG>(S, lane, M);
   int oo[TMAX];
   double vb[TMAX];
 #pragma unroll
@@ -1296,7 +1303,7 @@ __global__ __launch_bounds__(256, 4) void k_arrow_solve(rldl_dev_sym S, rldl_dev
   for (int t = 0; t < TMAX; t++) vb[t] = b[oo[t] >= 0 ? oo[t] : 0];   // permute_x  qdldl_interface.c:538-541
   arrow_load_diag(S, Fg, g0, g, G.rr, lane, Dg);
   wait_dma();
-  arrow_load_val<TG>(S, Tv, lane, R);                           // ... into registers ...
+  arrow_load_val<TG>(Tv, M, R);                                 // ... into registers ...
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   arrow_stage(S, Fg, Tv, lane, 0, G.tri2);                      // ... then the triangle over the same LDS
 #pragma unroll
@@ -1323,23 +1330,17 @@ __global__ __launch_bounds__(256, 4) void k_arrow_solve(rldl_dev_sym S, rldl_dev
   }
 }
 
-// Cohort staggering (G.stagger, workgroups of 8 waves = two per SIMD): with the whole batch resident every wave would
-// load at the same time and then compute at the same time.  The second half of each workgroup therefore issues its
-// loads only once the first half has all of its own in flight (one s_barrier, no memory fence), so one cohort's
-// substitution runs under the other cohort's factor stream.
-//
 // `iters` ADMM iterations per launch: an instance belongs to one wave, nothing couples instances, and the whole
 // factor row of the instance sits in that wave's registers + LDS -- so the wave simply keeps going.  The factor, q
 // and the iterates are read from HBM once per launch instead of once per iteration; only l, u, rho and the head's
 // Dinv (3.2 KB, L2-resident) are re-fetched per iteration because the register file has no room for them during
 // the sweeps.  x, z, y (and delta_x / delta_y when a check follows) are stored after the last iteration.
 template <int TMAX, int TG>
-__global__ __launch_bounds__(512, 4) void k_arrow_admm(rldl_dev_sym S, rldl_dev_num Nn, rldl_dev_admm W, ArrowGeom G, int iters) {
+__global__ __launch_bounds__(256, 4) void k_arrow_admm(rldl_dev_sym S, rldl_dev_num Nn, rldl_dev_admm W, ArrowGeom G, int iters) {
   extern __shared__ __attribute__((aligned(16))) double sh[];
   const int lane = threadIdx.x & (WAVE - 1), wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wpb = blockDim.x >> 6;
   const int inst = blockIdx.x * wpb + wv;
-  const bool late = G.stagger && wv >= (wpb >> 1);
-  if (inst >= Nn.batch) { if (G.stagger) __builtin_amdgcn_s_barrier(); return; }
+  if (inst >= Nn.batch) return;
   const int st = W.status[inst];                                // latency overlaps with the index loads below
   long long *tr = W.trace ? W.trace + 8 * (size_t)inst : nullptr;
   if (tr && lane == 0) tr[7] = wall_clock64();                  // wave start; slots 0..6 belong to the LAST iteration of the launch
@@ -1350,9 +1351,8 @@ __global__ __launch_bounds__(512, 4) void k_arrow_admm(rldl_dev_sym S, rldl_dev_
 #pragma unroll
   for (int t = 0; t < TMAX; t++) { const int j = t * WAVE + lane; oo[t] = j < S.N ? permg[j] : -1; }
   const int g0 = S.arrow_g0, g = S.arrow_g;
-  const int jr = lane < g ? reinterpret_cast<const unsigned short *>(S.plan + S.po_fsig)[g0 + lane] : 0;
-  if (st != ST_UNSOLVED) { if (G.stagger) __builtin_amdgcn_s_barrier(); return; }
-  if (late) __builtin_amdgcn_s_barrier();                       // second cohort: hold the loads back
+  const int jr = (S.plan + S.po_avrow)[lane];                   // row of this lane's piece (lanes >= arrow_vrows: unused)
+  if (st != ST_UNSOLVED) return;
   const int n = S.n, m = S.m;
   const size_t io = (size_t)inst;
   const double *Fg = Nn.F + io * S.ldF;
@@ -1373,18 +1373,23 @@ __global__ __launch_bounds__(512, 4) void k_arrow_admm(rldl_dev_sym S, rldl_dev_
     va[t] = *pa; vb[t] = *pb;
   }
   arrow_load_diag(S, Fg, g0, g, G.rr, lane, Dg);
-  if (G.stagger == 2 && !late) __builtin_amdgcn_s_barrier();    // (variant 2) first-phase requests queued: the second cohort queues behind them
   wait_dma();
-  arrow_load_val<TG>(S, Tv, lane, R);                           // ... into registers ...
+  {
+    ArrowIdx<TG> M;
+    arrow_load_map<TG>(S, lane, M);
+    arrow_load_val<TG>(Tv, M, R);                               // ... into registers ...
+  }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   arrow_stage(S, Fg, Tv, lane, 0, G.tri2);                      // ... then the triangle over the same LDS
-  if (G.stagger == 1 && !late) __builtin_amdgcn_s_barrier();    // (variant 1) release the second cohort once everything is in flight
   const double alpha = W.alpha;
-  double *dx = W.delta_x + io * n, *dy = W.delta_y + io * m;
+  auto ldg = [](const double *base, unsigned idx) {              // scalar base + 32-bit lane offset (no 64-bit lane arithmetic)
+    return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + (size_t)(idx * 8u));
+  };
 #pragma clang loop unroll(disable)
   for (int it = 0; it < iters; it++) {
     const bool last = it + 1 == iters;
-    if (tr && lane == 0 && last) tr[0] = wall_clock64();
+    const bool trit = tr && (W.trace_iter < 0 ? last : it == W.trace_iter);
+    if (trit && lane == 0) tr[0] = wall_clock64();
     // keep the per-lane index data opaque per iteration: otherwise every LDS / global address derived from it is
     // hoisted out of the loop and the 24 gather addresses alone cost 24 VGPRs of the 128 a wave may hold
     int ln = lane;                                              // (same for everything derived from the lane id)
@@ -1401,7 +1406,7 @@ __global__ __launch_bounds__(512, 4) void k_arrow_admm(rldl_dev_sym S, rldl_dev_
       const double *rip = ri + zero;
       double vr[TMAX];
 #pragma unroll
-      for (int t = 0; t < TMAX; t++) vr[t] = rip[oo[t] >= n ? oo[t] - n : 0];
+      for (int t = 0; t < TMAX; t++) vr[t] = ldg(rip, oo[t] >= n ? (unsigned)(oo[t] - n) : 0u);
 #pragma unroll
       for (int t = 0; t < TMAX; t++) {                          // compute_rhs (auxil.c:164-178) in permuted order
         const int j = t * WAVE + ln;
@@ -1409,18 +1414,18 @@ __global__ __launch_bounds__(512, 4) void k_arrow_admm(rldl_dev_sym S, rldl_dev_
       }
     }
     wave_sync();                                                // (the triangle DMA is awaited inside, behind the gather)
-    if (tr && ln == 0 && last) tr[1] = wall_clock64();          // rhs in LDS
-    arrow_tri_solve<TG>(S, R, Dg, Tv, xs, g0, g, G.rr, jr, ln, last ? tr : nullptr);
+    if (tr && ln == 0 && trit) tr[1] = wall_clock64();          // rhs in LDS
+    arrow_tri_solve<TG>(S, R, Dg, Tv, xs, g0, g, G.rr, jr, ln, trit ? tr : nullptr);
     // bounds, rho and the head's Dinv are needed only from here on: fetched behind the sweeps, under the scatter
     double vl[TMAX], vu[TMAX], vrho[TMAX], dv[TMAX], vr[TMAX];
 #pragma unroll
     for (int t = 0; t < TMAX; t++) {
-      const int ic = oo[t] >= n ? oo[t] - n : 0, j = t * WAVE + ln;
-      vl[t] = l[ic]; vu[t] = u[ic]; vrho[t] = rv[ic]; vr[t] = ri[ic];
-      dv[t] = Fg[S.nS + (j < S.N ? j : 0)];
+      const unsigned ic = oo[t] >= n ? (unsigned)(oo[t] - n) : 0u, j = (unsigned)(t * WAVE + ln);
+      vl[t] = ldg(l, ic); vu[t] = ldg(u, ic); vrho[t] = ldg(rv, ic); vr[t] = ldg(ri, ic);
+      dv[t] = ldg(Fg + S.nS, j < (unsigned)S.N ? j : 0u);
     }
     arrow_scatter<TG>(S, R, xs, g, jr, ln);
-    if (tr && ln == 0 && last) tr[5] = wall_clock64();          // scatter done
+    if (tr && ln == 0 && trit) tr[5] = wall_clock64();          // scatter done
 #pragma unroll
     for (int t = 0; t < TMAX; t++) {
       const int o = oo[t], j = t * WAVE + ln;
@@ -1434,9 +1439,9 @@ __global__ __launch_bounds__(512, 4) void k_arrow_admm(rldl_dev_sym S, rldl_dev_
         const double xp = va[t];
         const double xn = alpha * sv + (1.0 - alpha) * xp;    // update_x :188-201
         va[t] = xn;
-        if (last) {
-          x[o] = xn;
-          if (W.write_delta) dx[o] = xn - xp;
+        if (last) {                                            // (output pointers are formed here, not kept across the loop)
+          (W.x + io * n)[o] = xn;
+          if (W.write_delta) (W.delta_x + io * n)[o] = xn - xp;
         }
       } else {
         const int i = o - n;
@@ -1448,14 +1453,15 @@ __global__ __launch_bounds__(512, 4) void k_arrow_admm(rldl_dev_sym S, rldl_dev_
         const double d = vrho[t] * (mix - zn);                 // update_y :217-228
         va[t] = zn; vb[t] = yi + d;
         if (last) {
-          z[i] = zn;
-          if (W.write_delta) dy[i] = d;
-          y[i] = yi + d;
+          (W.z + io * m)[i] = zn;
+          if (W.write_delta) (W.delta_y + io * m)[i] = d;
+          (W.y + io * m)[i] = yi + d;
         }
       }
     }
+    if (trit && ln == 0 && W.trace_iter >= 0) tr[6] = wall_clock64();
   }
-  if (tr && lane == 0) tr[6] = wall_clock64();
+  if (tr && lane == 0 && W.trace_iter < 0) tr[6] = wall_clock64();
 }
 
 }  // namespace
@@ -1564,7 +1570,7 @@ static ArrowGeom arrow_geometry_rr(const rldl_dev_sym *S, int rr) {
   const int gp = g - rr, tri = (gp * (gp - 1)) / 2, trip = (tri + 1) & ~1;
   const int stage = trip > S->nOp ? trip : S->nOp;
   ArrowGeom G;
-  G.rr = rr; G.tri2 = trip >> 1; G.xoff = stage; G.per_wave = stage + ((S->N + 1) & ~1); G.stagger = 0;
+  G.rr = rr; G.tri2 = trip >> 1; G.xoff = stage; G.per_wave = stage + ((S->N + 1) & ~1);
   return G;
 }
 static ArrowGeom arrow_geometry(const rldl_dev_sym *S) {
@@ -1576,12 +1582,12 @@ static ArrowGeom arrow_geometry(const rldl_dev_sym *S) {
   }
   return arrow_geometry_rr(S, 0);
 }
-static int arrow_pick_wpb(const rldl_dev_sym *S, const void *kernel, const ArrowGeom &G, size_t *lds_out, int max_wpb = 4) {
-  static const void *ck = 0; static int cpw = -1, cbest = 0, cmax = 0; static size_t clds = 0;
-  if (ck == kernel && cpw == G.per_wave && cmax == max_wpb) { *lds_out = clds; return cbest; }
+static int arrow_pick_wpb(const rldl_dev_sym *S, const void *kernel, const ArrowGeom &G, size_t *lds_out) {
+  static const void *ck = 0; static int cpw = -1, cbest = 0; static size_t clds = 0;
+  if (ck == kernel && cpw == G.per_wave) { *lds_out = clds; return cbest; }
   int best = 0, best_waves = 0; size_t best_lds = 0;
   const char *force = getenv("RLDL_WPB");
-  for (int wpb = max_wpb == 8 ? 8 : 1; wpb <= max_wpb; wpb *= 2) {   // max_wpb == 8: the staggered launch needs exactly 8
+  for (int wpb = 1; wpb <= 4; wpb *= 2) {
     const size_t b = sizeof(double) * (size_t)wpb * (size_t)G.per_wave;
     if (b > (size_t)LDS_PER_CU) continue;
     if (force && atoi(force) != wpb) continue;
@@ -1591,7 +1597,7 @@ static int arrow_pick_wpb(const rldl_dev_sym *S, const void *kernel, const Arrow
     if (nb * wpb > best_waves) { best = wpb; best_waves = nb * wpb; best_lds = b; }
   }
   (void)hipGetLastError();
-  ck = kernel; cpw = G.per_wave; cbest = best; clds = best_lds; cmax = max_wpb;
+  ck = kernel; cpw = G.per_wave; cbest = best; clds = best_lds;
   if (getenv("RLDL_VERBOSE"))
     fprintf(stderr, "[rldl] arrow kernel: wpb=%d, %d waves/CU, %zu B LDS per workgroup, %d triangle rows in registers\n", best, best_waves,
             best_lds, G.rr);
@@ -1599,7 +1605,7 @@ static int arrow_pick_wpb(const rldl_dev_sym *S, const void *kernel, const Arrow
   return best;
 }
 static bool arrow_usable(const rldl_dev_sym *S) {
-  return S->plan_ok && S->arrow_ok && S->arrow_steps <= 32 && S->arrow_tb <= 0 && S->arrow_g <= WAVE && S->N <= 8 * WAVE &&
+  return S->plan_ok && S->arrow_ok && S->arrow_vsteps >= 1 && S->arrow_vsteps <= 24 && S->arrow_tb <= 0 && S->arrow_g <= WAVE && S->N <= 8 * WAVE &&
          !getenv("RLDL_NO_ARROW") && sizeof(double) * (size_t)arrow_geometry(S).per_wave <= (size_t)LDS_PER_CU;
 }
 template <int TMAX, int TG>
@@ -1614,10 +1620,12 @@ static int launch_arrow_solve_t(const rldl_dev_sym *S, const rldl_dev_num *Nn, d
 }
 template <int TMAX>
 static int launch_arrow_solve_g(const rldl_dev_sym *S, const rldl_dev_num *Nn, double *d_b, void *stream) {
-  if (S->arrow_steps <= 8) return launch_arrow_solve_t<TMAX, 8>(S, Nn, d_b, stream);
-  if (S->arrow_steps <= 16) return launch_arrow_solve_t<TMAX, 16>(S, Nn, d_b, stream);
-  if (S->arrow_steps <= 24) return launch_arrow_solve_t<TMAX, 24>(S, Nn, d_b, stream);
-  return launch_arrow_solve_t<TMAX, 32>(S, Nn, d_b, stream);
+  if (S->arrow_vsteps <= 8) return launch_arrow_solve_t<TMAX, 8>(S, Nn, d_b, stream);
+  if (S->arrow_vsteps <= 12) return launch_arrow_solve_t<TMAX, 12>(S, Nn, d_b, stream);
+  if (S->arrow_vsteps <= 14) return launch_arrow_solve_t<TMAX, 14>(S, Nn, d_b, stream);
+  if (S->arrow_vsteps <= 16) return launch_arrow_solve_t<TMAX, 16>(S, Nn, d_b, stream);
+  if (S->arrow_vsteps <= 18) return launch_arrow_solve_t<TMAX, 18>(S, Nn, d_b, stream);
+  return launch_arrow_solve_t<TMAX, 24>(S, Nn, d_b, stream);
 }
 static int launch_arrow_solve(const rldl_dev_sym *S, const rldl_dev_num *Nn, double *d_b, void *stream) {
   if (S->N <= 2 * WAVE) return launch_arrow_solve_g<2>(S, Nn, d_b, stream);
@@ -1628,15 +1636,8 @@ static int launch_arrow_solve(const rldl_dev_sym *S, const rldl_dev_num *Nn, dou
 template <int TMAX, int TG>
 static int launch_arrow_admm_t(const rldl_dev_sym *S, const rldl_dev_num *Nn, const rldl_dev_admm *W, int iters, void *stream) {
   size_t lds = 0;
-  ArrowGeom G = arrow_geometry(S);
-  // staggering pays when the batch fills the resident slots of the chip more than half (otherwise nothing contends)
-  static const int stagger_env = getenv("RLDL_STAGGER") ? atoi(getenv("RLDL_STAGGER")) : 0;
-  int wpb = 0;
-  if (stagger_env && Nn->batch >= 2048) {
-    wpb = arrow_pick_wpb(S, (const void *)k_arrow_admm<TMAX, TG>, G, &lds, 8);
-    if (wpb == 8) G.stagger = stagger_env;
-  }
-  if (!G.stagger) wpb = arrow_pick_wpb(S, (const void *)k_arrow_admm<TMAX, TG>, G, &lds);
+  const ArrowGeom G = arrow_geometry(S);
+  const int wpb = arrow_pick_wpb(S, (const void *)k_arrow_admm<TMAX, TG>, G, &lds);
   if (wpb <= 0) return -1;
   if (lds > 64 * 1024 && hipFuncSetAttribute((const void *)k_arrow_admm<TMAX, TG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
   hipLaunchKernelGGL((k_arrow_admm<TMAX, TG>), dim3((Nn->batch + wpb - 1) / wpb), dim3(wpb * WAVE), lds, (hipStream_t)stream, *S, *Nn, *W, G, iters);
@@ -1644,10 +1645,12 @@ static int launch_arrow_admm_t(const rldl_dev_sym *S, const rldl_dev_num *Nn, co
 }
 template <int TMAX>
 static int launch_arrow_admm_g(const rldl_dev_sym *S, const rldl_dev_num *Nn, const rldl_dev_admm *W, int iters, void *stream) {
-  if (S->arrow_steps <= 8) return launch_arrow_admm_t<TMAX, 8>(S, Nn, W, iters, stream);
-  if (S->arrow_steps <= 16) return launch_arrow_admm_t<TMAX, 16>(S, Nn, W, iters, stream);
-  if (S->arrow_steps <= 24) return launch_arrow_admm_t<TMAX, 24>(S, Nn, W, iters, stream);
-  return launch_arrow_admm_t<TMAX, 32>(S, Nn, W, iters, stream);
+  if (S->arrow_vsteps <= 8) return launch_arrow_admm_t<TMAX, 8>(S, Nn, W, iters, stream);
+  if (S->arrow_vsteps <= 12) return launch_arrow_admm_t<TMAX, 12>(S, Nn, W, iters, stream);
+  if (S->arrow_vsteps <= 14) return launch_arrow_admm_t<TMAX, 14>(S, Nn, W, iters, stream);
+  if (S->arrow_vsteps <= 16) return launch_arrow_admm_t<TMAX, 16>(S, Nn, W, iters, stream);
+  if (S->arrow_vsteps <= 18) return launch_arrow_admm_t<TMAX, 18>(S, Nn, W, iters, stream);
+  return launch_arrow_admm_t<TMAX, 24>(S, Nn, W, iters, stream);
 }
 static int launch_arrow_admm(const rldl_dev_sym *S, const rldl_dev_num *Nn, const rldl_dev_admm *W, int iters, void *stream) {
   if (S->N <= 2 * WAVE) return launch_arrow_admm_g<2>(S, Nn, W, iters, stream);

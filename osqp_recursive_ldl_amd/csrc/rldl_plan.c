@@ -157,10 +157,27 @@ int rldl_plan_build(rldl_symbolic *s) {
     if (fstep_ptr[k + 1] > fstep_ptr[k]) { ngather++; arrow_k = k; arrow_steps = fstep_ptr[k + 1] - fstep_ptr[k]; }
     if (coloff[gstart[k]] >= 0) ntri++;
   }
-  s->arrow_ok = (ngather == 1 && arrow_steps <= 32 && ntri <= 1 && (ntri == 0 || coloff[gstart[arrow_k]] >= 0)) ? 1 : 0;
+  s->arrow_ok = (ngather == 1 && ntri <= 1 && (ntri == 0 || coloff[gstart[arrow_k]] >= 0) && nO < 65535) ? 1 : 0;
   s->arrow_group = s->arrow_ok ? arrow_k : -1;
   s->arrow_steps = s->arrow_ok ? arrow_steps : 0;
-  s->po_apad = words; words += s->arrow_ok ? ((arrow_steps + 1) / 2) * 64 : 0;   /* dword [ceil(steps/2)][64]: idx(t even) | idx(t odd) << 16 */
+  /* VIRTUAL ROWS: the coupling rows of the tail group are cut into pieces of at most T consecutive entries, one
+   * piece per lane, with T the smallest length for which the pieces fit the 64 lanes.  A lane then keeps T values in
+   * registers instead of max-row-length (24 -> 13 on the metric shape: the rows average 15 entries and 14 lanes sat
+   * idle), forward results of the pieces of a row meet in its x slot through an LDS atomic add. */
+  s->arrow_vsteps = 0; s->arrow_vrows = 0;
+  if (s->arrow_ok) {
+    int g0 = gstart[arrow_k], g = gstart[arrow_k + 1] - g0, T, nv = 0;
+    for (T = 1; T <= arrow_steps; T++) {
+      nv = 0;
+      for (i = 0; i < g; i++) nv += (rowcnt[g0 + i] + T - 1) / T;
+      if (nv <= 64) break;
+    }
+    if (T > 32) s->arrow_ok = 0;
+    else { s->arrow_vsteps = T; s->arrow_vrows = nv; }
+  }
+  s->po_avmap = words; words += s->arrow_ok ? ((s->arrow_vsteps + 1) / 2) * 64 : 0;   /* dword [ceil(T/2)][64]: slot(t even) | slot(t odd) << 16, 0xffff = none */
+  s->po_avcol = words; words += s->arrow_ok ? ((s->arrow_vsteps + 1) / 2) * 64 : 0;   /* same packing, column index (0 where there is no entry) */
+  s->po_avrow = words; words += s->arrow_ok ? 64 : 0;                                 /* row (permuted index) of the lane's piece */
   blob = (int *)calloc((size_t)words + 4, sizeof(int));
   if (!blob) goto out;
 
@@ -205,12 +222,34 @@ int rldl_plan_build(rldl_symbolic *s) {
       }
     }
     for (k = 0; k < nfs; k++) { blob[s->po_fsb + k] = fsteps_base[k]; blob[s->po_fsc + k] = fsteps_cnt[k]; }
-    if (s->arrow_ok) {                                       /* padded column indices; padding -> column 0 (its value is 0) */
-      unsigned *apad = (unsigned *)(blob + s->po_apad);
-      int t, f0 = fstep_ptr[arrow_k];
-      for (t = 0; t < arrow_steps; t++)
-        for (i = 0; i < fsteps_cnt[f0 + t]; i++)
-          apad[(t >> 1) * 64 + i] |= (unsigned)fcol[fsteps_base[f0 + t] + i] << (16 * (t & 1));
+    if (s->arrow_ok) {                                       /* virtual-row tables, pieces sorted by length (descending) */
+      unsigned *vmap = (unsigned *)(blob + s->po_avmap), *vcol = (unsigned *)(blob + s->po_avcol);
+      int *vrow = blob + s->po_avrow;
+      const int T = s->arrow_vsteps, f0 = fstep_ptr[arrow_k], g0 = gstart[arrow_k], g = gstart[arrow_k + 1] - g0;
+      kv pieces[64];
+      int rows_of[64], e0_of[64], np = 0, t, l;
+      for (i = 0; i < g; i++) {
+        int len = rowcnt[g0 + i], e0;
+        for (e0 = 0; e0 < len; e0 += T) {
+          pieces[np].key = len - e0 < T ? len - e0 : T;
+          pieces[np].idx = np;                               /* stable tie-break */
+          rows_of[np] = g0 + i; e0_of[np] = e0;
+          np++;
+        }
+      }
+      qsort(pieces, (size_t)np, sizeof(kv), cmp_kv_desc);
+      for (l = 0; l < 64; l++) vrow[l] = 0;
+      for (t = 0; t < ((T + 1) / 2) * 64; t++) { vmap[t] = 0xffffffffu; vcol[t] = 0u; }
+      for (l = 0; l < np; l++) {
+        const int src = pieces[l].idx, r = rows_of[src], e0 = e0_of[src], len = pieces[l].key;
+        vrow[l] = r;
+        for (t = 0; t < len; t++) {
+          const int slot = fsteps_base[f0 + e0 + t] + fpos_of_row[r];
+          const int sh = 16 * (t & 1);
+          vmap[(t >> 1) * 64 + l] = (vmap[(t >> 1) * 64 + l] & ~(0xffffu << sh)) | ((unsigned)slot << sh);
+          vcol[(t >> 1) * 64 + l] |= (unsigned)fcol[slot] << sh;
+        }
+      }
     }
   }
   /* storage map: CSC position -> slot */

@@ -54,9 +54,10 @@ typedef struct {
   int *plan;                   /* packed int32 blob uploaded to the device */
   int plan_words;
   int po_gstart, po_gflag, po_gaptr, po_grptr, po_gToff, po_fsp, po_bsp, po_acol, po_aoff, po_arow, po_coloff, po_fsb,
-      po_fsc, po_bsb, po_bsc, po_fsig, po_bsig, po_fcol, po_brs, po_perm, po_apad;
+      po_fsc, po_bsb, po_bsc, po_fsig, po_bsig, po_fcol, po_brs, po_perm, po_avmap, po_avcol, po_avrow;
   int nOp;                     /* nO rounded up to even: first triangle slot */
-  int arrow_ok, arrow_group, arrow_steps; /* arrowhead specialisation (see rldl_plan.c) */        /* word offsets of the sub-arrays inside `plan` */
+  int arrow_ok, arrow_group, arrow_steps; /* arrowhead specialisation (see rldl_plan.c) */
+  int arrow_vsteps, arrow_vrows;          /* virtual rows: coupling rows cut into pieces of <= vsteps entries, one piece per lane */        /* word offsets of the sub-arrays inside `plan` */
   /* problem matrices for the residual kernels: CSC as given plus row-order (CSR) access maps */
   int *Pp, *Pi, *Prp, *Prj, *Prpos;   /* P upper triangular n x n */
   int *Ap, *Ai, *Arp, *Arj, *Arpos;   /* A m x n */
