@@ -685,73 +685,90 @@ __device__ __forceinline__ double readlane_f64(double v, int src) {   // src mus
 // which is off the dependency chain, so the chain per step is v_readlane x2 -> v_fma_f64 only.
 //   forward : step a eliminates local column a; lane i > a reads L(i, a) = rowp[a], rowp = Tp + i (i-1)/2
 //   backward: step s uses local row il = g-1-s; lane j < il reads L(il, j) = Tp[il (il-1)/2 + j]
+// The g-1 steps are run as (g-1) mod U single steps first and whole batches after, so no step needs a range check;
+// reads past a row / past the triangle return other finite values of the wave's LDS and are masked.
 // Lanes >= g are never touched (they may carry live values of rows handled elsewhere).
 template <int U>
 __device__ __forceinline__ double sweep_fwd(const double *Tp, int g, int lane, double acc) {
-  const int nst = g - 1, nb = (nst + U - 1) / U;
+  const int nst = g - 1, rem = nst % U, nb = nst / U;
   const int lc = lane < g ? lane : g - 1;
   const double *rowp = Tp + ((lc * (lc - 1)) >> 1);
   const unsigned long long live = g >= 64 ? ~0ull : ((1ull << g) - 1ull);
   double tA[U], tB[U];
   auto load = [&](int s0, double (&tb)[U]) {
 #pragma unroll
-    for (int u = 0; u < U; u++) tb[u] = rowp[s0 + u];          // reads past the row / the triangle are masked below
+    for (int u = 0; u < U; u++) tb[u] = rowp[s0 + u];
+  };
+  auto step = [&](int a, double t) {
+    const unsigned long long mk = (~1ull << a) & live;           // lanes (a, g)
+    const double tm = __builtin_amdgcn_inverse_ballot_w64(mk) ? t : 0.0;
+    const double xj = readlane_f64(acc, a);
+    acc = fma(-tm, xj, acc);
   };
   auto proc = [&](int s0, const double (&tb)[U]) {
 #pragma unroll
-    for (int u = 0; u < U; u++) {
-      const int a = s0 + u;
-      const unsigned long long mk = a < nst ? ((~1ull << a) & live) : 0ull;   // lanes (a, g)
-      const double tm = __builtin_amdgcn_inverse_ballot_w64(mk) ? tb[u] : 0.0;
-      const double xj = readlane_f64(acc, a & 63);
-      acc = fma(-tm, xj, acc);
-    }
+    for (int u = 0; u < U; u++) step(s0 + u, tb[u]);
   };
+  if (rem) {
+    load(0, tA);
+#pragma unroll
+    for (int u = 0; u < U - 1; u++)
+      if (u < rem) step(u, tA[u]);
+  }
   int b = 0;
-  if (nb > 0) load(0, tA);
+  if (nb > 0) load(rem, tA);
   while (b + 2 <= nb) {
-    load((b + 1) * U, tB);
-    proc(b * U, tA);
-    if (b + 2 < nb) load((b + 2) * U, tA);
-    proc((b + 1) * U, tB);
+    load(rem + (b + 1) * U, tB);
+    proc(rem + b * U, tA);
+    if (b + 2 < nb) load(rem + (b + 2) * U, tA);
+    proc(rem + (b + 1) * U, tB);
     b += 2;
   }
-  if (b < nb) proc(b * U, tA);
+  if (b < nb) proc(rem + b * U, tA);
   return acc;
 }
 template <int U>
 __device__ __forceinline__ double sweep_bwd(const double *Tp, int g, int lane, double acc) {
-  const int nst = g - 1, nb = (nst + U - 1) / U;
+  const int nst = g - 1, rem = nst % U, nb = nst / U;
   const double *lanep = Tp + lane;
   double tA[U], tB[U];
+  // step s uses row il = nst - s >= 1; the packed offset il (il-1)/2 is carried along, off(il-1) = off(il) - (il-1)
   auto load = [&](int s0, double (&tb)[U]) {
+    int il = nst - s0;
+    int off = (il * (il - 1)) >> 1;
 #pragma unroll
     for (int u = 0; u < U; u++) {
-      int il = g - 1 - (s0 + u);
-      il = il > 0 ? il : 0;
-      tb[u] = lanep[(il * (il - 1)) >> 1];
+      tb[u] = lanep[off];
+      il -= 1;
+      off -= il;                                                 // (rows below 1 only in unused slots of the odd batch)
     }
+  };
+  auto step = [&](int il, double t) {
+    const unsigned long long mk = ~(~0ull << il);                // lanes [0, il)
+    const double tm = __builtin_amdgcn_inverse_ballot_w64(mk) ? t : 0.0;
+    const double xi = readlane_f64(acc, il);
+    acc = fma(-tm, xi, acc);
   };
   auto proc = [&](int s0, const double (&tb)[U]) {
 #pragma unroll
-    for (int u = 0; u < U; u++) {
-      const int il = g - 1 - (s0 + u);
-      const unsigned long long mk = il > 0 ? ((1ull << il) - 1ull) : 0ull;     // lanes [0, il)
-      const double tm = __builtin_amdgcn_inverse_ballot_w64(mk) ? tb[u] : 0.0;
-      const double xi = readlane_f64(acc, il > 0 ? il : 0);
-      acc = fma(-tm, xi, acc);
-    }
+    for (int u = 0; u < U; u++) step(nst - (s0 + u), tb[u]);
   };
+  if (rem) {
+    load(0, tA);
+#pragma unroll
+    for (int u = 0; u < U - 1; u++)
+      if (u < rem) step(nst - u, tA[u]);
+  }
   int b = 0;
-  if (nb > 0) load(0, tA);
+  if (nb > 0) load(rem, tA);
   while (b + 2 <= nb) {
-    load((b + 1) * U, tB);
-    proc(b * U, tA);
-    if (b + 2 < nb) load((b + 2) * U, tA);
-    proc((b + 1) * U, tB);
+    load(rem + (b + 1) * U, tB);
+    proc(rem + b * U, tA);
+    if (b + 2 < nb) load(rem + (b + 2) * U, tA);
+    proc(rem + (b + 1) * U, tB);
     b += 2;
   }
-  if (b < nb) proc(b * U, tA);
+  if (b < nb) proc(rem + b * U, tA);
   return acc;
 }
 
