@@ -688,6 +688,13 @@ __device__ __forceinline__ double readlane_f64(double v, int src) {   // src mus
 // The g-1 steps are run as (g-1) mod U single steps first and whole batches after, so no step needs a range check;
 // reads past a row / past the triangle return other finite values of the wave's LDS and are masked.
 // Lanes >= g are never touched (they may carry live values of rows handled elsewhere).
+// Multiplier of a masked-out lane: only the HIGH dword is cleared (one v_cndmask instead of two).  What is left is
+// a denormal below 2^-1042, whose product with the pivot vanishes against any normal accumulator; an accumulator
+// that is exactly 0 picks up at most ~1e-314 |pivot|, far below every tolerance of the path.
+__device__ __forceinline__ double mask_hi(unsigned long long lanes, double t) {
+  const int hi = __builtin_amdgcn_inverse_ballot_w64(lanes) ? __double2hiint(t) : 0;
+  return __hiloint2double(hi, __double2loint(t));
+}
 template <int U>
 __device__ __forceinline__ double sweep_fwd(const double *Tp, int g, int lane, double acc) {
   const int nst = g - 1, rem = nst % U, nb = nst / U;
@@ -701,7 +708,7 @@ __device__ __forceinline__ double sweep_fwd(const double *Tp, int g, int lane, d
   };
   auto step = [&](int a, double t) {
     const unsigned long long mk = (~1ull << a) & live;           // lanes (a, g)
-    const double tm = __builtin_amdgcn_inverse_ballot_w64(mk) ? t : 0.0;
+    const double tm = mask_hi(mk, t);
     const double xj = readlane_f64(acc, a);
     acc = fma(-tm, xj, acc);
   };
@@ -745,7 +752,7 @@ __device__ __forceinline__ double sweep_bwd(const double *Tp, int g, int lane, d
   };
   auto step = [&](int il, double t) {
     const unsigned long long mk = ~(~0ull << il);                // lanes [0, il)
-    const double tm = __builtin_amdgcn_inverse_ballot_w64(mk) ? t : 0.0;
+    const double tm = mask_hi(mk, t);
     const double xi = readlane_f64(acc, il);
     acc = fma(-tm, xi, acc);
   };
