@@ -194,6 +194,22 @@ c_int rldl_batch_update_from_stage(rldl_batch *h, c_int first_stage, const c_flo
  * The optional kind/stage/entry arrays (sized by the outputs' nnz; upper bounds: (N-1) nnz(Qi) + nnz(Q0) + nnz(QN) and
  * N (nnz(Ai) + nnz(Aij)) + nnz(A0) + nnz(AN)) name the source of every stored value
  * (P kinds: 0=Q0 1=Qi 2=QN; A kinds: 0=A0 1=Ai 2=Aij 3=AN), which is what a batched update_AP_matrices (:1675-1778) needs. */
+/* ADMM-level mirror of the recursive entry points (include/recursive_ldl.h:52-74):
+ *   osqp_setup_recursive (src/recursive_ldl.c:2018-2230)        -> osqp_batch_setup_recursive
+ *   LDL_update_from_pivot at a fixed horizon (:946-1110)        -> osqp_batch_update_recursive (new values from a stage on)
+ *   osqp_solve_recursive (:2867-...)                            -> osqp_batch_solve
+ *   osqp_partial_update_bounds (:119-200)                       -> osqp_batch_partial_update_bounds
+ *   get_L_dimensions (:1334-1342) / cleanup_rldl (:15-60)       -> rldl_batch_dims(osqp_batch_linsys(w)) / osqp_batch_cleanup
+ * NOT built: osqp_update_recursive (:1973-2016), which CHANGES the horizon N.
+ * The stage blocks carry the NOMINAL values, replicated to every instance; per-instance values follow through
+ * osqp_batch_update_P_A / osqp_batch_update_recursive in the value order of *P_out / *A_out (free with rldl_csc_free). */
+c_int osqp_batch_setup_recursive(osqp_batch **wp, c_int batch, const rldl_stage_dims *dims, const csc *Q0, const csc *Qi,
+                                 const csc *QN, const csc *A0, const csc *Ai, const csc *Aij, const csc *AN,
+                                 const c_float *d_q, const c_float *d_l, const c_float *d_u,
+                                 const OSQPBatchSettings *settings, csc **P_out, csc **A_out, void *stream);
+c_int osqp_batch_update_recursive(osqp_batch *w, c_int first_stage, const c_float *d_Px, const c_float *d_Ax);
+c_int osqp_batch_partial_update_bounds(osqp_batch *w, c_int start, c_int stop, const c_float *d_l, const c_float *d_u);
+
 c_int rldl_setup_AP_matrices(const rldl_stage_dims *dims, const csc *Q0, const csc *Qi, const csc *QN, const csc *A0,
                              const csc *Ai, const csc *Aij, const csc *AN, csc **P_out, csc **A_out, c_int *P_kind,
                              c_int *P_stage, c_int *P_entry, c_int *A_kind, c_int *A_stage, c_int *A_entry);

@@ -30,20 +30,6 @@
 #define RHO_MIN 1e-06
 #define RHO_MAX 1e06
 
-struct osqp_batch {
-  c_int batch, n, m, nnzP, nnzA;
-  OSQPBatchSettings st;
-  rldl_batch *ls;
-  rldl_dev_admm W;
-  double *Px, *Ax, *q, *l, *u;   /* owned device copies of the problem data (osqp.c:106-114) */
-  void *stream;
-  void *ev0, *ev1;
-  int *h_tmp_i;                  /* [batch] host scratch */
-  double *h_tmp_d;               /* [batch] host scratch */
-  float last_loop_ms;
-  c_int last_loop_launches;     /* ADMM iterations run by the last solve loop ... */
-  c_int last_loop_groups;       /* ... in this many launch groups (one kernel launch each on the arrowhead path) */
-};
 
 void osqp_batch_set_default_settings(OSQPBatchSettings *s) {
   s->rho = 0.1; s->sigma = 1e-6; s->alpha = 1.6; s->eps_abs = 1e-3; s->eps_rel = 1e-3;
@@ -304,6 +290,35 @@ c_int osqp_batch_update_bounds(osqp_batch *w, const c_float *d_l, const c_float 
   if (rldl_batch_update_rho_vec(w->ls, w->W.rho_vec, w->W.refactor)) return 1;
   (void)hipMemsetAsync(w->W.refactor, 0, sizeof(int) * (size_t)w->batch, (hipStream_t)w->stream);
   return 0;
+}
+
+/* osqp_partial_update_bounds (src/recursive_ldl.c:119-200): rows [start, stop) of l and u of every instance.
+ * d_l / d_u: [batch][stop - start].  (The reference rescales the WHOLE of l, u by E again at :151-154, which
+ * compounds the scaling of the untouched rows; here only the new rows are scaled.) */
+c_int osqp_batch_partial_update_bounds(osqp_batch *w, c_int start, c_int stop, const c_float *d_l, const c_float *d_u) {
+  if (!w) return 7;
+  if (!d_l || !d_u || start < 0 || stop > w->m || start >= stop) return 1;
+  if (rldl_launch_set_range((int)w->batch, (int)w->m, (int)start, (int)(stop - start), w->l, d_l, w->st.scaling ? w->W.sE : 0, w->stream)) return 1;
+  if (rldl_launch_set_range((int)w->batch, (int)w->m, (int)start, (int)(stop - start), w->u, d_u, w->st.scaling ? w->W.sE : 0, w->stream)) return 1;
+  reset_info(w);
+  if (rldl_launch_set_rho_vec(&w->ls->dsym, &w->W, 0, w->stream)) return 1;
+  if (rldl_batch_update_rho_vec(w->ls, w->W.rho_vec, w->W.refactor)) return 1;
+  (void)hipMemsetAsync(w->W.refactor, 0, sizeof(int) * (size_t)w->batch, (hipStream_t)w->stream);
+  return 0;
+}
+
+/* New P / A values whose first difference lies in stage `first_stage`: the factorisation restarts there
+ * (LDL_update_from_pivot, src/recursive_ldl.c:946-1110, at a fixed horizon; the reference's osqp_update_recursive,
+ * :1973-2016, additionally changes N, which is not built).  With equilibration on, new
+ * values move D, E and c, i.e. every entry of the scaled KKT matrix: that case is a full osqp_batch_update_P_A. */
+c_int osqp_batch_update_recursive(osqp_batch *w, c_int first_stage, const c_float *d_Px, const c_float *d_Ax) {
+  if (!w) return 7;
+  if (!w->ls->recursive) return 1;
+  if (w->st.scaling) return osqp_batch_update_P_A(w, d_Px, d_Ax);
+  if (d_Px && !HIP_OK(hipMemcpyAsync(w->Px, d_Px, sizeof(double) * (size_t)w->batch * (size_t)w->nnzP, hipMemcpyDeviceToDevice, (hipStream_t)w->stream))) return 1;
+  if (d_Ax && !HIP_OK(hipMemcpyAsync(w->Ax, d_Ax, sizeof(double) * (size_t)w->batch * (size_t)w->nnzA, hipMemcpyDeviceToDevice, (hipStream_t)w->stream))) return 1;
+  reset_info(w);
+  return rldl_batch_update_from_stage(w->ls, first_stage, d_Px ? w->Px : 0, d_Ax ? w->Ax : 0, 0);
 }
 
 c_int osqp_batch_update_rho(osqp_batch *w, c_float rho_new) {

@@ -77,6 +77,8 @@ int rldl_launch_factor(const rldl_dev_sym *S, const rldl_dev_num *Nn, const int 
 int rldl_launch_factor_from(const rldl_dev_sym *S, const rldl_dev_num *Nn, int c_start, void *stream);
 int rldl_launch_solve(const rldl_dev_sym *S, const rldl_dev_num *Nn, double *d_b, void *stream);
 int rldl_launch_admm_iter(const rldl_dev_sym *S, const rldl_dev_num *Nn, const rldl_dev_admm *W, void *stream);
+int rldl_launch_bcast_rows(int batch, int len, double *dst, const double *src, void *stream);
+int rldl_launch_set_range(int batch, int ld, int start, int cnt, double *dst, const double *src, const double *s, void *stream);
 int rldl_launch_admm_iters(const rldl_dev_sym *S, const rldl_dev_num *Nn, const rldl_dev_admm *W, int iters, void *stream);
 int rldl_launch_admm_check(const rldl_dev_sym *S, const rldl_dev_admm *W, int iter, int approximate, int final_pass,
                            void *stream);

@@ -21,6 +21,22 @@ struct rldl_batch {
   void *rec;               /* rldl_rec_state* */
 };
 
+/* batched ADMM workspace (rldl_admm.c) */
+struct osqp_batch {
+  c_int batch, n, m, nnzP, nnzA;
+  OSQPBatchSettings st;
+  rldl_batch *ls;
+  rldl_dev_admm W;
+  double *Px, *Ax, *q, *l, *u;   /* owned device copies of the problem data (osqp.c:106-114) */
+  void *stream;
+  void *ev0, *ev1;
+  int *h_tmp_i;                  /* [batch] host scratch */
+  double *h_tmp_d;               /* [batch] host scratch */
+  float last_loop_ms;
+  c_int last_loop_launches;     /* ADMM iterations run by the last solve loop ... */
+  c_int last_loop_groups;       /* ... in this many launch groups (one kernel launch each on the arrowhead path) */
+};
+
 int rldl_device_available(void);
 c_int rldl_batch_check_status(rldl_batch *h); /* sync + qdldl_interface.c:80-92 verdict: 0 ok, 1 failed */
 

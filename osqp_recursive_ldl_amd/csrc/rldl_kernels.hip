@@ -624,6 +624,20 @@ __global__ __launch_bounds__(256) void k_ew_scale(int len, double *dst, const do
 
 // set_rho_vec (auxil.c:79-101) when init != 0, update_rho_vec (auxil.c:103-145) otherwise:
 // classify rows, fill rho_vec, raise the refactor mask when a constraint type changed.
+// dst[b][i] = src[i] (one nominal row to every instance)
+__global__ __launch_bounds__(256) void k_bcast_rows(int len, double *dst, const double *src) {
+  const int inst = blockIdx.x;
+  for (int i = threadIdx.x; i < len; i += blockDim.x) dst[(size_t)inst * len + i] = src[i];
+}
+// dst[b][start + i] = src[b][i] * (s ? s[b][start + i] : 1), i < cnt: a column range of instance-major rows
+__global__ __launch_bounds__(256) void k_set_range(int ld, int start, int cnt, double *dst, const double *src, const double *s) {
+  const int inst = blockIdx.x;
+  for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
+    const size_t o = (size_t)inst * ld + start + i;
+    dst[o] = src[(size_t)inst * cnt + i] * (s ? s[o] : 1.0);
+  }
+}
+
 __global__ __launch_bounds__(WAVE) void k_set_rho_vec(rldl_dev_sym S, rldl_dev_admm W, int init) {
   const int inst = blockIdx.x, lane = threadIdx.x, m = S.m;
   const double *l = W.l + (size_t)inst * m, *u = W.u + (size_t)inst * m;
@@ -1807,6 +1821,17 @@ extern "C" int rldl_launch_unscale_data(const rldl_dev_sym *S, const rldl_dev_ad
 extern "C" int rldl_launch_ew_scale(int batch, int len, double *dst, const double *src, const double *s, const double *c, void *stream) {
   if (batch <= 0 || len <= 0) return 0;
   hipLaunchKernelGGL(k_ew_scale, dim3(batch), dim3(256), 0, (hipStream_t)stream, len, dst, src, s, c);
+  return launch_status();
+}
+
+extern "C" int rldl_launch_bcast_rows(int batch, int len, double *dst, const double *src, void *stream) {
+  if (batch <= 0 || len <= 0) return 0;
+  hipLaunchKernelGGL(k_bcast_rows, dim3(batch), dim3(256), 0, (hipStream_t)stream, len, dst, src);
+  return launch_status();
+}
+extern "C" int rldl_launch_set_range(int batch, int ld, int start, int cnt, double *dst, const double *src, const double *s, void *stream) {
+  if (batch <= 0 || cnt <= 0) return 0;
+  hipLaunchKernelGGL(k_set_range, dim3(batch), dim3(256), 0, (hipStream_t)stream, ld, start, cnt, dst, src, s);
   return launch_status();
 }
 

@@ -13,6 +13,7 @@
  * reference's "continue from the saved pivot" semantics without the X_even cache.  Dense per-stage
  * block kernels (the MFMA candidate of SURVEY.md 8a-15) are the planned next step.
  */
+#include <hip/hip_runtime_api.h>
 #include <stdlib.h>
 
 #include "../../include/osqp_rldl_hip.h"
@@ -132,4 +133,47 @@ c_int rldl_setup_AP_matrices(const rldl_stage_dims *d, const csc *Q0, const csc 
   P->p[col] = nzP; A->p[col] = nzA;
   *P_out = P; *A_out = A;
   return 0;
+}
+
+/* osqp_setup_recursive (src/recursive_ldl.c:2018-2230): the caller hands over the seven stage blocks of an MPC problem
+ * (OSQPDataRLDL, include/recursive_ldl.h:17-50) instead of P and A.  The blocks are assembled on the host
+ * (rldl_setup_AP_matrices), their values are replicated to every instance as the nominal problem, and the workspace is
+ * built on the stage-interleaved permutation, so that osqp_batch_update_recursive can restart the factorisation at a
+ * stage.  Per-instance values go in afterwards through osqp_batch_update_P_A / osqp_batch_update_recursive in the
+ * value order of the assembled matrices (P_out / A_out, owned by the caller: rldl_csc_free). */
+c_int osqp_batch_setup_recursive(osqp_batch **wp, c_int batch, const rldl_stage_dims *dims, const csc *Q0, const csc *Qi,
+                                 const csc *QN, const csc *A0, const csc *Ai, const csc *Aij, const csc *AN, const c_float *d_q,
+                                 const c_float *d_l, const c_float *d_u, const OSQPBatchSettings *settings, csc **P_out,
+                                 csc **A_out, void *stream) {
+  csc *P = 0, *A = 0;
+  double *d_nom = 0, *d_Px = 0, *d_Ax = 0;
+  c_int rc, nzP, nzA, *perm = 0;
+  if (wp) *wp = 0;
+  if (!wp || !dims || batch <= 0) return 1;
+  rc = rldl_setup_AP_matrices(dims, Q0, Qi, QN, A0, Ai, Aij, AN, &P, &A, 0, 0, 0, 0, 0, 0);
+  if (rc) return rc;
+  nzP = P->p[P->n]; nzA = A->p[A->n];
+  perm = (c_int *)malloc(sizeof(c_int) * (size_t)(P->n + A->m));
+  rc = RLDL_MEM_ALLOC_ERROR;
+  if (!perm) goto out;
+  if (hipMalloc((void **)&d_nom, sizeof(double) * (size_t)(nzP > nzA ? nzP : nzA) + 8) != hipSuccess) goto out;
+  if (hipMalloc((void **)&d_Px, sizeof(double) * (size_t)batch * (size_t)nzP + 8) != hipSuccess) goto out;
+  if (hipMalloc((void **)&d_Ax, sizeof(double) * (size_t)batch * (size_t)nzA + 8) != hipSuccess) goto out;
+  if (hipMemcpyAsync(d_nom, P->x, sizeof(double) * (size_t)nzP, hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess) goto out;
+  if (rldl_launch_bcast_rows((int)batch, (int)nzP, d_Px, d_nom, stream)) goto out;
+  if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) goto out;
+  if (hipMemcpyAsync(d_nom, A->x, sizeof(double) * (size_t)nzA, hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess) goto out;
+  if (rldl_launch_bcast_rows((int)batch, (int)nzA, d_Ax, d_nom, stream)) goto out;
+  if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) goto out;
+  rldl_stage_permutation(dims->N, dims->nx, dims->nu, dims->ny, dims->nt, perm);
+  rc = osqp_batch_setup(wp, batch, P, A, d_Px, d_Ax, d_q, d_l, d_u, settings, perm, stream);
+  if (!rc) { (*wp)->ls->stage = *dims; (*wp)->ls->recursive = 1; }
+out:
+  free(perm);
+  if (d_nom) (void)hipFree(d_nom);
+  if (d_Px) (void)hipFree(d_Px);
+  if (d_Ax) (void)hipFree(d_Ax);
+  if (!rc && P_out) *P_out = P; else rldl_csc_free(P);
+  if (!rc && A_out) *A_out = A; else rldl_csc_free(A);
+  return rc;
 }

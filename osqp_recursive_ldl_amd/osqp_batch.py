@@ -41,6 +41,46 @@ class OSQPBatch:
                                                     None if pm is None else _ip(pm), None), "osqp_batch_setup")
         self._device = q.device
 
+    @classmethod
+    def recursive(cls, dims, Q0, Qi, QN, A0, Ai, Aij, AN, q, l, u, **settings):
+        """osqp_setup_recursive (src/recursive_ldl.c:2018-2230): the workspace is built from the seven stage blocks of an
+        MPC problem (nominal values, replicated to every instance); `dims` = (N, nx, nu, ny, nt).  P blocks upper
+        triangular.  The assembled patterns are kept as self.P / self.A (value order of update_P_A / update_recursive)."""
+        from scipy import sparse
+        L = _lib.lib()
+        self = cls.__new__(cls)
+        blocks = [CscPattern(sparse.triu(sparse.csc_matrix(b), format="csc")) for b in (Q0, Qi, QN)] + \
+                 [CscPattern(sparse.csc_matrix(b)) for b in (A0, Ai, Aij, AN)]
+        sd = _lib.StageDims(*[int(v) for v in dims])
+        self.batch = int(q.shape[0])
+        self.settings = default_settings(**settings)
+        Pp, Ap = C.POINTER(_lib.Csc)(), C.POINTER(_lib.Csc)()
+        self.h = C.c_void_p()
+        self.status = _lib.check(L.osqp_batch_setup_recursive(C.byref(self.h), self.batch, C.byref(sd), *[b.ref for b in blocks],
+                                                              _dptr(q), _dptr(l), _dptr(u), C.byref(self.settings), C.byref(Pp),
+                                                              C.byref(Ap), None), "osqp_batch_setup_recursive")
+
+        def to_scipy(M):
+            n, m = M.n, M.m
+            p = np.array([M.p[i] for i in range(n + 1)]); nz = int(p[-1])
+            i = np.array([M.i[k] for k in range(nz)]); x = np.array([M.x[k] for k in range(nz)])
+            return sparse.csc_matrix((x, i, p), shape=(m, n))
+        P, A = to_scipy(Pp.contents), to_scipy(Ap.contents)
+        L.rldl_csc_free(Pp); L.rldl_csc_free(Ap)
+        self.P, self.A = CscPattern(P), CscPattern(A)
+        self.n, self.m = self.P.shape[0], self.A.shape[0]
+        self._device = q.device
+        return self
+
+    def update_recursive(self, first_stage, Px=None, Ax=None):
+        """New values from stage `first_stage` on: the factorisation restarts there (LDL_update_from_pivot semantics)."""
+        return int(_lib.lib().osqp_batch_update_recursive(self.h, int(first_stage), _dptr(Px), _dptr(Ax)))
+
+    def partial_update_bounds(self, start, stop, l, u):
+        """osqp_partial_update_bounds (src/recursive_ldl.c:119-200): rows [start, stop) of the bounds of every instance."""
+        _dev_f64(l, (self.batch, stop - start), "l"); _dev_f64(u, (self.batch, stop - start), "u")
+        return int(_lib.lib().osqp_batch_partial_update_bounds(self.h, int(start), int(stop), _dptr(l), _dptr(u)))
+
     def linsys(self):
         return BatchLinsys(self.P, self.A, None, None, 0, None, _handle=_lib.lib().osqp_batch_linsys(self.h), _owned=False)
 

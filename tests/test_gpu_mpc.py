@@ -62,3 +62,44 @@ def test_mpc_equality_rows_get_the_stiff_rho_and_converge():
         assert int(r["iter"][b]) == ro["iter"]
         assert relerr(r["x"][b].cpu().numpy(), ro["x"]) < 1e-6
     w.cleanup()
+
+
+def test_setup_recursive_from_stage_blocks_equals_assembled_setup():
+    """osqp_setup_recursive mirror: building the workspace from the seven stage blocks gives the same iterates as handing
+    over the assembled P, A with the stage permutation; per-instance values then go in through update_recursive, which
+    restarts the factorisation at the first modified stage, and partial_update_bounds equals a full update_bounds."""
+    import osqp_recursive_ldl_amd as R
+    wl = R.workloads.MPCStageQPs(N=6)
+    B = 3
+    Px, Ax, q, l, u = wl.values(B)
+    perm = R.workloads.stage_permutation(*wl.dims)
+    kw = dict(rho=0.1, sigma=1e-6, alpha=1.6, max_iter=50, check_termination=0, adaptive_rho=0, warm_start=0, scaling=0)
+    wr = R.OSQPBatch.recursive(wl.dims, wl.Q0, wl.Qi, wl.QN, wl.A0, wl.Ai, wl.Aij, wl.AN, dev(q), dev(l), dev(u), **kw)
+    assert wr.status == 0
+    assert np.array_equal(wr.P.i, R.CscPattern(wl.P_pattern).i) and np.array_equal(wr.A.i, R.CscPattern(wl.A_pattern).i)
+    nomP = np.tile(wr.P.x, (B, 1)); nomA = np.tile(wr.A.x, (B, 1))
+    wa = R.OSQPBatch(wl.P_pattern, wl.A_pattern, dev(nomP), dev(nomA), dev(q), dev(l), dev(u), perm=perm, **kw)
+    ra, rr = wa.solve(), wr.solve()
+    assert torch.equal(ra["x"], rr["x"]) and torch.equal(ra["y"], rr["y"])          # same kernels, same inputs
+    # per-instance values: only stages >= 4 differ from the nominal problem
+    first = 4
+    col0 = wl.nu + (first - 1) * (wl.nx + wl.nu)
+    Pp, Ap = wr.P.p, wr.A.p
+    Px2, Ax2 = nomP.copy(), nomA.copy()
+    Px2[:, Pp[col0]:] = Px[:, Pp[col0]:]; Ax2[:, Ap[col0]:] = Ax[:, Ap[col0]:]
+    assert wr.update_recursive(first, dev(Px2), dev(Ax2)) == 0
+    assert wa.update_P_A(dev(Px2), dev(Ax2)) == 0                                     # full refactor
+    ra, rr = wa.solve(), wr.solve()
+    assert relerr(rr["x"].cpu().numpy(), ra["x"].cpu().numpy()) < 1e-9
+    for b in range(B):
+        assert relerr(wr.linsys().export_factor(b)["Lx"], wa.linsys().export_factor(b)["Lx"]) < 1e-11
+    # partial bounds update == full bounds update
+    l2, u2 = l.copy(), u.copy()
+    s0, s1 = 5, 17
+    l2[:, s0:s1] -= 0.25; u2[:, s0:s1] += 0.5
+    assert wr.partial_update_bounds(s0, s1, dev(l2[:, s0:s1]), dev(u2[:, s0:s1])) == 0
+    assert wa.update_bounds(dev(l2), dev(u2)) == 0
+    ra, rr = wa.solve(), wr.solve()
+    assert relerr(rr["x"].cpu().numpy(), ra["x"].cpu().numpy()) < 1e-9
+    assert wr.partial_update_bounds(3, 3, dev(l2[:, :0]), dev(u2[:, :0])) == 1         # start >= stop (recursive_ldl.c:126)
+    wa.cleanup(); wr.cleanup()

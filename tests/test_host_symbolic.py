@@ -214,3 +214,52 @@ def test_solve_plan_schedule_reproduces_the_reference_substitution(case):
     ob.lib().orc_qdldl_solve.argtypes = [ob.c_int, ob.IP, ob.IP, ob.FP, ob.FP, ob.FP]
     ob.lib().orc_qdldl_solve(n + m, ob.ip(e["Lp"]), ob.ip(e["Li"]), ob.fp(e["Lx"]), ob.fp(e["Dinv"]), ob.fp(ref))
     assert np.max(np.abs(got - ref)) <= 1e-12 * max(1.0, np.max(np.abs(ref)))
+
+
+@pytest.mark.parametrize("case", ["arrowhead", "small"])
+def test_virtual_row_tables_cover_every_coupling_entry_once(case):
+    """Arrowhead plans (csrc/rldl_plan.c, "virtual rows"): the coupling rows of the tail group are cut into pieces of
+    at most T entries, one piece per lane.  Every out-of-group entry of L must appear exactly once, under its own row,
+    with its own column and storage slot; T is minimal for 64 lanes; the pieces are sorted by length."""
+    from osqp_recursive_ldl_amd.linsys import plan_export
+    wl = R.workloads.SharedPatternQPs() if case == "arrowhead" else R.workloads.SharedPatternQPs(n=20, m=35, density=0.2, pattern_seed=5)
+    pl = plan_export(wl.P_pattern, wl.A_pattern)
+    sym = R.symbolic_analyze(wl.P_pattern, wl.A_pattern)
+    if not pl["arrow_ok"]:
+        pytest.skip("not an arrowhead plan")
+    T, nv = pl["arrow_vsteps"], pl["arrow_vrows"]
+    blob = pl["blob"].view(np.uint32)
+    half = (T + 1) // 2
+    vmap = blob[pl["po_avmap"]:pl["po_avmap"] + half * 64].reshape(half, 64)
+    vcol = blob[pl["po_avcol"]:pl["po_avcol"] + half * 64].reshape(half, 64)
+    vrow = pl["blob"][pl["po_avrow"]:pl["po_avrow"] + 64]
+    gs = pl["blob"][pl["po_gstart"]:pl["po_gstart"] + pl["ngroups"] + 1]
+    k = pl["arrow_group"]
+    g0, g1 = int(gs[k]), int(gs[k + 1])
+    # expected: all entries L(r, c) with r in the tail group and c outside it, keyed by storage slot
+    want = {}
+    Lp, Li = sym["Lp"], sym["Li"]
+    for c in range(sym["N"] if "N" in sym else wl.n + wl.m):
+        for p in range(Lp[c], Lp[c + 1]):
+            r = int(Li[p])
+            if g0 <= r < g1 and not (g0 <= c < g1):
+                want[int(pl["LtoS"][p])] = (r, c)
+    got, lens = {}, []
+    for lane in range(64):
+        ln = 0
+        for t in range(T):
+            slot = int((vmap[t >> 1, lane] >> (16 * (t & 1))) & 0xffff)
+            col = int((vcol[t >> 1, lane] >> (16 * (t & 1))) & 0xffff)
+            if slot == 0xffff:
+                assert col == 0
+                continue
+            assert lane < nv and t == ln, "entries of a piece are contiguous from step 0"
+            assert slot not in got
+            got[slot] = (int(vrow[lane]), col)
+            ln += 1
+        lens.append(ln)
+    assert got == want and len(want) == pl["nO"]
+    assert lens == sorted(lens, reverse=True) and all(v > 0 for v in lens[:nv]) and all(v == 0 for v in lens[nv:])
+    rows = np.bincount([r - g0 for r, _ in want.values()], minlength=g1 - g0)
+    pieces = lambda tt: int(sum((int(v) + tt - 1) // tt for v in rows))
+    assert pieces(T) == nv <= 64 and (T == 1 or pieces(T - 1) > 64)
