@@ -379,6 +379,9 @@ __device__ __forceinline__ int dual_infeasible(const rldl_dev_sym &S, const doub
 #define CHK_FINAL 4          /* tail of osqp_solve */
 #define CHK_FINAL_NEEDS_INFO 8
 
+// STAGED: the instance's P and A values are copied to LDS first (coalesced), so the three SpMVs of update_info and
+// the ones of the infeasibility tests walk LDS instead of issuing dependent global loads entry by entry.
+template <bool STAGED>
 __global__ __launch_bounds__(WAVE) void k_admm_check(rldl_dev_sym S, rldl_dev_admm W, int iter, int mode) {
   const int inst = blockIdx.x, lane = threadIdx.x;
   const int n = S.n, m = S.m;
@@ -389,7 +392,13 @@ __global__ __launch_bounds__(WAVE) void k_admm_check(rldl_dev_sym S, rldl_dev_ad
   const int active = st == ST_UNSOLVED;
   if (!active && !(mode & CHK_FINAL)) return;
 
-  const double *Pv = W.Px + (size_t)inst * S.nnzP, *Av = W.Ax + (size_t)inst * S.nnzA;
+  const double *Pg = W.Px + (size_t)inst * S.nnzP, *Ag = W.Ax + (size_t)inst * S.nnzA;
+  double *Pl = dyp + m, *Al = Pl + S.nnzP;
+  if (STAGED) {
+    for (int p = lane; p < S.nnzP; p += WAVE) Pl[p] = Pg[p];
+    for (int p = lane; p < S.nnzA; p += WAVE) Al[p] = Ag[p];
+  }
+  const double *Pv = STAGED ? Pl : Pg, *Av = STAGED ? Al : Ag;
   const double *q = W.q + (size_t)inst * n, *l = W.l + (size_t)inst * m, *u = W.u + (size_t)inst * m;
   double *x = W.x + (size_t)inst * n, *z = W.z + (size_t)inst * m, *y = W.y + (size_t)inst * m;
   double *dxg = W.delta_x + (size_t)inst * n, *dyg = W.delta_y + (size_t)inst * m;
@@ -552,14 +561,24 @@ __device__ __forceinline__ double colnorm_P_sym(const rldl_dev_sym &S, const dou
   return d;
 }
 
+// `STAGED`: the instance's P, A, q, D, E live in LDS for all `iters` passes (one coalesced read and one coalesced write
+// of the data instead of ~6 dependent global round trips per pass); the fallback works in place in global memory.
+template <bool STAGED>
 __global__ __launch_bounds__(WAVE) void k_scale_data(rldl_dev_sym S, rldl_dev_admm W, double *Px_all, double *Ax_all, double *q_all,
                                                      double *l_all, double *u_all, int iters) {
   const int inst = blockIdx.x, lane = threadIdx.x, n = S.n, m = S.m;
   extern __shared__ double sh[];
   double *Dt = sh, *Et = Dt + n;
-  double *P = Px_all + (size_t)inst * S.nnzP, *A = Ax_all + (size_t)inst * S.nnzA, *q = q_all + (size_t)inst * n;
+  double *Pg = Px_all + (size_t)inst * S.nnzP, *Ag = Ax_all + (size_t)inst * S.nnzA, *qg = q_all + (size_t)inst * n;
   double *l = l_all + (size_t)inst * m, *u = u_all + (size_t)inst * m;
-  double *D = W.sD + (size_t)inst * n, *Dinv = W.sDinv + (size_t)inst * n, *E = W.sE + (size_t)inst * m, *Einv = W.sEinv + (size_t)inst * m;
+  double *Dg = W.sD + (size_t)inst * n, *Dinv = W.sDinv + (size_t)inst * n, *Eg = W.sE + (size_t)inst * m, *Einv = W.sEinv + (size_t)inst * m;
+  double *D = STAGED ? Et + m : Dg, *E = STAGED ? D + n : Eg, *q = STAGED ? E + m : qg;
+  double *P = STAGED ? q + n : Pg, *A = STAGED ? P + S.nnzP : Ag;
+  if (STAGED) {
+    for (int p = lane; p < S.nnzP; p += WAVE) P[p] = Pg[p];
+    for (int p = lane; p < S.nnzA; p += WAVE) A[p] = Ag[p];
+    for (int j = lane; j < n; j += WAVE) q[j] = qg[j];
+  }
   for (int j = lane; j < n; j += WAVE) D[j] = 1.0;
   for (int i = lane; i < m; i += WAVE) E[i] = 1.0;
   double c = 1.0;
@@ -594,6 +613,12 @@ __global__ __launch_bounds__(WAVE) void k_scale_data(rldl_dev_sym S, rldl_dev_ad
     for (int j = lane; j < n; j += WAVE) q[j] *= ct;
     c *= ct;
     __syncthreads();
+  }
+  if (STAGED) {
+    for (int p = lane; p < S.nnzP; p += WAVE) Pg[p] = P[p];
+    for (int p = lane; p < S.nnzA; p += WAVE) Ag[p] = A[p];
+    for (int j = lane; j < n; j += WAVE) { qg[j] = q[j]; Dg[j] = D[j]; }
+    for (int i = lane; i < m; i += WAVE) Eg[i] = E[i];
   }
   for (int j = lane; j < n; j += WAVE) Dinv[j] = 1.0 / D[j];
   for (int i = lane; i < m; i += WAVE) { const double e = E[i]; Einv[i] = 1.0 / e; l[i] *= e; u[i] *= e; }
@@ -1775,6 +1800,7 @@ extern "C" int rldl_launch_admm_iter(const rldl_dev_sym *S, const rldl_dev_num *
 }
 
 static size_t check_lds(const rldl_dev_sym *S) { return sizeof(double) * (size_t)(6 * S->n + 6 * S->m + 8); }
+static size_t check_lds_staged(const rldl_dev_sym *S) { return check_lds(S) + sizeof(double) * (size_t)(S->nnzP + S->nnzA); }
 
 extern "C" int rldl_launch_admm_check(const rldl_dev_sym *S, const rldl_dev_admm *W, int iter, int approximate,
                                       int final_pass, void *stream) {
@@ -1785,7 +1811,10 @@ extern "C" int rldl_launch_admm_check(const rldl_dev_sym *S, const rldl_dev_admm
   if (approximate & 2) mode |= CHK_ADAPT;
   if (final_pass) mode |= CHK_FINAL;
   if (final_pass == 2) mode |= CHK_FINAL_NEEDS_INFO;
-  hipLaunchKernelGGL(k_admm_check, dim3(W->batch), dim3(WAVE), check_lds(S), (hipStream_t)stream, *S, *W, iter, mode);
+  if (check_lds_staged(S) <= 40 * 1024)
+    hipLaunchKernelGGL(k_admm_check<true>, dim3(W->batch), dim3(WAVE), check_lds_staged(S), (hipStream_t)stream, *S, *W, iter, mode);
+  else
+    hipLaunchKernelGGL(k_admm_check<false>, dim3(W->batch), dim3(WAVE), check_lds(S), (hipStream_t)stream, *S, *W, iter, mode);
   return launch_status();
 }
 
@@ -1808,8 +1837,12 @@ extern "C" int rldl_launch_finalize(const rldl_dev_sym *S, const rldl_dev_admm *
 extern "C" int rldl_launch_scale_data(const rldl_dev_sym *S, const rldl_dev_admm *W, double *Px, double *Ax, double *q, double *l,
                                       double *u, int iters, void *stream) {
   if (W->batch <= 0) return 0;
-  hipLaunchKernelGGL(k_scale_data, dim3(W->batch), dim3(WAVE), sizeof(double) * (size_t)(S->n + S->m + 2), (hipStream_t)stream, *S, *W, Px,
-                     Ax, q, l, u, iters);
+  const size_t small = sizeof(double) * (size_t)(S->n + S->m + 2);
+  const size_t staged = small + sizeof(double) * (size_t)(2 * S->n + S->m + S->nnzP + S->nnzA);
+  if (staged <= 64 * 1024)
+    hipLaunchKernelGGL(k_scale_data<true>, dim3(W->batch), dim3(WAVE), staged, (hipStream_t)stream, *S, *W, Px, Ax, q, l, u, iters);
+  else
+    hipLaunchKernelGGL(k_scale_data<false>, dim3(W->batch), dim3(WAVE), small, (hipStream_t)stream, *S, *W, Px, Ax, q, l, u, iters);
   return launch_status();
 }
 extern "C" int rldl_launch_unscale_data(const rldl_dev_sym *S, const rldl_dev_admm *W, double *Px, double *Ax, double *q, double *l,

@@ -71,8 +71,32 @@ def metric_shape():
         w.update_P_A(dPx[:B2].contiguous(), dAx[:B2].contiguous())
         w.solve()
     ms = timed(step, reps=5)
+    lm, its, gr = w.last_loop()
     emit(name="config2_batch1024_factor_plus_200_iters", batch=B2, ms_per_step=ms, qp_solves_per_sec=B2 / (ms * 1e-3),
-         iter_kernel_us=1e3 * w.time_iteration(0))
+         us_per_iteration=1e3 * lm / its, launches_per_solve=gr)
+    w.cleanup()
+    # end-to-end with the reference's default equilibration (scaling=10 for the end-to-end number)
+    kw10 = dict(kw, scaling=10)
+    w = R.OSQPBatch(wl.P_pattern, wl.A_pattern, dPx, dAx, t(q), t(l), t(u), **kw10)
+
+    def step10():
+        w.update_P_A(dPx, dAx)
+        w.solve()
+    ms = timed(step10, reps=5)
+    emit(name="metric_shape_batch4096_scaling10_factor_plus_200_iters", batch=B, ms_per_step=ms, qp_solves_per_sec=B / (ms * 1e-3))
+    # default OSQP behaviour: termination checks every 25 iterations, adaptive rho, eps 1e-3
+    kwd = dict(rho=0.1, sigma=1e-6, alpha=1.6, max_iter=4000, check_termination=25, adaptive_rho=1, adaptive_rho_interval=100,
+               eps_abs=1e-3, eps_rel=1e-3, warm_start=0, scaling=10)
+    w.cleanup()
+    w = R.OSQPBatch(wl.P_pattern, wl.A_pattern, dPx, dAx, t(q), t(l), t(u), **kwd)
+    r = None
+
+    def stepd():
+        nonlocal r
+        r = w.solve()
+    ms = timed(stepd, reps=5)
+    emit(name="metric_shape_batch4096_default_termination_scaling10", batch=B, ms_per_solve=ms, qp_solves_per_sec=B / (ms * 1e-3),
+         mean_iterations=float(r["iter"].double().mean()), solved=int((r["status"] == 1).sum()))
     w.cleanup()
 
 
