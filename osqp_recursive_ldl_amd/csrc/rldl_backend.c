@@ -97,6 +97,7 @@ static void free_dev_symbolic(rldl_dev_sym *D) {
 void rldl_batch_free(rldl_batch *h) {
   if (!h) return;
   if (h->stream_owned && h->stream) (void)hipStreamSynchronize((hipStream_t)h->stream);
+  rldl_stage_maps_free(h);
   free_dev_symbolic(&h->dsym);
   if (h->num.Kx) (void)hipFree(h->num.Kx);
   if (h->num.F) (void)hipFree(h->num.F);

@@ -12,6 +12,18 @@ extern "C" {
 #endif
 
 /* device-resident copy of rldl_symbolic (all pointers are DEVICE pointers) */
+/* Dense stage-block view of a block-tridiagonal (MPC) pattern for k_stage_factor: per diagonal block b the
+ * entries of the permuted KKT matrix and of L that fall into block (b, b) and into the coupling block (b+1, b), each
+ * with its position in a dense ld x ld LDS tile (row * ld + col, rows/cols local to their blocks). */
+typedef struct {
+  int nb, ld, smax;
+  const int *bs;                          /* [nb+1] first permuted index of each block */
+  const int *kd_ptr, *kd_src, *kd_pos;    /* KKT values of the diagonal block: Kx index -> tile position (lower part) */
+  const int *kc_ptr, *kc_src, *kc_pos;    /* KKT values of the coupling block (b+1, b) */
+  const int *ld_ptr, *ld_slot, *ld_pos;   /* L entries inside block b: factor slot <- tile position */
+  const int *lc_ptr, *lc_slot, *lc_pos;   /* L entries of L(b+1, b) */
+} rldl_dev_stage;
+
 typedef struct {
   int n, m, N, nnzP, nnzA, nnzK, nnzL, nsig, polish;
   const int *perm, *PtoK, *AtoK, *rhotoK, *sigK;
@@ -34,6 +46,7 @@ typedef struct {
   int arrow_g0, arrow_g;       /* index range of the tail group */
   int arrow_tb;                /* its triangle base relative to slot nOp, or -1 */
   int arrow_cnt[32];           /* per virtual-row step: number of lanes with an entry (kernarg segment -> scalar loads) */
+  rldl_dev_stage stage;        /* stage.nb > 0: block-tridiagonal pattern, numeric factorisation by dense stage blocks */
 } rldl_dev_sym;
 
 /* per-batch numeric state of the linear-system backend (DEVICE pointers, instance-major) */
@@ -74,6 +87,7 @@ typedef struct {
 int rldl_launch_kkt_assemble(const rldl_dev_sym *S, const rldl_dev_num *Nn, const double *d_Px, const double *d_Ax,
                              const double *d_rho_vec, int set_sigma_only, const int *d_mask, void *stream);
 int rldl_launch_factor(const rldl_dev_sym *S, const rldl_dev_num *Nn, const int *d_mask, void *stream);
+int rldl_launch_stage_factor(const rldl_dev_sym *S, const rldl_dev_num *Nn, const int *d_mask, int first_block, void *stream);
 int rldl_launch_factor_from(const rldl_dev_sym *S, const rldl_dev_num *Nn, int c_start, void *stream);
 int rldl_launch_solve(const rldl_dev_sym *S, const rldl_dev_num *Nn, double *d_b, void *stream);
 int rldl_launch_admm_iter(const rldl_dev_sym *S, const rldl_dev_num *Nn, const rldl_dev_admm *W, void *stream);

@@ -1178,6 +1178,103 @@ __global__ __launch_bounds__(1024) void k_plan_admm_loop(rldl_dev_sym S, rldl_de
 }
 
 // ================================================================================================
+// k_stage_factor -- numeric LDL' of a block-tridiagonal (MPC stage-interleaved) KKT matrix by dense stage blocks,
+// the arithmetic of the reference's recursion (src/recursive_ldl.c: pivot_even :686-808, pivot_odd :554-680,
+// pivot_final :813-935, driver LDL_factorize_recursive :1139-1318) on one wavefront per instance:
+//   S_b = K_bb - L(b,b-1) D_{b-1} L(b,b-1)'     Schur complement of the previous block (dense, LDS)
+//   S_b = L_bb D_b L_bb'                          dense LDL' in place (right-looking, column by column)
+//   L(b+1,b) = K(b+1,b) L_bb^-T D_b^-1            one row per lane
+// Where the reference works on the positive form of the odd pivots and flips signs afterwards (:616, :651-655,
+// :673-675), the blocks here are the quasi-definite ones themselves -- same L, same D.  Inputs come from the
+// permuted KKT values, outputs go straight into the factor's slot layout through host-built maps, so the solve
+// kernels, the restart logic and export see no difference to k_factor.  first block b0 > 0: blocks < b0 keep
+// their L and D (LDL_update_from_pivot, :946-1110); L(b0,b0-1) and D_{b0-1} are read back from the factor.
+// ================================================================================================
+__global__ __launch_bounds__(WAVE) void k_stage_factor(rldl_dev_sym S, rldl_dev_num Nn, const int *__restrict__ mask, int b0) {
+  const int inst = blockIdx.x, lane = threadIdx.x;
+  if (mask && !mask[inst]) return;
+  const rldl_dev_stage &G = S.stage;
+  const int ld = G.ld, nb = G.nb;
+  extern __shared__ double sh[];
+  // Wp: panel [S_b ; C_b] (rows of block b, then rows of block b+1), 2*smax rows x ld;  Lc: L(b, b-1), smax rows x ld
+  double *Wp = sh, *Lc = Wp + 2 * G.smax * ld, *dg = Lc + G.smax * ld, *dc = dg + ld;
+  const double *Kx = Nn.Kx + (size_t)inst * S.nnzK;
+  double *F = Nn.F + (size_t)inst * S.ldF, *Dv = Nn.D + (size_t)inst * S.N;
+  const int rl = lane >> 2, cl = lane & 3;                        // 16 row lanes x 4 column lanes for the rank-1 updates
+  int npos = 0, zero = 0;
+  for (int j = lane; j < G.bs[b0]; j += WAVE) npos += Dv[j] > 0.0 ? 1 : 0;        // pivots kept from the blocks before b0
+  if (b0 > 0) {
+    const int sprev = G.bs[b0] - G.bs[b0 - 1], scur = G.bs[b0 + 1] - G.bs[b0];
+    for (int p = lane; p < scur * ld; p += WAVE) Lc[p] = 0.0;
+    wave_sync();
+    for (int e = G.lc_ptr[b0 - 1] + lane; e < G.lc_ptr[b0]; e += WAVE) Lc[G.lc_pos[e]] = F[G.lc_slot[e]];
+    for (int c = lane; c < sprev; c += WAVE) dg[c] = Dv[G.bs[b0 - 1] + c];
+    wave_sync();
+  }
+  for (int b = b0; b < nb; b++) {
+    const int bs = G.bs[b], s = G.bs[b + 1] - bs, sp = b > 0 ? bs - G.bs[b - 1] : 0;
+    const int sn = b + 1 < nb ? G.bs[b + 2] - G.bs[b + 1] : 0, R = s + sn;
+    // 1. dense copy of the diagonal block (lower part incl. the diagonal) and of the coupling block below it
+    for (int p = lane; p < R * ld; p += WAVE) Wp[p] = 0.0;
+    wave_sync();
+    for (int e = G.kd_ptr[b] + lane; e < G.kd_ptr[b + 1]; e += WAVE) Wp[G.kd_pos[e]] = Kx[G.kd_src[e]];
+    if (sn)
+      for (int e = G.kc_ptr[b] + lane; e < G.kc_ptr[b + 1]; e += WAVE) Wp[s * ld + G.kc_pos[e]] = Kx[G.kc_src[e]];
+    wave_sync();
+    // 2. Schur complement of the previous block, 1 x 4 tiles on and below the diagonal (8 tile columns per row)
+    if (b > 0) {
+      for (int tile = lane; tile < s * 8; tile += WAVE) {
+        const int i = tile >> 3, j0 = (tile & 7) * 4;
+        if (j0 > i) continue;
+        const double *ri = Lc + i * ld, *r0 = Lc + j0 * ld;
+        const double *r1 = Lc + (j0 + 1 < s ? j0 + 1 : j0) * ld, *r2 = Lc + (j0 + 2 < s ? j0 + 2 : j0) * ld, *r3 = Lc + (j0 + 3 < s ? j0 + 3 : j0) * ld;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll 4
+        for (int c = 0; c < sp; c++) {
+          const double w = ri[c] * dg[c];
+          a0 = fma(w, r0[c], a0); a1 = fma(w, r1[c], a1); a2 = fma(w, r2[c], a2); a3 = fma(w, r3[c], a3);
+        }
+        double *o = Wp + i * ld + j0;
+        o[0] -= a0;
+        if (j0 + 1 <= i) o[1] -= a1;
+        if (j0 + 2 <= i) o[2] -= a2;
+        if (j0 + 3 <= i) o[3] -= a3;
+      }
+      wave_sync();
+    }
+    // 3. right-looking elimination of the panel: L_bb, D_b and L(b+1, b) = C L_bb^-T D_b^-1 in one sweep.
+    //    Column j: W[i][k] -= W[i][j] W[k][j] / d for j < k < s, k <= i < R (rows of C take every k), then W[i][j] /= d.
+    for (int j = 0; j < s; j++) {
+      const double d = Wp[j * ld + j];
+      if (d == 0.0) zero = 1;                                     // QDLDL contract: zero pivot -> -1
+      if (lane == 0 && d > 0.0) npos++;
+      const double dinv = 1.0 / d;
+      for (int i = j + 1 + rl; i < R; i += 16) {
+        const double a = Wp[i * ld + j];
+        const int kend = i < s ? i : s - 1;
+        for (int k = j + 1 + cl; k <= kend; k += 4) Wp[i * ld + k] -= a * (Wp[k * ld + j] * dinv);
+      }
+      wave_sync();
+      for (int i = j + 1 + lane; i < R; i += WAVE) Wp[i * ld + j] *= dinv;
+      if (lane == 0) dc[j] = d;
+      wave_sync();
+    }
+    // 4. this block's D, Dinv, L_bb and the coupling block into the factor
+    for (int j = lane; j < s; j += WAVE) { const double d = dc[j]; Dv[bs + j] = d; F[S.nS + bs + j] = 1.0 / d; }
+    for (int e = G.ld_ptr[b] + lane; e < G.ld_ptr[b + 1]; e += WAVE) F[G.ld_slot[e]] = Wp[G.ld_pos[e]];
+    if (sn) {
+      for (int e = G.lc_ptr[b] + lane; e < G.lc_ptr[b + 1]; e += WAVE) F[G.lc_slot[e]] = Wp[s * ld + G.lc_pos[e]];
+      for (int p = lane; p < sn * ld; p += WAVE) Lc[p] = Wp[s * ld + p];             // keep L(b+1, b) for the next Schur complement
+      double *tp = dg; dg = dc; dc = tp;
+      wave_sync();
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) npos += __shfl_xor(npos, o);
+  if (lane == 0) Nn.status[inst] = zero ? -1 : npos;
+}
+
+// ================================================================================================
 // Arrowhead specialisation (plan->arrow_ok): all out-of-group entries feed ONE dense group (the Schur
 // tail of a KKT matrix ordered by minimum degree) and no other group has a triangle.  Then
 //   * the coupling values (jagged-diagonal order, one row per lane) are staged by LDS-DMA, moved to
@@ -1741,7 +1838,17 @@ static int launch_factor(const rldl_dev_sym *S, const rldl_dev_num *Nn, const in
   return launch_status();
 }
 
+extern "C" int rldl_launch_stage_factor(const rldl_dev_sym *S, const rldl_dev_num *Nn, const int *d_mask, int first_block, void *stream) {
+  if (Nn->batch <= 0) return 0;
+  const rldl_dev_stage *G = &S->stage;
+  if (G->nb <= 0 || first_block < 0 || first_block >= G->nb) return -1;
+  const size_t lds = sizeof(double) * (size_t)(3 * G->smax * G->ld + 2 * G->ld);
+  hipLaunchKernelGGL(k_stage_factor, dim3(Nn->batch), dim3(WAVE), lds, (hipStream_t)stream, *S, *Nn, d_mask, first_block);
+  return launch_status();
+}
+
 extern "C" int rldl_launch_factor(const rldl_dev_sym *S, const rldl_dev_num *Nn, const int *d_mask, void *stream) {
+  if (S->stage.nb > 0 && !getenv("RLDL_NO_STAGE_FACTOR")) return rldl_launch_stage_factor(S, Nn, d_mask, 0, stream);
   return launch_factor(S, Nn, d_mask, 0, stream);
 }
 

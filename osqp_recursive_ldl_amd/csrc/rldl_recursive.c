@@ -15,11 +15,145 @@
  */
 #include <hip/hip_runtime_api.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "../../include/osqp_rldl_hip.h"
 #include "rldl_device.h"
 #include "rldl_internal.h"
 #include "rldl_symbolic.h"
+
+/* ---------------------------------------------------------------------------------------------------
+ * Stage blocks of the interleaved order  Q0, C0, Q1, C1, ..., Q_N, C_N  (compute_permutations,
+ * src/recursive_ldl.c:1350-1362): sizes nu, (ny+nx, nx+nu) x (N-1), ny+nx, nx, nt.  The permuted KKT matrix and
+ * its factor are block tridiagonal over these blocks; build_stage_maps lists, per block, where every KKT value and
+ * every L entry sits in a dense tile, which is all k_stage_factor needs (csrc/rldl_device.h: rldl_dev_stage).
+ * Host copy of the block starts: h->rec = int[nb + 2] = { nb, bs[0..nb] }.
+ * --------------------------------------------------------------------------------------------------- */
+#define STAGE_BLOCK_MAX 32
+
+static int *upload_ints(const int *src, size_t count) {
+  int *d = 0;
+  if (hipMalloc((void **)&d, sizeof(int) * (count ? count : 1)) != hipSuccess) return 0;
+  if (count && hipMemcpy(d, src, sizeof(int) * count, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return 0; }
+  return d;
+}
+
+void rldl_stage_maps_free(rldl_batch *h) {
+  rldl_dev_stage *G;
+  if (!h) return;
+  G = &h->dsym.stage;
+#define FRI(p) if (p) (void)hipFree((void *)(p))
+  FRI(G->bs); FRI(G->kd_ptr); FRI(G->kd_src); FRI(G->kd_pos); FRI(G->kc_ptr); FRI(G->kc_src); FRI(G->kc_pos);
+  FRI(G->ld_ptr); FRI(G->ld_slot); FRI(G->ld_pos); FRI(G->lc_ptr); FRI(G->lc_slot); FRI(G->lc_pos);
+#undef FRI
+  memset(G, 0, sizeof(*G));
+  free(h->rec); h->rec = 0;
+}
+
+/* 0: maps built and uploaded (h->dsym.stage.nb > 0); 1: the pattern does not qualify (generic kernels stay in use) */
+static int build_stage_maps(rldl_batch *h) {
+  const rldl_symbolic *s = h->sym;
+  const rldl_stage_dims *d = &h->stage;
+  const int N = s->N, nb = 2 * (int)d->N + 2;
+  int *bs = 0, *blk = 0, *cnt = 0, *ptr[4] = {0, 0, 0, 0}, *a[4] = {0, 0, 0, 0}, *b[4] = {0, 0, 0, 0}, *fill = 0;
+  int i, j, k, p, smax = 0, ld, rc = 1, tot[4] = {0, 0, 0, 0};
+  rldl_dev_stage G;
+  memset(&G, 0, sizeof(G));
+  bs = (int *)malloc(sizeof(int) * (size_t)(nb + 2));
+  blk = (int *)malloc(sizeof(int) * (size_t)(N + 1));
+  cnt = (int *)calloc((size_t)4 * (size_t)(nb + 1), sizeof(int));
+  fill = (int *)calloc((size_t)4 * (size_t)(nb + 1), sizeof(int));
+  if (!bs || !blk || !cnt || !fill) goto out;
+  bs[0] = 0; k = 1;
+  bs[1] = (int)d->nu;                                                                 /* Q0 */
+  for (i = 1; i < d->N; i++) { bs[k + 1] = bs[k] + (int)(d->ny + d->nx); k++; bs[k + 1] = bs[k] + (int)(d->nx + d->nu); k++; }
+  bs[k + 1] = bs[k] + (int)(d->ny + d->nx); k++;                                      /* C_{N-1} */
+  bs[k + 1] = bs[k] + (int)d->nx; k++;                                                /* Q_N */
+  bs[k + 1] = bs[k] + (int)d->nt; k++;                                                /* C_N */
+  if (k != nb || bs[nb] != N) goto out;
+  for (k = 0; k < nb; k++) {
+    if (bs[k + 1] - bs[k] > smax) smax = bs[k + 1] - bs[k];
+    if (bs[k + 1] <= bs[k]) goto out;                                                 /* empty blocks are not handled */
+    for (i = bs[k]; i < bs[k + 1]; i++) blk[i] = k;
+  }
+  if (smax > STAGE_BLOCK_MAX) goto out;
+  ld = smax | 1;                                                                      /* odd leading dimension: fewer LDS bank conflicts */
+  /* pass 1: classify and count; lists: 0 = K diagonal, 1 = K coupling, 2 = L diagonal, 3 = L coupling */
+  for (j = 0; j < N; j++)
+    for (p = s->Kp[j]; p < s->Kp[j + 1]; p++) {
+      i = s->Ki[p];
+      if (blk[i] == blk[j]) cnt[0 * (nb + 1) + blk[j]]++;
+      else if (blk[i] + 1 == blk[j]) cnt[1 * (nb + 1) + blk[i]]++;
+      else goto out;                                                                  /* not block tridiagonal */
+    }
+  for (j = 0; j < N; j++)
+    for (p = s->Lp[j]; p < s->Lp[j + 1]; p++) {
+      i = s->Li[p];
+      if (blk[i] == blk[j]) cnt[2 * (nb + 1) + blk[j]]++;
+      else if (blk[i] == blk[j] + 1) cnt[3 * (nb + 1) + blk[j]]++;
+      else goto out;
+    }
+  for (k = 0; k < 4; k++) {
+    ptr[k] = (int *)malloc(sizeof(int) * (size_t)(nb + 1));
+    if (!ptr[k]) goto out;
+    ptr[k][0] = 0;
+    for (i = 0; i < nb; i++) ptr[k][i + 1] = ptr[k][i] + cnt[k * (nb + 1) + i];
+    tot[k] = ptr[k][nb];
+    a[k] = (int *)malloc(sizeof(int) * (size_t)(tot[k] + 1));
+    b[k] = (int *)malloc(sizeof(int) * (size_t)(tot[k] + 1));
+    if (!a[k] || !b[k]) goto out;
+  }
+  /* pass 2: fill.  Tile positions are row * ld + col with the LATER index as the row (lower triangle / block below) */
+  for (j = 0; j < N; j++)
+    for (p = s->Kp[j]; p < s->Kp[j + 1]; p++) {
+      i = s->Ki[p];                                                                   /* i <= j: entry K(j, i) of the lower part */
+      if (blk[i] == blk[j]) { k = 0; }
+      else k = 1;
+      {
+        const int bb = k == 0 ? blk[j] : blk[i];
+        const int e = ptr[k][bb] + fill[k * (nb + 1) + bb]++;
+        a[k][e] = p;
+        b[k][e] = (j - bs[blk[j]]) * ld + (i - bs[blk[i]]);
+      }
+    }
+  for (j = 0; j < N; j++)
+    for (p = s->Lp[j]; p < s->Lp[j + 1]; p++) {
+      i = s->Li[p];                                                                   /* i > j: entry L(i, j) */
+      k = blk[i] == blk[j] ? 2 : 3;
+      {
+        const int bb = blk[j];
+        const int e = ptr[k][bb] + fill[k * (nb + 1) + bb]++;
+        a[k][e] = s->LtoS[p];
+        b[k][e] = (i - bs[blk[i]]) * ld + (j - bs[blk[j]]);
+      }
+    }
+  G.nb = nb; G.ld = ld; G.smax = smax;
+  G.bs = upload_ints(bs, (size_t)nb + 1);
+  G.kd_ptr = upload_ints(ptr[0], (size_t)nb + 1); G.kd_src = upload_ints(a[0], (size_t)tot[0]); G.kd_pos = upload_ints(b[0], (size_t)tot[0]);
+  G.kc_ptr = upload_ints(ptr[1], (size_t)nb + 1); G.kc_src = upload_ints(a[1], (size_t)tot[1]); G.kc_pos = upload_ints(b[1], (size_t)tot[1]);
+  G.ld_ptr = upload_ints(ptr[2], (size_t)nb + 1); G.ld_slot = upload_ints(a[2], (size_t)tot[2]); G.ld_pos = upload_ints(b[2], (size_t)tot[2]);
+  G.lc_ptr = upload_ints(ptr[3], (size_t)nb + 1); G.lc_slot = upload_ints(a[3], (size_t)tot[3]); G.lc_pos = upload_ints(b[3], (size_t)tot[3]);
+  h->dsym.stage = G;
+  if (!G.bs || !G.kd_ptr || !G.kd_src || !G.kd_pos || !G.kc_ptr || !G.kc_src || !G.kc_pos || !G.ld_ptr || !G.ld_slot || !G.ld_pos ||
+      !G.lc_ptr || !G.lc_slot || !G.lc_pos) { rldl_stage_maps_free(h); goto out; }
+  h->rec = malloc(sizeof(int) * (size_t)(nb + 2));
+  if (!h->rec) { rldl_stage_maps_free(h); goto out; }
+  ((int *)h->rec)[0] = nb;
+  memcpy((int *)h->rec + 1, bs, sizeof(int) * (size_t)(nb + 1));
+  rc = 0;
+out:
+  free(bs); free(blk); free(cnt); free(fill);
+  for (k = 0; k < 4; k++) { free(ptr[k]); free(a[k]); free(b[k]); }
+  return rc;
+}
+
+/* Mark a handle as stage-structured: enables restart-from-stage and, when the pattern qualifies, the dense
+ * stage-block factorisation for every later numeric factorisation of the handle. */
+void rldl_batch_enable_stage(rldl_batch *h, const rldl_stage_dims *dims) {
+  h->stage = *dims;
+  h->recursive = 1;
+  if (!getenv("RLDL_NO_STAGE_FACTOR")) (void)build_stage_maps(h);
+}
 
 /* first column (in the permuted matrix) of cost block Q_k, k = 0..N */
 static c_int stage_first_col(const rldl_stage_dims *d, c_int k) {
@@ -42,8 +176,13 @@ c_int rldl_batch_init_recursive(rldl_batch **hp, c_int batch, const rldl_stage_d
   rc = rldl_batch_init(hp, batch, P, A, d_Px, d_Ax, sigma, d_rho_vec, 0, perm, stream);
   free(perm);
   if (rc) return rc;
-  (*hp)->stage = *dims;
-  (*hp)->recursive = 1;
+  rldl_batch_enable_stage(*hp, dims);
+  if ((*hp)->dsym.stage.nb > 0) {                               /* the factor of record comes from the stage kernel */
+    if (rldl_launch_stage_factor(&(*hp)->dsym, &(*hp)->num, 0, 0, (*hp)->stream) || rldl_batch_check_status(*hp)) {
+      rldl_batch_free(*hp); *hp = 0;
+      return RLDL_NONCVX_ERROR;
+    }
+  }
   return 0;
 }
 
@@ -53,7 +192,13 @@ c_int rldl_batch_update_from_stage(rldl_batch *h, c_int first_stage, const c_flo
   if (!h || !h->recursive || first_stage < 0 || first_stage > h->stage.N) return 1;
   col0 = stage_first_col(&h->stage, first_stage);
   if (rldl_launch_kkt_assemble(&h->dsym, &h->num, d_Px, d_Ax, d_rho_vec, 0, 0, h->stream)) return 1;
-  if (rldl_launch_factor_from(&h->dsym, &h->num, (int)col0, h->stream)) return 1;
+  if (h->dsym.stage.nb > 0 && h->rec) {                         /* dense stage blocks: restart at the block of Q_first_stage */
+    const int *bs = (const int *)h->rec + 1, nb = ((const int *)h->rec)[0];
+    int b = 0;
+    while (b < nb && bs[b] < col0) b++;
+    if (b >= nb || bs[b] != col0) return 1;
+    if (rldl_launch_stage_factor(&h->dsym, &h->num, 0, b, h->stream)) return 1;
+  } else if (rldl_launch_factor_from(&h->dsym, &h->num, (int)col0, h->stream)) return 1;
   return rldl_batch_check_status(h);
 }
 
@@ -167,7 +312,7 @@ c_int osqp_batch_setup_recursive(osqp_batch **wp, c_int batch, const rldl_stage_
   if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) goto out;
   rldl_stage_permutation(dims->N, dims->nx, dims->nu, dims->ny, dims->nt, perm);
   rc = osqp_batch_setup(wp, batch, P, A, d_Px, d_Ax, d_q, d_l, d_u, settings, perm, stream);
-  if (!rc) { (*wp)->ls->stage = *dims; (*wp)->ls->recursive = 1; }
+  if (!rc) rldl_batch_enable_stage((*wp)->ls, dims);
 out:
   free(perm);
   if (d_nom) (void)hipFree(d_nom);
