@@ -1274,6 +1274,119 @@ __global__ __launch_bounds__(WAVE) void k_stage_factor(rldl_dev_sym S, rldl_dev_
   if (lane == 0) Nn.status[inst] = zero ? -1 : npos;
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_stage_factor_r -- the same block recursion with the panel [S_b ; C_b] held ROW-PER-LANE IN REGISTERS (lane r owns
+// row r, SM = compile-time bound on the block width).  The rank-1 updates then cost one fma per column for the whole
+// panel; what a lane needs from other rows travels as LDS broadcast reads (one address for all lanes) or v_readlane,
+// so the LDS traffic of the LDS-resident version (which bounds it) drops by an order of magnitude.
+//   Schur   : w[k] -= sum_c (Lc[r][c] d_c) Lc[k][c]      own Lc row in registers, Lc[k][c] broadcast from LDS
+//   column j: d = w[j] of lane j (v_readlane); colj[r] = w[j] / d -> LDS; w[k] -= w[j] colj[k] for k > j (broadcast)
+// Entries above the diagonal of a row pick up garbage and are never read.  1/d: v_rcp_f64 + 3 Newton steps.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double recip_nr(double d) {
+  double x = __builtin_amdgcn_rcp(d);
+#pragma unroll
+  for (int it = 0; it < 3; it++) { const double e = fma(-d, x, 1.0); x = fma(x, e, x); }
+  return x;
+}
+
+template <int SM>
+__global__ __launch_bounds__(WAVE) void k_stage_factor_r(rldl_dev_sym S, rldl_dev_num Nn, const int *__restrict__ mask, int b0) {
+  const int inst = blockIdx.x, lane = threadIdx.x;
+  if (mask && !mask[inst]) return;
+  const rldl_dev_stage &G = S.stage;
+  const int ld = G.ld, nb = G.nb;
+  extern __shared__ double sh[];
+  // T: staging tile of the panel (2 smax rows); Lt: L(b, b-1) as broadcast source (smax rows); colj: pivot column (x2)
+  double *T = sh, *Lt = T + 2 * G.smax * ld, *dprev = Lt + G.smax * ld, *dcur = dprev + ld, *colj = dcur + ld;
+  const double *Kx = Nn.Kx + (size_t)inst * S.nnzK;
+  double *F = Nn.F + (size_t)inst * S.ldF, *Dv = Nn.D + (size_t)inst * S.N;
+  double w[SM], lcd[SM];
+  int npos = 0, zero = 0;
+  // every inner loop below runs to SM without range checks (checks would fence the LDS reads one by one): the tiles are
+  // SM + 1 wide (host: ld), zero outside the live block, so the surplus terms are exact zeros
+  for (int p = lane; p < 3 * G.smax * ld + 2 * ld + 128; p += WAVE) sh[p] = 0.0;
+  wave_sync();
+  for (int j = lane; j < G.bs[b0]; j += WAVE) npos += Dv[j] > 0.0 ? 1 : 0;        // pivots kept from the blocks before b0
+  if (b0 > 0) {                                                  // L(b0, b0-1) and D_{b0-1} back from the stored factor
+    const int sprev = G.bs[b0] - G.bs[b0 - 1], scur = G.bs[b0 + 1] - G.bs[b0];
+    for (int p = lane; p < scur * ld; p += WAVE) Lt[p] = 0.0;
+    wave_sync();
+    for (int e = G.lc_ptr[b0 - 1] + lane; e < G.lc_ptr[b0]; e += WAVE) Lt[G.lc_pos[e]] = F[G.lc_slot[e]];
+    for (int c = lane; c < sprev; c += WAVE) dprev[c] = Dv[G.bs[b0 - 1] + c];
+    wave_sync();
+  }
+  for (int b = b0; b < nb; b++) {
+    const int bs = G.bs[b], s = G.bs[b + 1] - bs, sp = b > 0 ? bs - G.bs[b - 1] : 0;
+    const int sn = b + 1 < nb ? G.bs[b + 2] - G.bs[b + 1] : 0, R = s + sn;
+    // 1. KKT values of the diagonal block and of the coupling block below it -> staging tile -> own row
+    for (int p = lane; p < R * ld; p += WAVE) T[p] = 0.0;
+    wave_sync();
+    for (int e = G.kd_ptr[b] + lane; e < G.kd_ptr[b + 1]; e += WAVE) T[G.kd_pos[e]] = Kx[G.kd_src[e]];
+    if (sn)
+      for (int e = G.kc_ptr[b] + lane; e < G.kc_ptr[b + 1]; e += WAVE) T[s * ld + G.kc_pos[e]] = Kx[G.kc_src[e]];
+    wave_sync();
+    const double *myT = T + (lane < R ? lane : 0) * ld, *myL = Lt + (lane < s ? lane : 0) * ld;
+#pragma unroll
+    for (int c = 0; c < SM; c++) {
+      w[c] = myT[c];
+      lcd[c] = myL[c] * dprev[c];                                // own row of L(b, b-1) times D_{b-1} (rows of S_b only)
+    }
+    // 2. Schur complement of the previous block (rows of C_b: lcd is garbage-free zero? no -- they must stay untouched)
+    if (b > 0) {
+      const bool srow = lane < s;
+#pragma unroll
+      for (int k = 0; k < SM; k++) {
+        if (k < s) {                                             // uniform
+          const double *lk = Lt + k * ld;
+          double acc = 0.0;
+#pragma unroll
+          for (int c = 0; c < SM; c++) acc = fma(lcd[c], lk[c], acc);   // lk[c]: one address for the whole wave
+          if (srow) w[k] -= acc;
+        }
+      }
+    }
+    wave_sync();                                                 // T, Lt are free again
+    // 3. right-looking elimination of the panel
+#pragma unroll
+    for (int j = 0; j < SM; j++) {
+      if (j < s) {                                               // uniform
+        const double d = readlane_f64(w[j], j);
+        if (d == 0.0) zero = 1;                                  // QDLDL contract: zero pivot -> -1
+        if (lane == 0) { if (d > 0.0) npos++; dcur[j] = d; }
+        const double dinv = recip_nr(d);
+        const double a = w[j];                                   // unscaled W[r][j]
+        const double l = a * dinv;
+        double *cj = colj + (j & 1) * 64;                        // two buffers: the next column's writes need no barrier
+        cj[lane] = l;
+        if (lane > j) w[j] = l;
+        wave_sync();
+#pragma unroll
+        for (int k = j + 1; k < SM; k++) w[k] = fma(-a, cj[k], w[k]);   // rows <= j only touch their dead upper part; k >= s: unused registers
+      }
+    }
+    // 4. outputs: rows back to the tile, then D, Dinv, L_bb and L(b+1, b) into the factor's slots
+    wave_sync();
+    if (lane < R) {
+      double *o = T + lane * ld;
+#pragma unroll
+      for (int c = 0; c < SM; c++) o[c] = c < s ? w[c] : 0.0;   // (keeps the tile zero outside the block)
+    }
+    wave_sync();
+    for (int j = lane; j < s; j += WAVE) { const double d = dcur[j]; Dv[bs + j] = d; F[S.nS + bs + j] = 1.0 / d; }
+    for (int e = G.ld_ptr[b] + lane; e < G.ld_ptr[b + 1]; e += WAVE) F[G.ld_slot[e]] = T[G.ld_pos[e]];
+    if (sn) {
+      for (int e = G.lc_ptr[b] + lane; e < G.lc_ptr[b + 1]; e += WAVE) F[G.lc_slot[e]] = T[s * ld + G.lc_pos[e]];
+      for (int p = lane; p < sn * ld; p += WAVE) Lt[p] = T[s * ld + p];              // L(b+1, b): broadcast source of the next block
+      double *tp = dprev; dprev = dcur; dcur = tp;
+    }
+    wave_sync();
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) npos += __shfl_xor(npos, o);
+  if (lane == 0) Nn.status[inst] = zero ? -1 : npos;
+}
+
 // ================================================================================================
 // Arrowhead specialisation (plan->arrow_ok): all out-of-group entries feed ONE dense group (the Schur
 // tail of a KKT matrix ordered by minimum degree) and no other group has a triangle.  Then
@@ -1842,8 +1955,17 @@ extern "C" int rldl_launch_stage_factor(const rldl_dev_sym *S, const rldl_dev_nu
   if (Nn->batch <= 0) return 0;
   const rldl_dev_stage *G = &S->stage;
   if (G->nb <= 0 || first_block < 0 || first_block >= G->nb) return -1;
-  const size_t lds = sizeof(double) * (size_t)(3 * G->smax * G->ld + 2 * G->ld);
-  hipLaunchKernelGGL(k_stage_factor, dim3(Nn->batch), dim3(WAVE), lds, (hipStream_t)stream, *S, *Nn, d_mask, first_block);
+  if (getenv("RLDL_STAGE_LDS") || G->smax > 32) {                // LDS-resident panel (reference version of the same recursion)
+    const size_t lds = sizeof(double) * (size_t)(3 * G->smax * G->ld + 2 * G->ld);
+    hipLaunchKernelGGL(k_stage_factor, dim3(Nn->batch), dim3(WAVE), lds, (hipStream_t)stream, *S, *Nn, d_mask, first_block);
+    return launch_status();
+  }
+  const size_t lds = sizeof(double) * (size_t)(3 * G->smax * G->ld + 2 * G->ld + 128);
+  const dim3 grid(Nn->batch), blk(WAVE);
+  if (G->smax <= 8) hipLaunchKernelGGL(k_stage_factor_r<8>, grid, blk, lds, (hipStream_t)stream, *S, *Nn, d_mask, first_block);
+  else if (G->smax <= 16) hipLaunchKernelGGL(k_stage_factor_r<16>, grid, blk, lds, (hipStream_t)stream, *S, *Nn, d_mask, first_block);
+  else if (G->smax <= 24) hipLaunchKernelGGL(k_stage_factor_r<24>, grid, blk, lds, (hipStream_t)stream, *S, *Nn, d_mask, first_block);
+  else hipLaunchKernelGGL(k_stage_factor_r<32>, grid, blk, lds, (hipStream_t)stream, *S, *Nn, d_mask, first_block);
   return launch_status();
 }
 

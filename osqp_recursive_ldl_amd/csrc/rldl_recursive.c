@@ -77,7 +77,7 @@ static int build_stage_maps(rldl_batch *h) {
     for (i = bs[k]; i < bs[k + 1]; i++) blk[i] = k;
   }
   if (smax > STAGE_BLOCK_MAX) goto out;
-  ld = smax | 1;                                                                      /* odd leading dimension: fewer LDS bank conflicts */
+  ld = ((smax + 7) & ~7) + 1;                                                         /* register-kernel bound SM = 8/16/24/32, tiles SM + 1 wide (odd) */
   /* pass 1: classify and count; lists: 0 = K diagonal, 1 = K coupling, 2 = L diagonal, 3 = L coupling */
   for (j = 0; j < N; j++)
     for (p = s->Kp[j]; p < s->Kp[j + 1]; p++) {
