@@ -96,9 +96,7 @@ int rldl_launch_set_range(int batch, int ld, int start, int cnt, double *dst, co
 int rldl_launch_admm_iters(const rldl_dev_sym *S, const rldl_dev_num *Nn, const rldl_dev_admm *W, int iters, void *stream);
 int rldl_launch_admm_check(const rldl_dev_sym *S, const rldl_dev_admm *W, int iter, int approximate, int final_pass,
                            void *stream);
-int rldl_launch_admm_adapt_rho(const rldl_dev_sym *S, const rldl_dev_admm *W, void *stream);
 int rldl_launch_set_rho_vec(const rldl_dev_sym *S, const rldl_dev_admm *W, int init, void *stream);
-int rldl_launch_finalize(const rldl_dev_sym *S, const rldl_dev_admm *W, int max_iter, void *stream);
 /* scale_data / unscale_data (src/scaling.c:44-173) on the workspace's own copies of P, A, q, l, u */
 int rldl_launch_scale_data(const rldl_dev_sym *S, const rldl_dev_admm *W, double *Px, double *Ax, double *q, double *l, double *u,
                            int iters, void *stream);

@@ -7,13 +7,19 @@
 // 512-byte rows; all index arrays describe the shared sparsity pattern and stay L2-resident.
 //
 // Kernels and the reference code each one replaces:
-//   k_kkt_assemble : update_KKT_P/A/param2            src/kkt.c:184-222  (+ rho_inv = 1/rho, qdldl_interface.c:609-611)
-//   k_factor       : QDLDL_factor (numeric LDL')       call sites qdldl_interface.c:74-77, :598-600, :616-618
-//   k_solve        : permute_x, QDLDL_solve, permutet_x, z-tilde epilogue   qdldl_interface.c:538-585
-//   k_admm_iter    : compute_rhs, solve, update_x, update_z+project, update_y   src/auxil.c:164-228, src/proj.c:4-14
-//   k_admm_check   : update_info, check_termination, adapt_rho   src/auxil.c:13-77, :243-515, :567-626, :684-789
-//   k_set_rho_vec  : set_rho_vec / update_rho_vec      src/auxil.c:79-145
-//   k_finalize     : tail of osqp_solve                src/osqp.c:541-641, store_solution src/auxil.c:527-565
+//   k_kkt_assemble   : update_KKT_P/A/param2            src/kkt.c:184-222  (+ rho_inv = 1/rho, qdldl_interface.c:609-611)
+//   k_factor         : QDLDL_factor (numeric LDL'), generic sparse, right-looking; restart at a column
+//                      call sites qdldl_interface.c:74-77, :598-600, :616-618
+//   k_stage_factor_r : the same factor by dense stage blocks for MPC patterns (k_stage_factor: LDS-resident variant)
+//                      src/recursive_ldl.c:554-935, :1139-1318; restart at a block :946-1110
+//   k_arrow_solve / k_plan_solve / k_solve : permute_x, QDLDL_solve, permutet_x, z-tilde epilogue
+//                      qdldl_interface.c:538-585 (arrowhead plan / grouped plan / generic column sweep)
+//   k_arrow_admm / k_plan_admm / k_plan_admm_loop / k_admm_iter : compute_rhs, solve, update_x, update_z + project,
+//                      update_y   src/auxil.c:164-228, src/proj.c:4-14 (k_arrow_admm: a group of iterations per launch)
+//   k_admm_check     : update_info, check_termination, adapt_rho, tail of osqp_solve, store_solution
+//                      src/auxil.c:13-77, :243-515, :527-626, :684-789, src/osqp.c:541-641
+//   k_set_rho_vec    : set_rho_vec / update_rho_vec      src/auxil.c:79-145
+//   k_scale_data / k_unscale_data / k_ew_scale : scale_data, unscale_data, scaled updates   src/scaling.c:44-192
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -312,12 +318,6 @@ __device__ __forceinline__ void spmv_Psym(const rldl_dev_sym &S, const double *P
     out[j] = acc;
   }
 }
-__device__ __forceinline__ double norm_inf_lds(const double *v, int len, int lane) {
-  double mx = 0.0;
-  for (int i = lane; i < len; i += WAVE) { const double a = fabs(v[i]); mx = a > mx ? a : mx; }
-  return wave_max(mx);
-}
-
 // scaled infinity norm max_i |s_i v_i| (s == nullptr: plain norm)
 __device__ __forceinline__ double norm_inf_s(const double *s, const double *v, int len, int lane) {
   double mx = 0.0;
@@ -1317,7 +1317,7 @@ __global__ __launch_bounds__(WAVE) void k_stage_factor_r(rldl_dev_sym S, rldl_de
     wave_sync();
   }
   for (int b = b0; b < nb; b++) {
-    const int bs = G.bs[b], s = G.bs[b + 1] - bs, sp = b > 0 ? bs - G.bs[b - 1] : 0;
+    const int bs = G.bs[b], s = G.bs[b + 1] - bs;
     const int sn = b + 1 < nb ? G.bs[b + 2] - G.bs[b + 1] : 0, R = s + sn;
     // 1. KKT values of the diagonal block and of the coupling block below it -> staging tile -> own row
     for (int p = lane; p < R * ld; p += WAVE) T[p] = 0.0;
@@ -2047,10 +2047,6 @@ extern "C" int rldl_launch_admm_check(const rldl_dev_sym *S, const rldl_dev_admm
   return launch_status();
 }
 
-extern "C" int rldl_launch_admm_adapt_rho(const rldl_dev_sym *S, const rldl_dev_admm *W, void *stream) {
-  (void)S; (void)W; (void)stream;
-  return 0; /* folded into k_admm_check (mode bit CHK_ADAPT) */
-}
 
 extern "C" int rldl_launch_set_rho_vec(const rldl_dev_sym *S, const rldl_dev_admm *W, int init, void *stream) {
   if (W->batch <= 0) return 0;
@@ -2058,10 +2054,6 @@ extern "C" int rldl_launch_set_rho_vec(const rldl_dev_sym *S, const rldl_dev_adm
   return launch_status();
 }
 
-extern "C" int rldl_launch_finalize(const rldl_dev_sym *S, const rldl_dev_admm *W, int max_iter, void *stream) {
-  (void)S; (void)W; (void)max_iter; (void)stream;
-  return 0; /* folded into k_admm_check (mode bit CHK_FINAL) */
-}
 
 extern "C" int rldl_launch_scale_data(const rldl_dev_sym *S, const rldl_dev_admm *W, double *Px, double *Ax, double *q, double *l,
                                       double *u, int iters, void *stream) {

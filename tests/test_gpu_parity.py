@@ -438,3 +438,23 @@ def test_full_size_batch_4096_properties(R):
     assert torch.equal(r["x"][0], r["x"][1]) and torch.equal(r["x"][0], r["x"][4095])
     assert bool(torch.isfinite(r["x"]).all())
     w.cleanup()
+
+
+def test_resident_iterations_equal_single_iteration_launches(R):
+    """The fused kernel keeps an instance's factor and iterates on chip for a whole group of iterations; running the
+    same number of iterations as separate one-iteration launches (state through HBM every time) must give the same
+    iterates bit for bit, and a solve split by termination checks must match the oracle's iteration count."""
+    wl = R.workloads.SharedPatternQPs()
+    B = 8
+    Px, Ax, q, l, u = wl.values(B)
+    K = 37
+    kw = dict(rho=0.1, sigma=1e-6, alpha=1.6, max_iter=K, check_termination=0, adaptive_rho=0, warm_start=0, scaling=0)
+    a = R.OSQPBatch(wl.P_pattern, wl.A_pattern, dev(Px), dev(Ax), dev(q), dev(l), dev(u), **kw)
+    ra = a.solve()
+    assert a.last_loop()[1] == K and a.last_loop()[2] == 1          # one launch for the whole group
+    b = R.OSQPBatch(wl.P_pattern, wl.A_pattern, dev(Px), dev(Ax), dev(q), dev(l), dev(u), **kw)
+    b.time_iteration(K)                                               # K launches of one iteration each, from the cold start
+    rb = b.results()
+    for key in ("x_iter", "y_iter", "z"):
+        assert torch.equal(ra[key], rb[key]), key
+    a.cleanup(); b.cleanup()
