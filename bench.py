@@ -85,7 +85,7 @@ def main():
     def step():
         if w.update_P_A(dPx, dAx):                           # KKT value scatter + numeric factor of every instance
             raise RuntimeError("refactor failed")
-        res = w.solve()                                      # 200 fused ADMM iterations + final info
+        res = w.solve(clone=False)                           # 200 fused ADMM iterations + final info (views, no copies)
         if world > 1:
             res = rdist.gather_results(res, n, m)            # the path's only collective
         return res

@@ -51,11 +51,8 @@ static double *dclone(const double *src, size_t count, void *stream, int *ok) {
   return d;
 }
 
-static int fill_int(osqp_batch *w, int *d, int value) {
-  c_int b;
-  for (b = 0; b < w->batch; b++) w->h_tmp_i[b] = value;
-  return HIP_OK(hipMemcpyAsync(d, w->h_tmp_i, sizeof(int) * (size_t)w->batch, hipMemcpyHostToDevice, (hipStream_t)w->stream)) &&
-                 HIP_OK(hipStreamSynchronize((hipStream_t)w->stream)) ? 0 : 1;
+static int fill_int(osqp_batch *w, int *d, int value) {  /* asynchronous 32-bit fill on the workspace stream: no host round trip */
+  return HIP_OK(hipMemsetD32Async((hipDeviceptr_t)d, value, (size_t)w->batch, (hipStream_t)w->stream)) ? 0 : 1;
 }
 static int fill_double(osqp_batch *w, double *d, double value) {
   c_int b;
@@ -217,8 +214,7 @@ c_int osqp_batch_solve(osqp_batch *w) {
   }
   if (fill_int(w, w->W.status, ST_UNSOLVED)) return 1;
   nact = (int)w->batch;
-  if (!HIP_OK(hipMemcpyAsync(w->W.n_active, &nact, sizeof(int), hipMemcpyHostToDevice, st))) return 1;
-  if (!HIP_OK(hipStreamSynchronize(st))) return 1;
+  if (!HIP_OK(hipMemsetD32Async((hipDeviceptr_t)w->W.n_active, nact, 1, st))) return 1;
 
   (void)hipEventRecord((hipEvent_t)w->ev0, st);
   iter = 0;

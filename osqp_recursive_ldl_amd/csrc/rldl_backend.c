@@ -73,6 +73,24 @@ static int upload_symbolic(rldl_batch *h) {
     D->arrow_g0 = s->plan[s->po_gstart + s->arrow_group];
     D->arrow_g = s->plan[s->po_gstart + s->arrow_group + 1] - D->arrow_g0;
     D->arrow_tb = s->plan[s->po_gflag + s->arrow_group] ? s->plan[s->po_gToff + s->arrow_group] - s->nOp : -1;
+    {                                                         /* k_arrow_factor: independent head columns, tail group at the very end */
+      int c, p, okf = D->arrow_tb >= 0 && D->arrow_g0 + D->arrow_g == s->N && D->arrow_g <= 64;
+      for (c = 0; c < D->arrow_g0 && okf; c++)
+        for (p = s->Lp[c]; p < s->Lp[c + 1]; p++)
+          if (s->Li[p] < D->arrow_g0) { okf = 0; break; }
+      D->arrow_dense = 0;
+      if (okf) {                                              /* workspace position of L(g0 + r, g0 + c), or -1: table [g][64] */
+        int *tp = (int *)malloc(sizeof(int) * (size_t)D->arrow_g * 64);
+        if (tp) {
+          for (p = 0; p < D->arrow_g * 64; p++) tp[p] = -1;
+          for (c = 0; c < D->arrow_g; c++)
+            for (p = s->Lp[D->arrow_g0 + c]; p < s->Lp[D->arrow_g0 + c + 1]; p++) tp[c * 64 + (s->Li[p] - D->arrow_g0)] = p;
+          D->arrow_tpos = (const int *)dev_upload(tp, sizeof(int) * (size_t)D->arrow_g * 64, &ok);
+          free(tp);
+          D->arrow_dense = D->arrow_tpos != 0;
+        }
+      }
+    }
     for (t = 0; t < 32; t++) {                                /* lanes whose virtual row has an entry at step t */
       const unsigned *vm = (const unsigned *)(s->plan + s->po_avmap);
       D->arrow_cnt[t] = 0;
@@ -89,7 +107,7 @@ static void free_dev_symbolic(rldl_dev_sym *D) {
 #define FR(f) if (D->f) (void)hipFree((void *)D->f)
   FR(perm); FR(PtoK); FR(AtoK); FR(rhotoK); FR(sigK); FR(Pisdiag); FR(Lp); FR(Li); FR(Rp); FR(Rj); FR(Rpos);
   FR(KtoW); FR(Udst); FR(Uab); FR(Up); FR(Pp); FR(Pi); FR(Prp); FR(Prj); FR(Prpos); FR(Ap); FR(Ai); FR(Arp);
-  FR(Arj); FR(Arpos); FR(LtoS); FR(plan);
+  FR(Arj); FR(Arpos); FR(LtoS); FR(plan); FR(arrow_tpos);
 #undef FR
   memset(D, 0, sizeof(*D));
 }

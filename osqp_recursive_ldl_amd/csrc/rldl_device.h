@@ -45,6 +45,8 @@ typedef struct {
   int arrow_vsteps, arrow_vrows;          /* virtual rows: coupling rows cut into pieces of <= vsteps entries, one piece per lane */
   int arrow_g0, arrow_g;       /* index range of the tail group */
   int arrow_tb;                /* its triangle base relative to slot nOp, or -1 */
+  int arrow_dense;             /* 1: every head column has entries only in the tail group, which ends the matrix (k_arrow_factor) */
+  const int *arrow_tpos;       /* [arrow_g][64]: CSC position of L(g0 + lane, g0 + c), or -1 */
   int arrow_cnt[32];           /* per virtual-row step: number of lanes with an entry (kernarg segment -> scalar loads) */
   rldl_dev_stage stage;        /* stage.nb > 0: block-tridiagonal pattern, numeric factorisation by dense stage blocks */
 } rldl_dev_sym;

@@ -1387,6 +1387,96 @@ __global__ __launch_bounds__(WAVE) void k_stage_factor_r(rldl_dev_sym S, rldl_de
   if (lane == 0) Nn.status[inst] = zero ? -1 : npos;
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_arrow_factor -- numeric LDL' for arrowhead patterns (S.arrow_dense): the head columns have entries only in the
+// dense tail group, so they do not see each other:
+//   head : D_c = K_cc, and all their rank-1 contributions to the tail are accumulated in ONE pass with LDS double
+//          atomics (the generic kernel walks the 100 head columns of the metric shape one barrier at a time);
+//   tail : the g x g Schur complement moves to registers, row per lane, and is eliminated like a stage block
+//          (pivot by v_readlane, pivot column through a 64-entry LDS buffer, one fma per column for the whole block).
+// Same outputs as k_factor (factor in plan slot order, D, Dinv, status); summation order of the Schur complement differs.
+// ------------------------------------------------------------------------------------------------
+template <int SM>
+__global__ __launch_bounds__(WAVE) void k_arrow_factor(rldl_dev_sym S, rldl_dev_num Nn, const int *__restrict__ mask) {
+  const int inst = blockIdx.x, lane = threadIdx.x;
+  if (mask && !mask[inst]) return;
+  extern __shared__ double sh[];                                  // W = [L values, CSC order | D] as in k_factor, then scratch
+  const int nW = S.nnzL + S.N, g0 = S.arrow_g0, g = S.arrow_g;
+  double *Wd = sh + S.nnzL, *dih = sh + nW, *colj = dih + ((g0 + 1) & ~1);
+  double *F = Nn.F + (size_t)inst * S.ldF, *Dg = Nn.D + (size_t)inst * S.N;
+  const double *K = Nn.Kx + (size_t)inst * S.nnzK;
+  for (int i = lane; i < nW; i += WAVE) sh[i] = 0.0;
+  wave_sync();
+  for (int k = lane; k < S.nnzK; k += WAVE) sh[S.KtoW[k]] = K[k];
+  wave_sync();
+  int npos = 0, zero = 0;
+  for (int j = lane; j < g0; j += WAVE) {                        // head pivots are final as they come
+    const double d = Wd[j];
+    if (d == 0.0) zero = 1;
+    if (d > 0.0) npos++;
+    dih[j] = 1.0 / d;
+  }
+  wave_sync();
+  // head: every pair (a, b) of column j adds -l_a l_b d_j to a tail entry; columns are independent -> no barrier, atomics
+  for (int j = 0; j < g0; j++) {
+    const int base = S.Lp[j];
+    const double dinv = dih[j];
+    for (long long t = S.Up[j] + lane; t < S.Up[j + 1]; t += WAVE) {
+      const unsigned ab = S.Uab[t];
+      unsafeAtomicAdd(&sh[S.Udst[t]], -(sh[base + (ab & 0xffffu)] * (sh[base + (ab >> 16)] * dinv)));
+    }
+  }
+  wave_sync();
+  for (int q = lane; q < S.nnzL; q += WAVE) {                    // l_rc = K_rc / d_c for the head columns (row-order walk: column known)
+    const int c = S.Rj[q];
+    if (c < g0) sh[S.Rpos[q]] *= dih[c];
+  }
+  // tail: Schur complement -> registers, row per lane; positions from the [g][64] table (-1: structural zero / c >= r)
+  double w[SM];
+  int tp[SM];
+  const int r = lane < g ? lane : g - 1;
+#pragma unroll
+  for (int c = 0; c < SM; c++) tp[c] = c < g ? S.arrow_tpos[c * 64 + r] : -1;
+  wave_sync();
+#pragma unroll
+  for (int c = 0; c < SM; c++) {
+    const double lo = sh[tp[c] >= 0 ? tp[c] : 0];
+    w[c] = tp[c] >= 0 ? lo : (c == r ? Wd[g0 + r] : 0.0);
+  }
+  wave_sync();
+#pragma unroll
+  for (int j = 0; j < SM; j++) {
+    if (j < g) {                                                 // uniform
+      const double d = readlane_f64(w[j], j);
+      if (d == 0.0) zero = 1;
+      if (lane == 0 && d > 0.0) npos++;
+      const double dinv = recip_nr(d);
+      const double a = w[j];
+      const double l = a * dinv;
+      double *cj = colj + (j & 1) * 64;
+      cj[lane] = lane < g ? l : 0.0;
+      if (lane > j) w[j] = l;
+      wave_sync();
+#pragma unroll
+      for (int k = j + 1; k < SM; k++) w[k] = fma(-a, cj[k], w[k]);
+    }
+  }
+  // back to the CSC workspace, then the common coalesced write-out in plan slot order
+  if (lane < g) {
+#pragma unroll
+    for (int c = 0; c < SM; c++) {
+      if (tp[c] >= 0) sh[tp[c]] = w[c];
+      else if (c == lane) Wd[g0 + lane] = w[c];
+    }
+  }
+  wave_sync();
+  for (int i = lane; i < S.nnzL; i += WAVE) F[S.LtoS[i]] = sh[i];
+  for (int j = lane; j < S.N; j += WAVE) { const double d = Wd[j]; Dg[j] = d; F[S.nS + j] = 1.0 / d; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { npos += __shfl_xor(npos, o); zero |= __shfl_xor(zero, o); }
+  if (lane == 0) Nn.status[inst] = zero ? -1 : npos;
+}
+
 // ================================================================================================
 // Arrowhead specialisation (plan->arrow_ok): all out-of-group entries feed ONE dense group (the Schur
 // tail of a KKT matrix ordered by minimum degree) and no other group has a triangle.  Then
@@ -1943,6 +2033,19 @@ extern "C" int rldl_launch_kkt_assemble(const rldl_dev_sym *S, const rldl_dev_nu
 
 static int launch_factor(const rldl_dev_sym *S, const rldl_dev_num *Nn, const int *d_mask, int c_start, void *stream) {
   if (Nn->batch <= 0) return 0;
+  if (c_start <= 0 && S->arrow_ok && S->arrow_dense && S->arrow_g <= 64 && !getenv("RLDL_NO_ARROW_FACTOR")) {
+    const size_t al = sizeof(double) * (size_t)(S->nnzL + S->N + S->arrow_g0 + 2 + 128);
+    if (al <= RLDL_LDS_LIMIT) {
+      const dim3 grid(Nn->batch), blk(WAVE);
+      const int g = S->arrow_g;
+      if (g <= 16) hipLaunchKernelGGL(k_arrow_factor<16>, grid, blk, al, (hipStream_t)stream, *S, *Nn, d_mask);
+      else if (g <= 32) hipLaunchKernelGGL(k_arrow_factor<32>, grid, blk, al, (hipStream_t)stream, *S, *Nn, d_mask);
+      else if (g <= 48) hipLaunchKernelGGL(k_arrow_factor<48>, grid, blk, al, (hipStream_t)stream, *S, *Nn, d_mask);
+      else if (g <= 56) hipLaunchKernelGGL(k_arrow_factor<56>, grid, blk, al, (hipStream_t)stream, *S, *Nn, d_mask);
+      else hipLaunchKernelGGL(k_arrow_factor<64>, grid, blk, al, (hipStream_t)stream, *S, *Nn, d_mask);
+      return launch_status();
+    }
+  }
   const size_t lds = sizeof(double) * (size_t)(S->nnzL + S->N);
   if (lds <= RLDL_LDS_LIMIT)
     hipLaunchKernelGGL(k_factor<true>, dim3(Nn->batch), dim3(WAVE), lds, (hipStream_t)stream, *S, *Nn, d_mask, c_start);

@@ -84,11 +84,13 @@ class OSQPBatch:
     def linsys(self):
         return BatchLinsys(self.P, self.A, None, None, 0, None, _handle=_lib.lib().osqp_batch_linsys(self.h), _owned=False)
 
-    def solve(self):
+    def solve(self, clone=True):
+        """osqp_solve for every instance.  clone=False returns zero-copy views of the workspace's result arrays (valid
+        until the next call that changes them) instead of a dozen device-to-device copies."""
         rc = _lib.lib().osqp_batch_solve(self.h)
         if rc:
             raise RuntimeError("osqp_batch_solve failed (%d)" % rc)
-        return self.results()
+        return self.results(clone=clone)
 
     def _view(self, ptr, shape, dtype):
         """Zero-copy torch view of a workspace-owned device array (valid until cleanup)."""
