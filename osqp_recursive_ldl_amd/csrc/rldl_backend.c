@@ -89,6 +89,25 @@ static int upload_symbolic(rldl_batch *h) {
           free(tp);
           D->arrow_dense = D->arrow_tpos != 0;
         }
+        /* flat list of the head columns' pair updates with absolute workspace positions:
+         * pab = posA | posB << 16, pdc = dst | column << 16 (all < 65536) */
+        if (D->arrow_dense && s->nnzL + s->N < 65536 && s->Up[D->arrow_g0] < (1ll << 30)) {
+          const long long P = s->Up[D->arrow_g0];
+          unsigned *pab = (unsigned *)malloc(sizeof(unsigned) * (size_t)(P + 1)), *pdc = (unsigned *)malloc(sizeof(unsigned) * (size_t)(P + 1));
+          long long t;
+          if (pab && pdc) {
+            for (c = 0; c < D->arrow_g0; c++)
+              for (t = s->Up[c]; t < s->Up[c + 1]; t++) {
+                pab[t] = (unsigned)(s->Lp[c] + (int)(s->Uab[t] & 0xffffu)) | ((unsigned)(s->Lp[c] + (int)(s->Uab[t] >> 16)) << 16);
+                pdc[t] = (unsigned)s->Udst[t] | ((unsigned)c << 16);
+              }
+            D->arrow_pab = (const unsigned *)dev_upload(pab, sizeof(unsigned) * (size_t)P, &ok);
+            D->arrow_pdc = (const unsigned *)dev_upload(pdc, sizeof(unsigned) * (size_t)P, &ok);
+            D->arrow_npairs = (int)P;
+          }
+          free(pab); free(pdc);
+          if (!D->arrow_pab || !D->arrow_pdc) D->arrow_dense = 0;
+        } else D->arrow_dense = 0;
       }
     }
     for (t = 0; t < 32; t++) {                                /* lanes whose virtual row has an entry at step t */
@@ -107,7 +126,7 @@ static void free_dev_symbolic(rldl_dev_sym *D) {
 #define FR(f) if (D->f) (void)hipFree((void *)D->f)
   FR(perm); FR(PtoK); FR(AtoK); FR(rhotoK); FR(sigK); FR(Pisdiag); FR(Lp); FR(Li); FR(Rp); FR(Rj); FR(Rpos);
   FR(KtoW); FR(Udst); FR(Uab); FR(Up); FR(Pp); FR(Pi); FR(Prp); FR(Prj); FR(Prpos); FR(Ap); FR(Ai); FR(Arp);
-  FR(Arj); FR(Arpos); FR(LtoS); FR(plan); FR(arrow_tpos);
+  FR(Arj); FR(Arpos); FR(LtoS); FR(plan); FR(arrow_tpos); FR(arrow_pab); FR(arrow_pdc);
 #undef FR
   memset(D, 0, sizeof(*D));
 }

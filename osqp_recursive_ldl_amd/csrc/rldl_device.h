@@ -47,6 +47,8 @@ typedef struct {
   int arrow_tb;                /* its triangle base relative to slot nOp, or -1 */
   int arrow_dense;             /* 1: every head column has entries only in the tail group, which ends the matrix (k_arrow_factor) */
   const int *arrow_tpos;       /* [arrow_g][64]: CSC position of L(g0 + lane, g0 + c), or -1 */
+  const unsigned *arrow_pab, *arrow_pdc;  /* head pair updates, flat: posA | posB << 16 and dst | column << 16 (workspace positions) */
+  int arrow_npairs;
   int arrow_cnt[32];           /* per virtual-row step: number of lanes with an entry (kernarg segment -> scalar loads) */
   rldl_dev_stage stage;        /* stage.nb > 0: block-tridiagonal pattern, numeric factorisation by dense stage blocks */
 } rldl_dev_sym;

@@ -1418,13 +1418,10 @@ __global__ __launch_bounds__(WAVE) void k_arrow_factor(rldl_dev_sym S, rldl_dev_
   }
   wave_sync();
   // head: every pair (a, b) of column j adds -l_a l_b d_j to a tail entry; columns are independent -> no barrier, atomics
-  for (int j = 0; j < g0; j++) {
-    const int base = S.Lp[j];
-    const double dinv = dih[j];
-    for (long long t = S.Up[j] + lane; t < S.Up[j + 1]; t += WAVE) {
-      const unsigned ab = S.Uab[t];
-      unsafeAtomicAdd(&sh[S.Udst[t]], -(sh[base + (ab & 0xffffu)] * (sh[base + (ab >> 16)] * dinv)));
-    }
+#pragma unroll 4
+  for (int t = lane; t < S.arrow_npairs; t += WAVE) {            // flat over all head columns: independent iterations
+    const unsigned ab = S.arrow_pab[t], dc = S.arrow_pdc[t];
+    unsafeAtomicAdd(&sh[dc & 0xffffu], -(sh[ab & 0xffffu] * (sh[ab >> 16] * dih[dc >> 16])));
   }
   wave_sync();
   for (int q = lane; q < S.nnzL; q += WAVE) {                    // l_rc = K_rc / d_c for the head columns (row-order walk: column known)
