@@ -1514,7 +1514,7 @@ __device__ __forceinline__ void arrow_load_idx(const rldl_dev_sym &S, int lane, 
   asm volatile("" : "+s"(off));
   const unsigned *ap = reinterpret_cast<const unsigned *>(S.plan + off);
 #pragma unroll
-  for (int t2 = 0; t2 < (TG + 1) / 2; t2++) I.ix[t2] = 2 * t2 < S.arrow_vsteps ? ap[t2 * 64 + lane] : 0u;
+  for (int t2 = 0; t2 < (TG + 1) / 2; t2++) I.ix[t2] = ap[t2 * 64 + lane];   // (table padded to TG steps by the host)
 }
 // Dinv of the tail and the register-resident triangle rows: straight from the factor row in HBM (coalesced)
 __device__ __forceinline__ void arrow_load_diag(const rldl_dev_sym &S, const double *Fg, int g0, int g, int rr, int lane, ArrowDiag &Dg) {
@@ -1537,7 +1537,7 @@ template <int TG>
 __device__ __forceinline__ void arrow_load_map(const rldl_dev_sym &S, int lane, ArrowIdx<TG> &M) {
   const unsigned *vm = reinterpret_cast<const unsigned *>(S.plan + S.po_avmap);
 #pragma unroll
-  for (int t2 = 0; t2 < (TG + 1) / 2; t2++) M.ix[t2] = 2 * t2 < S.arrow_vsteps ? vm[t2 * 64 + lane] : 0xffffffffu;
+  for (int t2 = 0; t2 < (TG + 1) / 2; t2++) M.ix[t2] = vm[t2 * 64 + lane];   // (table padded to TG steps by the host)
 }
 template <int TG>
 __device__ __forceinline__ void arrow_load_val(const double *Ov, const ArrowIdx<TG> &M, ArrowRegs<TG> &R) {
@@ -1695,15 +1695,16 @@ __global__ __launch_bounds__(256, 4) void k_arrow_solve(rldl_dev_sym S, rldl_dev
 // and the iterates are read from HBM once per launch instead of once per iteration; only l, u, rho and the head's
 // Dinv (3.2 KB, L2-resident) are re-fetched per iteration because the register file has no room for them during
 // the sweeps.  x, z, y (and delta_x / delta_y when a check follows) are stored after the last iteration.
-template <int TMAX, int TG>
+// TRACE: instantiation with the wave-timeline stores (osqp_batch_trace_iteration); the production kernel carries none.
+template <int TMAX, int TG, bool TRACE>
 __global__ __launch_bounds__(256, 4) void k_arrow_admm(rldl_dev_sym S, rldl_dev_num Nn, rldl_dev_admm W, ArrowGeom G, int iters) {
   extern __shared__ __attribute__((aligned(16))) double sh[];
   const int lane = threadIdx.x & (WAVE - 1), wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wpb = blockDim.x >> 6;
   const int inst = blockIdx.x * wpb + wv;
   if (inst >= Nn.batch) return;
   const int st = W.status[inst];                                // latency overlaps with the index loads below
-  long long *tr = W.trace ? W.trace + 8 * (size_t)inst : nullptr;
-  if (tr && lane == 0) tr[7] = wall_clock64();                  // wave start; slots 0..6 belong to the LAST iteration of the launch
+  long long *tr = TRACE && W.trace ? W.trace + 8 * (size_t)inst : nullptr;
+  if (TRACE && tr && lane == 0) tr[7] = wall_clock64();         // wave start; slots 0..6 belong to ONE iteration of the launch
   double *Tv = sh + (size_t)wv * G.per_wave;
   double *xs = Tv + G.xoff;
   const int *permg = S.plan + S.po_perm;
@@ -1748,7 +1749,7 @@ __global__ __launch_bounds__(256, 4) void k_arrow_admm(rldl_dev_sym S, rldl_dev_
 #pragma clang loop unroll(disable)
   for (int it = 0; it < iters; it++) {
     const bool last = it + 1 == iters;
-    const bool trit = tr && (W.trace_iter < 0 ? last : it == W.trace_iter);
+    const bool trit = TRACE && tr && (W.trace_iter < 0 ? last : it == W.trace_iter);
     if (trit && lane == 0) tr[0] = wall_clock64();
     // keep the per-lane index data opaque per iteration: otherwise every LDS / global address derived from it is
     // hoisted out of the loop and the 24 gather addresses alone cost 24 VGPRs of the 128 a wave may hold
@@ -1997,10 +1998,13 @@ template <int TMAX, int TG>
 static int launch_arrow_admm_t(const rldl_dev_sym *S, const rldl_dev_num *Nn, const rldl_dev_admm *W, int iters, void *stream) {
   size_t lds = 0;
   const ArrowGeom G = arrow_geometry(S);
-  const int wpb = arrow_pick_wpb(S, (const void *)k_arrow_admm<TMAX, TG>, G, &lds);
+  const int wpb = arrow_pick_wpb(S, (const void *)k_arrow_admm<TMAX, TG, false>, G, &lds);
   if (wpb <= 0) return -1;
-  if (lds > 64 * 1024 && hipFuncSetAttribute((const void *)k_arrow_admm<TMAX, TG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
-  hipLaunchKernelGGL((k_arrow_admm<TMAX, TG>), dim3((Nn->batch + wpb - 1) / wpb), dim3(wpb * WAVE), lds, (hipStream_t)stream, *S, *Nn, *W, G, iters);
+  if (lds > 64 * 1024 && hipFuncSetAttribute((const void *)k_arrow_admm<TMAX, TG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+  if (W->trace)
+    hipLaunchKernelGGL((k_arrow_admm<TMAX, TG, true>), dim3((Nn->batch + wpb - 1) / wpb), dim3(wpb * WAVE), lds, (hipStream_t)stream, *S, *Nn, *W, G, iters);
+  else
+    hipLaunchKernelGGL((k_arrow_admm<TMAX, TG, false>), dim3((Nn->batch + wpb - 1) / wpb), dim3(wpb * WAVE), lds, (hipStream_t)stream, *S, *Nn, *W, G, iters);
   return launch_status();
 }
 template <int TMAX>

@@ -38,7 +38,7 @@ int rldl_plan_build(rldl_symbolic *s) {
   unsigned char *col_active = 0, *row_active = 0;
   kv *order = 0;
   int ng = 0, i, k, c, p, q, nO = 0, nOp = 0, tri = 0, na = 0, nr = 0, words, nfs = 0, nbs = 0, rc = -2;
-  int arrow_k = -1, arrow_steps = 0, ngather = 0, ntri = 0;
+  int arrow_k = -1, arrow_steps = 0, ngather = 0, ntri = 0, vpad = 0;
 
   s->plan_ok = 0;
   s->LtoS = (int *)malloc(sizeof(int) * (size_t)(s->nnzL > 0 ? s->nnzL : 1));
@@ -175,8 +175,14 @@ int rldl_plan_build(rldl_symbolic *s) {
     if (T > 32) s->arrow_ok = 0;
     else { s->arrow_vsteps = T; s->arrow_vrows = nv; }
   }
-  s->po_avmap = words; words += s->arrow_ok ? ((s->arrow_vsteps + 1) / 2) * 64 : 0;   /* dword [ceil(T/2)][64]: slot(t even) | slot(t odd) << 16, 0xffff = none */
-  s->po_avcol = words; words += s->arrow_ok ? ((s->arrow_vsteps + 1) / 2) * 64 : 0;   /* same packing, column index (0 where there is no entry) */
+  /* The tables are padded to the register bound the kernels are compiled for (8, 12, 14, 16, 18, 24 steps, see
+   * launch_arrow_*), so the device reads them without range checks. */
+  {
+    const int T = s->arrow_vsteps;
+    vpad = T <= 8 ? 8 : T <= 12 ? 12 : T <= 14 ? 14 : T <= 16 ? 16 : T <= 18 ? 18 : T <= 24 ? 24 : ((T + 1) & ~1);
+  }
+  s->po_avmap = words; words += s->arrow_ok ? ((vpad + 1) / 2) * 64 : 0;   /* dword [ceil(Tpad/2)][64]: slot(t even) | slot(t odd) << 16, 0xffff = none */
+  s->po_avcol = words; words += s->arrow_ok ? ((vpad + 1) / 2) * 64 : 0;   /* same packing, column index (0 where there is no entry) */
   s->po_avrow = words; words += s->arrow_ok ? 64 : 0;                                 /* row (permuted index) of the lane's piece */
   blob = (int *)calloc((size_t)words + 4, sizeof(int));
   if (!blob) goto out;
@@ -239,7 +245,7 @@ int rldl_plan_build(rldl_symbolic *s) {
       }
       qsort(pieces, (size_t)np, sizeof(kv), cmp_kv_desc);
       for (l = 0; l < 64; l++) vrow[l] = 0;
-      for (t = 0; t < ((T + 1) / 2) * 64; t++) { vmap[t] = 0xffffffffu; vcol[t] = 0u; }
+      for (t = 0; t < ((vpad + 1) / 2) * 64; t++) { vmap[t] = 0xffffffffu; vcol[t] = 0u; }
       for (l = 0; l < np; l++) {
         const int src = pieces[l].idx, r = rows_of[src], e0 = e0_of[src], len = pieces[l].key;
         vrow[l] = r;
