@@ -458,3 +458,33 @@ def test_resident_iterations_equal_single_iteration_launches(R):
     for key in ("x_iter", "y_iter", "z"):
         assert torch.equal(ra[key], rb[key]), key
     a.cleanup(); b.cleanup()
+
+
+def test_arrowhead_factor_inertia_and_odd_batch(R):
+    """k_arrow_factor on the metric shape: status = number of positive pivots (qdldl_interface.c:80-92) per instance,
+    a non-convex instance is reported, and a batch that is neither a multiple of the workgroup size nor within one
+    resident round (4099 > 16 waves x 256 CUs) gives identical answers for identical instances."""
+    wl = R.workloads.SharedPatternQPs()
+    B = 6
+    Px, Ax, q, l, u = wl.values(B)
+    rho = np.full((B, wl.m), 0.1)
+    ls = R.BatchLinsys(wl.P_pattern, wl.A_pattern, dev(Px), dev(Ax), 1e-6, dev(rho))
+    assert ls.status == 0 and (ls.factor_status() == wl.n).all()
+    Px2 = Px.copy(); Px2[4] = -Px2[4]                               # indefinite P for instance 4 only
+    assert ls.update_matrices(dev(Px2), dev(Ax)) == 1                # reference: update returns non-zero (qdldl_interface.c:598-600)
+    st = ls.factor_status()
+    assert st[4] < wl.n and (np.delete(st, 4) == wl.n).all()
+    ls.free()
+    # 4099 copies of two instances, interleaved
+    Bb = 4099
+    sel = np.arange(Bb) % 2
+    kw = dict(rho=0.1, sigma=1e-6, alpha=1.6, max_iter=30, check_termination=0, adaptive_rho=0, warm_start=0, scaling=0)
+    w = R.OSQPBatch(wl.P_pattern, wl.A_pattern, dev(Px[sel]), dev(Ax[sel]), dev(q[sel]), dev(l[sel]), dev(u[sel]), **kw)
+    r = w.solve()
+    for k in (0, 1):
+        idx = torch.from_numpy(np.nonzero(sel == k)[0]).cuda()
+        xs = r["x"][idx]
+        assert torch.equal(xs, xs[:1].expand_as(xs))
+    ro = ob.OracleOSQP(*[wl.instance(1)[i] for i in (0, 1, 2, 3, 4)], perm=w.linsys().export_symbolic()["perm"], **kw).solve()
+    assert relerr(r["x"][1].cpu().numpy(), ro["x"]) < 1e-8
+    w.cleanup()
