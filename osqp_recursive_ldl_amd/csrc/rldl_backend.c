@@ -59,7 +59,6 @@ static int upload_symbolic(rldl_batch *h) {
   UP(LtoS, s->nnzL, int);
   D->plan = (const int *)dev_upload(s->plan, sizeof(int) * (size_t)(s->plan_ok ? ((s->plan_words + 3) & ~3) : 0), &ok); /* blob is calloc'ed with 4 words of slack */
   D->ldF = (s->nS + s->N + 2) & ~1;             /* even, and at least one spare slot that stays 0.0 (ldF-1) */
-  D->dbg = getenv("RLDL_DBG") ? atoi(getenv("RLDL_DBG")) : 0;
   D->nS = s->nS; D->nO = s->nO; D->ngroups = s->ngroups; D->plan_ok = s->plan_ok; D->plan_words = s->plan_ok ? s->plan_words : 0;
   D->po_gstart = s->po_gstart; D->po_gflag = s->po_gflag; D->po_gaptr = s->po_gaptr; D->po_grptr = s->po_grptr;
   D->po_gToff = s->po_gToff; D->po_fsp = s->po_fsp; D->po_bsp = s->po_bsp; D->po_acol = s->po_acol; D->po_aoff = s->po_aoff;

@@ -36,7 +36,6 @@ typedef struct {
   const int *LtoS;             /* [nnzL] CSC position -> storage slot */
   const int *plan;             /* packed blob, plan_words int32 */
   int nS, nO, ngroups, plan_ok, plan_words;
-  int dbg;                     /* timing experiments only (env RLDL_DBG): bit mask of phases to skip; 0 in production */
   int ldF;                     /* row stride of rldl_dev_num.F in doubles: nS + N rounded up to even (16-byte rows) */
   int po_gstart, po_gflag, po_gaptr, po_grptr, po_gToff, po_fsp, po_bsp, po_acol, po_aoff, po_arow, po_coloff, po_fsb,
       po_fsc, po_bsb, po_bsc, po_fsig, po_bsig, po_fcol, po_brs, po_perm, po_avmap, po_avcol, po_avrow;

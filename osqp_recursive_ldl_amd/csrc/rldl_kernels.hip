@@ -834,8 +834,8 @@ __device__ __forceinline__ void plan_tri_solve(const rldl_dev_sym &S, const int 
     const int g0 = __builtin_amdgcn_readfirstlane(w[S.po_gstart + k]);
     const int g = __builtin_amdgcn_readfirstlane(w[S.po_gstart + k + 1]) - g0;
     const int fs0 = __builtin_amdgcn_readfirstlane(w[S.po_fsp + k]);
-    const int nfs = (S.dbg & 1) ? 0 : __builtin_amdgcn_readfirstlane(w[S.po_fsp + k + 1]) - fs0;
-    const int na = ((S.dbg & 2) || !__builtin_amdgcn_readfirstlane(w[S.po_gflag + k])) ? 0 : g - 1;
+    const int nfs = __builtin_amdgcn_readfirstlane(w[S.po_fsp + k + 1]) - fs0;
+    const int na = !__builtin_amdgcn_readfirstlane(w[S.po_gflag + k]) ? 0 : g - 1;
     if (nfs == 0 && na == 0) continue;                           // nothing flows into this group
     const bool act = lane < g;
     const int r = g0 + lane;
@@ -878,8 +878,8 @@ __device__ __forceinline__ void plan_tri_solve(const rldl_dev_sym &S, const int 
     const int g0 = __builtin_amdgcn_readfirstlane(w[S.po_gstart + k]);
     const int g = __builtin_amdgcn_readfirstlane(w[S.po_gstart + k + 1]) - g0;
     const int bs0 = __builtin_amdgcn_readfirstlane(w[S.po_bsp + k]);
-    const int nbs = (S.dbg & 4) ? 0 : __builtin_amdgcn_readfirstlane(w[S.po_bsp + k + 1]) - bs0;
-    const int nr = ((S.dbg & 8) || !__builtin_amdgcn_readfirstlane(w[S.po_gflag + k])) ? 0 : g - 1;
+    const int nbs = __builtin_amdgcn_readfirstlane(w[S.po_bsp + k + 1]) - bs0;
+    const int nr = !__builtin_amdgcn_readfirstlane(w[S.po_gflag + k]) ? 0 : g - 1;
     const bool act = lane < g;
     const int c = g0 + lane;
     if (nbs == 0 && nr == 0) {                                   // only the diagonal scaling is left
@@ -1032,7 +1032,7 @@ __global__ __launch_bounds__(1024) void k_plan_admm(rldl_dev_sym S, rldl_dev_num
   double va[TMAX], vb[TMAX], vr[TMAX], vl[TMAX], vu[TMAX], vrho[TMAX];
   const double *Sv = STAGE ? Sl : Nn.F + io * S.ldF;
   if (live) {
-    if (STAGE && !(S.dbg & 16)) stage_factor_dma(S, Nn.F + io * S.ldF, Sl, lane);
+    if (STAGE) stage_factor_dma(S, Nn.F + io * S.ldF, Sl, lane);
 #pragma unroll
     for (int t = 0; t < TMAX; t++) {
       // branch-free: every lane loads from a valid address chosen by pointer select, so all loads of all
@@ -1059,7 +1059,7 @@ __global__ __launch_bounds__(1024) void k_plan_admm(rldl_dev_sym S, rldl_dev_num
   wait_dma();
   __syncthreads();
   if (!live) return;
-  if (!(S.dbg & 32)) plan_tri_solve(S, wl, Sv, xs, lane);
+  plan_tri_solve(S, wl, Sv, xs, lane);
   const double alpha = W.alpha;
   double *dx = W.delta_x + io * n, *dy = W.delta_y + io * m;
 #pragma unroll

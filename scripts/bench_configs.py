@@ -125,6 +125,18 @@ def mpc_shape():
     emit(name="config3_solve_kernel", batch=B, us_per_launch=1e3 * ms, bytes_per_instance=by,
          achieved_GBs=by * B / (ms * 1e-3) / 1e9, frac=by * B / (ms * 1e-3) / 1e9 / PEAK)
     ls.free()
+    # ADMM on the MPC shape: stage-block factorisation + 200 fused iterations (grouped-plan kernels, factor from global memory)
+    kw = dict(rho=0.1, sigma=1e-6, alpha=1.6, max_iter=200, check_termination=0, adaptive_rho=0, warm_start=0, scaling=0)
+    w = R.OSQPBatch.recursive(wl.dims, wl.Q0, wl.Qi, wl.QN, wl.A0, wl.Ai, wl.Aij, wl.AN, t(q), t(l), t(u), **kw)
+
+    def step():
+        w.update_recursive(0, dPx, dAx)
+        w.solve(clone=False)
+    ms = timed(step, reps=3)
+    lm, its, gr = w.last_loop()
+    emit(name="config3_admm_factor_plus_200_iters", batch=B, ms_per_step=ms, qp_solves_per_sec=B / (ms * 1e-3),
+         us_per_iteration=1e3 * lm / its)
+    w.cleanup()
 
 
 if __name__ == "__main__":

@@ -1,7 +1,6 @@
 #!/usr/bin/env python3
-"""Kernel micro-benchmark for the fused ADMM-iteration kernel on the metric shape (timing experiments).
-RLDL_DBG=<mask> skips phases (results are then wrong; timing only):
-  1 fwd gather, 2 fwd sweep, 4 bwd gather, 8 bwd sweep, 16 factor DMA, 32 whole tri-solve."""
+"""Kernel micro-benchmark for the fused ADMM-iteration kernel on the metric shape: a resident loop of KB_ITERS
+iterations in one launch, and single-iteration launches (factor re-streamed every time) for comparison."""
 import os, sys, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -26,4 +25,4 @@ for _ in range(3):
     best = lm if best is None else min(best, lm)
 print(json.dumps({"resident_loop_iters": it, "launches": gr, "loop_ms": best, "us_per_iteration": 1e3 * best / it,
                   "algorithmic_GBs": by * B * it / (best * 1e-3) / 1e9}))
-print(json.dumps({"dbg": os.environ.get("RLDL_DBG", "0"), "batch": B, "us_per_launch": 1e3 * ms, "GBs": by * B / (ms * 1e-3) / 1e9}))
+print(json.dumps({"single_iteration_launches": True, "batch": B, "us_per_launch": 1e3 * ms, "GBs": by * B / (ms * 1e-3) / 1e9}))
