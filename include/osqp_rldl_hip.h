@@ -145,6 +145,10 @@ c_int osqp_batch_setup(osqp_batch **wp, c_int batch, const csc *P, const csc *A,
                        const c_float *d_Ax, const c_float *d_q, const c_float *d_l, const c_float *d_u,
                        const OSQPBatchSettings *settings, const c_int *perm, void *stream);
 c_int osqp_batch_solve(osqp_batch *w);                                  /* osqp.c:288-641 */
+/* the same, enqueued on the workspace's stream without waiting when the settings need no host decision inside the
+ * loop (check_termination == 0 and adaptive_rho == 0); results are valid after osqp_batch_wait */
+c_int osqp_batch_solve_async(osqp_batch *w);
+c_int osqp_batch_wait(osqp_batch *w);
 c_int osqp_batch_update_lin_cost(osqp_batch *w, const c_float *d_q);   /* osqp.c:752-790 */
 c_int osqp_batch_update_bounds(osqp_batch *w, const c_float *d_l, const c_float *d_u); /* osqp.c:792-841 */
 c_int osqp_batch_update_rho(osqp_batch *w, c_float rho_new);           /* osqp.c:1268-1319 */

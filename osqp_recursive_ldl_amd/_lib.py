@@ -64,7 +64,7 @@ EXPORTED = [
     "rldl_batch_factor_status", "rldl_batch_time_solve",
     "osqp_batch_set_default_settings", "osqp_batch_setup", "osqp_batch_solve", "osqp_batch_update_lin_cost",
     "osqp_batch_update_bounds", "osqp_batch_update_rho", "osqp_batch_update_P_A", "osqp_batch_warm_start",
-    "osqp_batch_get", "osqp_batch_get_iterates", "osqp_batch_get_scaling", "osqp_batch_linsys", "osqp_batch_setup_recursive", "osqp_batch_update_recursive", "osqp_batch_partial_update_bounds",
+    "osqp_batch_get", "osqp_batch_get_iterates", "osqp_batch_get_scaling", "osqp_batch_linsys", "osqp_batch_solve_async", "osqp_batch_wait", "osqp_batch_setup_recursive", "osqp_batch_update_recursive", "osqp_batch_partial_update_bounds",
     "osqp_batch_time_iteration", "osqp_batch_last_loop", "osqp_batch_trace_iteration", "osqp_batch_cleanup",
     "rldl_batch_init_recursive", "rldl_batch_update_from_stage", "rldl_version",
     "rldl_symbolic_analyze", "rldl_stage_permutation", "rldl_plan_export", "rldl_setup_AP_matrices", "rldl_csc_free",
@@ -141,6 +141,10 @@ def _declare(L):
     L.osqp_batch_linsys.restype = VP
     L.osqp_batch_time_iteration.argtypes = [VP, c_int, FP]
     L.osqp_batch_time_iteration.restype = c_int
+    L.osqp_batch_solve_async.argtypes = [VP]
+    L.osqp_batch_solve_async.restype = c_int
+    L.osqp_batch_wait.argtypes = [VP]
+    L.osqp_batch_wait.restype = c_int
     L.osqp_batch_setup_recursive.argtypes = [C.POINTER(VP), c_int, C.POINTER(StageDims)] + [C.POINTER(Csc)] * 7 + [VP, VP, VP,
                                              C.POINTER(OSQPBatchSettings), C.POINTER(C.POINTER(Csc)), C.POINTER(C.POINTER(Csc)), VP]
     L.osqp_batch_setup_recursive.restype = c_int

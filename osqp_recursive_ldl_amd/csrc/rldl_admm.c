@@ -200,7 +200,30 @@ static int read_active(osqp_batch *w) {
   return v;
 }
 
-c_int osqp_batch_solve(osqp_batch *w) {
+static c_int solve_impl(osqp_batch *w, int wait);
+
+c_int osqp_batch_solve(osqp_batch *w) { return solve_impl(w, 1); }
+
+/* Enqueue a solve on the workspace's stream and return: nothing in the loop needs the host when there are no
+ * termination checks and no rho adaptation (fixed number of iterations); otherwise this is osqp_batch_solve.
+ * Several workspaces on different streams (e.g. one per sparsity pattern) then run concurrently.  Results are valid
+ * after osqp_batch_wait. */
+c_int osqp_batch_solve_async(osqp_batch *w) {
+  if (!w) return 7;
+  return solve_impl(w, (w->st.check_termination || w->st.adaptive_rho) ? 1 : 0);
+}
+
+c_int osqp_batch_wait(osqp_batch *w) {
+  if (!w) return 7;
+  if (!HIP_OK(hipStreamSynchronize((hipStream_t)w->stream))) return 1;
+  if (w->loop_pending) {
+    (void)hipEventElapsedTime(&w->last_loop_ms, (hipEvent_t)w->ev0, (hipEvent_t)w->ev1);
+    w->loop_pending = 0;
+  }
+  return 0;
+}
+
+static c_int solve_impl(osqp_batch *w, int wait) {
   c_int iter, last_iter = 0, launches = 0, groups = 0;
   int can_check = 0, nact;
   size_t B;
@@ -253,11 +276,10 @@ c_int osqp_batch_solve(osqp_batch *w) {
   (void)hipEventRecord((hipEvent_t)w->ev1, st);
   /* tail of osqp_solve (osqp.c:521-633) */
   if (rldl_launch_admm_check(&w->ls->dsym, &w->W, (int)last_iter, 0, can_check ? 1 : 2, w->stream)) return 1;
-  if (!HIP_OK(hipStreamSynchronize(st))) return 1;
-  (void)hipEventElapsedTime(&w->last_loop_ms, (hipEvent_t)w->ev0, (hipEvent_t)w->ev1);
   w->last_loop_launches = launches;
   w->last_loop_groups = groups;
-  return 0;
+  w->loop_pending = 1;
+  return wait ? osqp_batch_wait(w) : 0;
 }
 
 c_int osqp_batch_update_lin_cost(osqp_batch *w, const c_float *d_q) {
@@ -398,6 +420,7 @@ rldl_batch *osqp_batch_linsys(osqp_batch *w) { return w ? w->ls : 0; }
  * the number of launch groups (= kernel launches of the fused iteration kernel on the arrowhead path). */
 c_int osqp_batch_last_loop(osqp_batch *w, c_float *ms, c_int *iterations, c_int *launch_groups) {
   if (!w || !w->last_loop_launches) return 1;
+  if (w->loop_pending && osqp_batch_wait(w)) return 1;
   if (ms) *ms = (c_float)w->last_loop_ms;
   if (iterations) *iterations = w->last_loop_launches;
   if (launch_groups) *launch_groups = w->last_loop_groups;

@@ -32,6 +32,7 @@ struct osqp_batch {
   void *ev0, *ev1;
   int *h_tmp_i;                  /* [batch] host scratch */
   double *h_tmp_d;               /* [batch] host scratch */
+  int loop_pending;              /* a solve loop was enqueued and its event pair not read yet */
   float last_loop_ms;
   c_int last_loop_launches;     /* ADMM iterations run by the last solve loop ... */
   c_int last_loop_groups;       /* ... in this many launch groups (one kernel launch each on the arrowhead path) */

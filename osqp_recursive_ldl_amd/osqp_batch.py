@@ -25,8 +25,10 @@ def default_settings(**kw):
 
 
 class OSQPBatch:
-    def __init__(self, P_pattern, A_pattern, Px, Ax, q, l, u, perm=None, **settings):
+    def __init__(self, P_pattern, A_pattern, Px, Ax, q, l, u, perm=None, stream=None, **settings):
+        """stream: optional torch.cuda.Stream the workspace enqueues on (default: the legacy default stream)."""
         L = _lib.lib()
+        self._stream = stream
         self.P = P_pattern if isinstance(P_pattern, CscPattern) else CscPattern(P_pattern)
         self.A = A_pattern if isinstance(A_pattern, CscPattern) else CscPattern(A_pattern)
         self.n, self.m = self.P.shape[0], self.A.shape[0]
@@ -38,7 +40,8 @@ class OSQPBatch:
         self.h = C.c_void_p()
         self.status = _lib.check(L.osqp_batch_setup(C.byref(self.h), self.batch, self.P.ref, self.A.ref, _dptr(Px), _dptr(Ax),
                                                     _dptr(q), _dptr(l), _dptr(u), C.byref(self.settings),
-                                                    None if pm is None else _ip(pm), None), "osqp_batch_setup")
+                                                    None if pm is None else _ip(pm),
+                                                    None if stream is None else C.c_void_p(stream.cuda_stream)), "osqp_batch_setup")
         self._device = q.device
 
     @classmethod
@@ -90,6 +93,17 @@ class OSQPBatch:
         rc = _lib.lib().osqp_batch_solve(self.h)
         if rc:
             raise RuntimeError("osqp_batch_solve failed (%d)" % rc)
+        return self.results(clone=clone)
+
+    def solve_async(self):
+        """Enqueue the solve on the workspace's stream (no host wait when the settings allow it, see the C header)."""
+        rc = _lib.lib().osqp_batch_solve_async(self.h)
+        if rc:
+            raise RuntimeError("osqp_batch_solve_async failed (%d)" % rc)
+
+    def wait(self, clone=True):
+        if _lib.lib().osqp_batch_wait(self.h):
+            raise RuntimeError("osqp_batch_wait failed")
         return self.results(clone=clone)
 
     def _view(self, ptr, shape, dtype):

@@ -100,6 +100,20 @@ def metric_shape():
     w.cleanup()
 
 
+def pattern_groups():
+    """Per-instance-pattern variant of config 2: 8 different random patterns x 512 instances each."""
+    probs = []
+    for s in range(8):
+        wl = R.workloads.SharedPatternQPs(pattern_seed=2000 + s)
+        probs += [wl.instance(b) for b in range(512)]
+    kw = dict(rho=0.1, sigma=1e-6, alpha=1.6, max_iter=200, check_termination=0, adaptive_rho=0, warm_start=0, scaling=0)
+    g = R.OSQPBatchGroups(probs, **kw)
+    ms = timed(lambda: g.solve(), reps=3)
+    emit(name="config2_pattern_groups_8x512_200_iters", batch=len(probs), patterns=g.n_patterns, ms_per_solve=ms,
+         qp_solves_per_sec=len(probs) / (ms * 1e-3))
+    g.cleanup()
+
+
 def mpc_shape():
     wl = R.workloads.MPCStageQPs(N=20)
     B = 4096
@@ -143,5 +157,7 @@ if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     if which in ("all", "metric"):
         metric_shape()
+    if which in ("all", "groups"):
+        pattern_groups()
     if which in ("all", "mpc"):
         mpc_shape()

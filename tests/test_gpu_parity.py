@@ -488,3 +488,32 @@ def test_arrowhead_factor_inertia_and_odd_batch(R):
     ro = ob.OracleOSQP(*[wl.instance(1)[i] for i in (0, 1, 2, 3, 4)], perm=w.linsys().export_symbolic()["perm"], **kw).solve()
     assert relerr(r["x"][1].cpu().numpy(), ro["x"]) < 1e-8
     w.cleanup()
+
+
+def test_pattern_groups_solve_mixed_sparsity_batches(R):
+    """Instances with different sparsity patterns: bucketed by pattern, one workspace and stream per bucket, enqueued
+    together (osqp_batch_solve_async), results back in the caller's order and equal to the oracle per instance."""
+    wls = [R.workloads.SharedPatternQPs(n=20, m=30, density=0.25, pattern_seed=s) for s in (3, 4, 5)]
+    problems, src = [], []
+    for k in range(14):                                            # interleave the three patterns
+        wl = wls[k % 3]
+        problems.append(wl.instance(k // 3))
+        src.append((k % 3, k // 3))
+    kw = dict(rho=0.1, sigma=1e-6, alpha=1.6, max_iter=60, check_termination=0, adaptive_rho=0, warm_start=0, scaling=0)
+    g = R.OSQPBatchGroups(problems, **kw)
+    assert g.n_patterns == 3
+    r = g.solve()
+    for k, (P, q, A, l, u) in enumerate(problems):
+        w = [w for idx, w in g.groups if int(k) in idx.tolist()][0]
+        ro = ob.OracleOSQP(P, q, A, l, u, perm=w.linsys().export_symbolic()["perm"], **kw).solve()
+        assert relerr(r["x"][k].cpu().numpy(), ro["x"]) < 1e-8 and relerr(r["y"][k].cpu().numpy(), ro["y"]) < 1e-8
+        assert int(r["iter"][k]) == 60
+    # with termination checks the groups fall back to the blocking solve and still agree with the oracle
+    kw2 = dict(kw, max_iter=2000, check_termination=10, eps_abs=1e-5, eps_rel=1e-5)
+    g2 = R.OSQPBatchGroups(problems, **kw2)
+    r2 = g2.solve()
+    P, q, A, l, u = problems[4]
+    w = [w for idx, w in g2.groups if 4 in idx.tolist()][0]
+    ro = ob.OracleOSQP(P, q, A, l, u, perm=w.linsys().export_symbolic()["perm"], **kw2).solve()
+    assert int(r2["iter"][4]) == ro["iter"] and int(r2["status"][4]) == ro["status"]
+    g.cleanup(); g2.cleanup()
