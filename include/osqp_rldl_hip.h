@@ -134,6 +134,8 @@ typedef struct {           /* subset of OSQPSettings, include/types.h:139-176; d
   c_int   max_iter, check_termination, warm_start, scaling, scaled_termination;
   c_int   adaptive_rho, adaptive_rho_interval;
   c_float adaptive_rho_tolerance;
+  c_int   polish, polish_refine_iter;   /* constants.h:77-78 (0, 3) */
+  c_float delta;                        /* constants.h:76 (1e-6) */
 } OSQPBatchSettings;
 
 typedef struct osqp_batch osqp_batch;
@@ -163,6 +165,8 @@ c_int osqp_batch_get_iterates(osqp_batch *w, c_float **d_x, c_float **d_y, c_flo
                               c_float **d_delta_y);
 /* OSQPScaling (include/types.h:43-48): D[batch][n], E[batch][m], c[batch]; returns 1 when scaling is off */
 c_int osqp_batch_get_scaling(osqp_batch *w, c_float **d_D, c_float **d_E, c_float **d_c);
+/* info->status_polish per instance (types.h:95): 0 not performed, 1 successful, -1 unsuccessful */
+c_int osqp_batch_get_polish_status(osqp_batch *w, int **d_status_polish);
 rldl_batch *osqp_batch_linsys(osqp_batch *w);
 /* timing of the fused ADMM-iteration kernel (HIP events on the workspace stream), for the roofline:
  * reps == 0: device time per ITERATION of the last solve loop; reps > 0: time `reps` single-iteration launches now */

@@ -47,9 +47,15 @@ static orc_float scaled_norm_inf(const orc_float *S, const orc_float *v, orc_int
   for (i = 0; i < n; i++) { a = fabs(S[i] * v[i]); if (a > m) m = a; }
   return m;
 }
+/* plus_eq: 0 y = A x, 1 y += A x, -1 y -= A x (lin_alg.c:241-271) */
 static void mat_vec(const orc_csc *A, const orc_float *x, orc_float *y, int plus_eq) {
   orc_int i, j;
   if (!plus_eq) for (i = 0; i < A->m; i++) y[i] = 0;
+  if (plus_eq == -1) {
+    for (j = 0; j < A->n; j++)
+      for (i = A->p[j]; i < A->p[j + 1]; i++) y[A->i[i]] -= A->x[i] * x[j];
+    return;
+  }
   for (j = 0; j < A->n; j++)
     for (i = A->p[j]; i < A->p[j + 1]; i++) y[A->i[i]] += A->x[i] * x[j];
 }
@@ -60,7 +66,8 @@ static void mat_tpose_vec(const orc_csc *A, const orc_float *x, orc_float *y, in
     for (k = A->p[j]; k < A->p[j + 1]; k++) {
       i = A->i[k];
       if (skip_diag && i == j) continue;
-      y[j] += A->x[k] * x[i];
+      if (plus_eq == -1) y[j] -= A->x[k] * x[i];
+      else y[j] += A->x[k] * x[i];
     }
 }
 static orc_float quad_form(const orc_csc *P, const orc_float *x) {
@@ -79,6 +86,7 @@ void orc_set_default_settings(orc_settings *s) { /* osqp.c:24-71, constants.h:59
   s->eps_prim_inf = 1e-4; s->eps_dual_inf = 1e-4; s->max_iter = 4000; s->check_termination = 25;
   s->warm_start = 1; s->scaling = 10; s->scaled_termination = 0; s->adaptive_rho = 1;
   s->adaptive_rho_interval = 0; s->adaptive_rho_tolerance = 5;
+  s->polish = 0; s->polish_refine_iter = 3; s->delta = 1e-6;
 }
 
 /* ---------------------------------------------------------------- scaling ---- */
@@ -475,6 +483,92 @@ static void store_solution(orc_workspace *w) { /* auxil.c:527-565 */
   }
 }
 
+/* ------------------------------------------------------------------ polish ----
+ * src/polish.c: guess the active constraints from (z, y), solve the equality-constrained QP on them through the
+ * backend's polish = 1 mode (delta-regularised reduced KKT, raw solution), refine, accept if the residuals improve. */
+static orc_int polish(orc_workspace *w) {
+  const orc_int n = w->n, m = w->m;
+  orc_int *A_to_Alow = (orc_int *)malloc(sizeof(orc_int) * (size_t)(m + 1)), *A_to_Aupp = (orc_int *)malloc(sizeof(orc_int) * (size_t)(m + 1));
+  orc_int *low_to_A = (orc_int *)malloc(sizeof(orc_int) * (size_t)(m + 1)), *upp_to_A = (orc_int *)malloc(sizeof(orc_int) * (size_t)(m + 1));
+  orc_int n_low = 0, n_upp = 0, j, ptr, nnz = 0, mred, it, ok, i;
+  orc_csc Ared;
+  orc_linsys *plsh = 0;
+  orc_float *rhs_red, *pol_sol, *rhs, *px, *pz, *py, *sx, *sz, *sy, pol_obj, pol_pri, pol_dua;
+  /* form_Ared, polish.c:19-103 */
+  for (j = 0; j < m; j++) {
+    if (w->z[j] - w->l[j] < -w->y[j]) { low_to_A[n_low] = j; A_to_Alow[j] = n_low++; } else A_to_Alow[j] = -1;
+  }
+  for (j = 0; j < m; j++) {
+    if (w->u[j] - w->z[j] < w->y[j]) { upp_to_A[n_upp] = j; A_to_Aupp[j] = n_upp++; } else A_to_Aupp[j] = -1;
+  }
+  mred = n_low + n_upp;
+  for (j = 0; j < w->A->p[n]; j++)
+    if (A_to_Alow[w->A->i[j]] != -1 || A_to_Aupp[w->A->i[j]] != -1) nnz++;
+  Ared.m = mred; Ared.n = n; Ared.nzmax = nnz > 0 ? nnz : 1; Ared.nz = -1;
+  Ared.p = (orc_int *)calloc((size_t)n + 1, sizeof(orc_int));
+  Ared.i = (orc_int *)malloc(sizeof(orc_int) * (size_t)Ared.nzmax);
+  Ared.x = (orc_float *)malloc(sizeof(orc_float) * (size_t)Ared.nzmax);
+  nnz = 0;
+  for (j = 0; j < n; j++) {
+    Ared.p[j] = nnz;
+    for (ptr = w->A->p[j]; ptr < w->A->p[j + 1]; ptr++) {
+      if (A_to_Alow[w->A->i[ptr]] != -1) { Ared.i[nnz] = A_to_Alow[w->A->i[ptr]]; Ared.x[nnz++] = w->A->x[ptr]; }
+      else if (A_to_Aupp[w->A->i[ptr]] != -1) { Ared.i[nnz] = A_to_Aupp[w->A->i[ptr]] + n_low; Ared.x[nnz++] = w->A->x[ptr]; }
+    }
+  }
+  Ared.p[n] = nnz;
+  /* reduced KKT, polish.c:228-243 */
+  if (orc_linsys_init(&plsh, w->P, &Ared, w->settings.delta, 0, 1, 0)) {
+    w->info.status_polish = -1;
+    free(A_to_Alow); free(A_to_Aupp); free(low_to_A); free(upp_to_A); free(Ared.p); free(Ared.i); free(Ared.x);
+    return 1;
+  }
+  rhs_red = dvec(n + mred); pol_sol = dvec(n + mred); rhs = dvec(n + mred);
+  for (j = 0; j < n; j++) rhs_red[j] = -w->q[j];                                   /* form_rhs_red :105-121 */
+  for (j = 0; j < n_low; j++) rhs_red[n + j] = w->l[low_to_A[j]];
+  for (j = 0; j < n_upp; j++) rhs_red[n + n_low + j] = w->u[upp_to_A[j]];
+  memcpy(pol_sol, rhs_red, sizeof(orc_float) * (size_t)(n + mred));
+  orc_linsys_solve(plsh, pol_sol);
+  for (it = 0; it < w->settings.polish_refine_iter; it++) {                        /* iterative_refinement :134-181 */
+    memcpy(rhs, rhs_red, sizeof(orc_float) * (size_t)(n + mred));
+    mat_vec(w->P, pol_sol, rhs, -1);
+    mat_tpose_vec(w->P, pol_sol, rhs, -1, 1);
+    mat_tpose_vec(&Ared, pol_sol + n, rhs, -1, 0);
+    mat_vec(&Ared, pol_sol, rhs + n, -1);
+    orc_linsys_solve(plsh, rhs);
+    for (j = 0; j < n + mred; j++) pol_sol[j] += rhs[j];
+  }
+  px = dvec(n); pz = dvec(m); py = dvec(m);
+  memcpy(px, pol_sol, sizeof(orc_float) * (size_t)n);
+  mat_vec(w->A, px, pz, 0);
+  for (j = 0; j < m; j++)                                                          /* get_ypol_from_yred :188-210 */
+    py[j] = A_to_Alow[j] != -1 ? pol_sol[n + A_to_Alow[j]] : (A_to_Aupp[j] != -1 ? pol_sol[n + n_low + A_to_Aupp[j]] : 0.0);
+  for (i = 0; i < m; i++) {                                                        /* project_normalcone, proj.c:16-29 */
+    const orc_float t = pz[i] + py[i];
+    pz[i] = dmin(dmax(t, w->l[i]), w->u[i]);
+    py[i] = t - pz[i];
+  }
+  /* update_info(work, 0, 1, 1), auxil.c:567-626, on the polished point */
+  sx = w->x; sz = w->z; sy = w->y;
+  w->x = px; w->z = pz; w->y = py;
+  pol_obj = compute_obj_val(w, w->x);
+  pol_pri = m == 0 ? 0. : compute_pri_res(w);
+  pol_dua = compute_dua_res(w);
+  w->x = sx; w->z = sz; w->y = sy;
+  ok = (pol_pri < w->info.pri_res && pol_dua < w->info.dua_res) || (pol_pri < w->info.pri_res && w->info.dua_res < 1e-10) ||
+       (pol_dua < w->info.dua_res && w->info.pri_res < 1e-10);                      /* polish.c:298-311 */
+  if (ok) {
+    w->info.obj_val = pol_obj; w->info.pri_res = pol_pri; w->info.dua_res = pol_dua; w->info.status_polish = 1;
+    memcpy(w->x, px, sizeof(orc_float) * (size_t)n);
+    memcpy(w->z, pz, sizeof(orc_float) * (size_t)m);
+    memcpy(w->y, py, sizeof(orc_float) * (size_t)m);
+  } else w->info.status_polish = -1;
+  orc_linsys_free(plsh);
+  free(A_to_Alow); free(A_to_Aupp); free(low_to_A); free(upp_to_A); free(Ared.p); free(Ared.i); free(Ared.x);
+  free(rhs_red); free(pol_sol); free(rhs); free(px); free(pz); free(py);
+  return 0;
+}
+
 orc_int orc_solve(orc_workspace *w) { /* osqp.c:288-641 */
   orc_int iter, can_check = 0, i;
   if (!w->settings.warm_start) {
@@ -507,6 +601,8 @@ orc_int orc_solve(orc_workspace *w) { /* osqp.c:288-641 */
   if (w->info.status_val == ORC_UNSOLVED)
     if (!check_termination(w, 1)) w->info.status_val = ORC_MAX_ITER_REACHED;
   w->info.rho_estimate = compute_rho_estimate(w);
+  w->info.status_polish = 0;
+  if (w->settings.polish && w->info.status_val == ORC_SOLVED) polish(w);             /* osqp.c:591-595 */
   store_solution(w);
   return 0;
 }

@@ -115,11 +115,14 @@ typedef struct {
   orc_int   max_iter, check_termination, warm_start, scaling, scaled_termination;
   orc_int   adaptive_rho, adaptive_rho_interval;
   orc_float adaptive_rho_tolerance;
+  orc_int   polish, polish_refine_iter;   /* constants.h:77-78 */
+  orc_float delta;                        /* constants.h:76 */
 } orc_settings;
 
 typedef struct {
   orc_int   iter, status_val, rho_updates;
   orc_float obj_val, pri_res, dua_res, rho_estimate;
+  orc_int   status_polish;                /* 0 not performed, 1 successful, -1 unsuccessful (types.h:95) */
 } orc_info;
 
 typedef struct {

@@ -48,7 +48,8 @@ class OSQPBatchSettings(C.Structure):
                 ("eps_rel", c_float), ("eps_prim_inf", c_float), ("eps_dual_inf", c_float),
                 ("max_iter", c_int), ("check_termination", c_int), ("warm_start", c_int),
                 ("scaling", c_int), ("scaled_termination", c_int), ("adaptive_rho", c_int),
-                ("adaptive_rho_interval", c_int), ("adaptive_rho_tolerance", c_float)]
+                ("adaptive_rho_interval", c_int), ("adaptive_rho_tolerance", c_float),
+                ("polish", c_int), ("polish_refine_iter", c_int), ("delta", c_float)]
 
 
 class StageDims(C.Structure):
@@ -64,7 +65,7 @@ EXPORTED = [
     "rldl_batch_factor_status", "rldl_batch_time_solve",
     "osqp_batch_set_default_settings", "osqp_batch_setup", "osqp_batch_solve", "osqp_batch_update_lin_cost",
     "osqp_batch_update_bounds", "osqp_batch_update_rho", "osqp_batch_update_P_A", "osqp_batch_warm_start",
-    "osqp_batch_get", "osqp_batch_get_iterates", "osqp_batch_get_scaling", "osqp_batch_linsys", "osqp_batch_solve_async", "osqp_batch_wait", "osqp_batch_setup_recursive", "osqp_batch_update_recursive", "osqp_batch_partial_update_bounds",
+    "osqp_batch_get", "osqp_batch_get_iterates", "osqp_batch_get_scaling", "osqp_batch_get_polish_status", "osqp_batch_linsys", "osqp_batch_solve_async", "osqp_batch_wait", "osqp_batch_setup_recursive", "osqp_batch_update_recursive", "osqp_batch_partial_update_bounds",
     "osqp_batch_time_iteration", "osqp_batch_last_loop", "osqp_batch_trace_iteration", "osqp_batch_cleanup",
     "rldl_batch_init_recursive", "rldl_batch_update_from_stage", "rldl_version",
     "rldl_symbolic_analyze", "rldl_stage_permutation", "rldl_plan_export", "rldl_setup_AP_matrices", "rldl_csc_free",
@@ -137,6 +138,8 @@ def _declare(L):
     L.osqp_batch_get_iterates.restype = c_int
     L.osqp_batch_get_scaling.argtypes = [VP] + [C.POINTER(VP)] * 3
     L.osqp_batch_get_scaling.restype = c_int
+    L.osqp_batch_get_polish_status.argtypes = [VP, C.POINTER(VP)]
+    L.osqp_batch_get_polish_status.restype = c_int
     L.osqp_batch_linsys.argtypes = [VP]
     L.osqp_batch_linsys.restype = VP
     L.osqp_batch_time_iteration.argtypes = [VP, c_int, FP]

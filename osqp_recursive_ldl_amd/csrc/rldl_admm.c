@@ -15,7 +15,8 @@
  *     headline metric is quoted without equilibration; pass scaling = 10 for the reference behaviour.
  *   - adaptive_rho with adaptive_rho_interval == 0 uses the PROFILING-off rule of osqp.c:266-279
  *     (the shipped default derives the interval from wall-clock time and is not reproducible).
- *   - polish is out of scope.
+ *   - polish (src/polish.c) keeps the shared sparsity pattern: rows of A that are not active are zeroed instead of
+ *     removed (see k_polish_prep), so the reduced KKT systems of all instances share one symbolic analysis.
  */
 #include <hip/hip_runtime_api.h>
 #include <stdlib.h>
@@ -37,6 +38,7 @@ void osqp_batch_set_default_settings(OSQPBatchSettings *s) {
   s->warm_start = 1;
   s->scaling = 0; /* reference default is 10 (constants.h:85); see header comment */
   s->scaled_termination = 0; s->adaptive_rho = 1; s->adaptive_rho_interval = 0; s->adaptive_rho_tolerance = 5;
+  s->polish = 0; s->polish_refine_iter = 3; s->delta = 1e-6;      /* constants.h:76-78 */
 }
 
 static void *dmalloc(size_t bytes, int *ok) {
@@ -85,11 +87,13 @@ void osqp_batch_cleanup(osqp_batch *w) {
   if (!w) return;
   (void)hipStreamSynchronize((hipStream_t)w->stream);
   rldl_batch_free(w->ls);
+  rldl_batch_free(w->pls);
 #define FR(p) if (p) (void)hipFree(p)
   FR(w->Px); FR(w->Ax); FR(w->q); FR(w->l); FR(w->u);
   FR(w->W.x); FR(w->W.z); FR(w->W.y); FR(w->W.delta_x); FR(w->W.delta_y); FR(w->W.rho_vec); FR(w->W.constr_type);
   FR(w->W.pri_res); FR(w->W.dua_res); FR(w->W.obj); FR(w->W.rho_cur); FR(w->W.rho_est); FR(w->W.status);
   FR(w->W.iter); FR(w->W.rho_updates); FR(w->W.refactor); FR(w->W.n_active);
+  FR(w->W.pol_Ax); FR(w->W.pol_b); FR(w->W.pol_z); FR(w->W.pol_r); FR(w->W.pol_mask); FR(w->W.status_polish);
   FR(w->W.sD); FR(w->W.sDinv); FR(w->W.sE); FR(w->W.sEinv); FR(w->W.sc); FR(w->W.scinv); FR(w->W.sol_x); FR(w->W.sol_y);
 #undef FR
   if (w->ev0) (void)hipEventDestroy((hipEvent_t)w->ev0);
@@ -109,8 +113,9 @@ c_int osqp_batch_setup(osqp_batch **wp, c_int batch, const csc *P, const csc *A,
   if (!rldl_device_available()) return RLDL_NO_DEVICE_ERROR;
   if (!P || !A || !settings || batch <= 0) return 1;                /* OSQP_DATA_VALIDATION_ERROR */
   if (settings->scaling < 0 || settings->rho <= 0 || settings->sigma <= 0 || settings->alpha <= 0 ||
-      settings->alpha >= 2 || settings->max_iter <= 0)
-    return 2;                                                       /* OSQP_SETTINGS_VALIDATION_ERROR */
+      settings->alpha >= 2 || settings->max_iter <= 0 || (settings->polish != 0 && settings->polish != 1) ||
+      settings->polish_refine_iter < 0 || (settings->polish && settings->delta <= 0))
+    return 2;                                                       /* OSQP_SETTINGS_VALIDATION_ERROR (auxil.c:893-1008) */
   w = (osqp_batch *)calloc(1, sizeof(osqp_batch));
   if (!w) return RLDL_MEM_ALLOC_ERROR;
   n = P->n; m = A->m; B = (size_t)batch;
@@ -139,6 +144,14 @@ c_int osqp_batch_setup(osqp_batch **wp, c_int batch, const csc *P, const csc *A,
   w->W.status = (int *)dmalloc(sizeof(int) * B, &ok); w->W.iter = (int *)dmalloc(sizeof(int) * B, &ok);
   w->W.rho_updates = (int *)dmalloc(sizeof(int) * B, &ok); w->W.refactor = (int *)dmalloc(sizeof(int) * B, &ok);
   w->W.n_active = (int *)dmalloc(sizeof(int), &ok);
+  w->W.status_polish = (int *)dmalloc(sizeof(int) * B, &ok);
+  if (w->st.polish) {
+    w->W.pol_Ax = (double *)dmalloc(sizeof(double) * B * (size_t)w->nnzA, &ok);
+    w->W.pol_b = (double *)dmalloc(sizeof(double) * B * (size_t)(n + m), &ok);
+    w->W.pol_z = (double *)dmalloc(sizeof(double) * B * (size_t)(n + m), &ok);
+    w->W.pol_r = (double *)dmalloc(sizeof(double) * B * (size_t)(n + m), &ok);
+    w->W.pol_mask = (int *)dmalloc(sizeof(int) * B, &ok);
+  }
   w->W.sol_x = (double *)dmalloc(sizeof(double) * B * (size_t)n, &ok);
   w->W.sol_y = (double *)dmalloc(sizeof(double) * B * (size_t)m, &ok);
   w->W.scaling = (int)w->st.scaling; w->W.scaled_termination = (int)w->st.scaled_termination;
@@ -187,6 +200,11 @@ c_int osqp_batch_setup(osqp_batch **wp, c_int batch, const csc *P, const csc *A,
     if (rc) { osqp_batch_cleanup(w); return rc; }
   }
   (void)hipMemsetAsync(w->W.refactor, 0, sizeof(int) * B, (hipStream_t)stream);
+  (void)hipMemsetAsync(w->W.status_polish, 0, sizeof(int) * B, (hipStream_t)stream);
+  if (w->st.polish) {   /* polish.c:228-231: init_linsys_solver(&plsh, P, Ared, delta, NULL, ..., 1), once per pattern here */
+    rc = rldl_batch_init(&w->pls, batch, P, A, w->Px, w->Ax, w->st.delta, 0, 1, 0, stream);
+    if (rc) { osqp_batch_cleanup(w); return rc; }
+  }
   if (w->st.adaptive_rho && !w->st.adaptive_rho_interval) /* osqp.c:266-279 */
     w->st.adaptive_rho_interval = w->st.check_termination ? 4 * w->st.check_termination : 100;
   *wp = w;
@@ -201,6 +219,21 @@ static int read_active(osqp_batch *w) {
 }
 
 static c_int solve_impl(osqp_batch *w, int wait);
+
+/* polish (src/polish.c:212-350) of every instance that reached OSQP_SOLVED; all on the workspace's stream */
+static c_int run_polish(osqp_batch *w) {
+  const rldl_dev_sym *S = &w->ls->dsym;
+  c_int it;
+  if (rldl_launch_polish_prep(S, &w->W, w->stream)) return 1;
+  if (rldl_launch_kkt_assemble(&w->pls->dsym, &w->pls->num, w->Px, w->W.pol_Ax, 0, 0, w->W.pol_mask, w->stream)) return 1;
+  if (rldl_launch_factor(&w->pls->dsym, &w->pls->num, w->W.pol_mask, w->stream)) return 1;
+  if (rldl_launch_solve(&w->pls->dsym, &w->pls->num, w->W.pol_z, w->stream)) return 1;          /* plsh->solve(plsh, pol_sol) */
+  for (it = 0; it < w->st.polish_refine_iter; it++) {                                           /* iterative_refinement */
+    if (rldl_launch_polish_resid(S, &w->W, it > 0, w->stream)) return 1;
+    if (rldl_launch_solve(&w->pls->dsym, &w->pls->num, w->W.pol_r, w->stream)) return 1;
+  }
+  return rldl_launch_polish_finish(S, &w->W, w->st.polish_refine_iter > 0, w->stream) ? 1 : 0;
+}
 
 c_int osqp_batch_solve(osqp_batch *w) { return solve_impl(w, 1); }
 
@@ -276,6 +309,7 @@ static c_int solve_impl(osqp_batch *w, int wait) {
   (void)hipEventRecord((hipEvent_t)w->ev1, st);
   /* tail of osqp_solve (osqp.c:521-633) */
   if (rldl_launch_admm_check(&w->ls->dsym, &w->W, (int)last_iter, 0, can_check ? 1 : 2, w->stream)) return 1;
+  if (w->st.polish && run_polish(w)) return 1;                   /* osqp.c:591-595 */
   w->last_loop_launches = launches;
   w->last_loop_groups = groups;
   w->loop_pending = 1;
@@ -403,6 +437,12 @@ c_int osqp_batch_get_iterates(osqp_batch *w, c_float **d_x, c_float **d_y, c_flo
   if (d_z) *d_z = w->W.z;
   if (d_delta_x) *d_delta_x = w->W.delta_x;
   if (d_delta_y) *d_delta_y = w->W.delta_y;
+  return 0;
+}
+
+c_int osqp_batch_get_polish_status(osqp_batch *w, int **d_status_polish) {
+  if (!w || !d_status_polish) return 1;
+  *d_status_polish = w->W.status_polish;
   return 0;
 }
 

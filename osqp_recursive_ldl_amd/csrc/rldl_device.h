@@ -75,6 +75,9 @@ typedef struct {
   int *refactor;                                       /* [batch] mask written by the adapt-rho step */
   int *n_active;                                       /* [1] instances still iterating */
   int write_delta;                                     /* 1: this iteration also stores delta_x / delta_y (a check follows) */
+  /* polish (src/polish.c): masked copy of A (inactive rows zeroed), rhs / solution / refinement vectors [batch][n+m] */
+  double *pol_Ax, *pol_b, *pol_z, *pol_r;
+  int *pol_mask, *status_polish;
   int trace_iter;                                      /* iteration of the launch whose phases are recorded (-1: the last) */
   long long *trace;                                    /* wave timeline [batch][8] (s_memrealtime ticks) or NULL; osqp_batch_trace_iteration */
   /* Ruiz equilibration (src/scaling.c): per-instance D[n], E[m], their inverses, cost scaling c; 0 iterations = off */
@@ -96,6 +99,9 @@ int rldl_launch_solve(const rldl_dev_sym *S, const rldl_dev_num *Nn, double *d_b
 int rldl_launch_admm_iter(const rldl_dev_sym *S, const rldl_dev_num *Nn, const rldl_dev_admm *W, void *stream);
 int rldl_launch_bcast_rows(int batch, int len, double *dst, const double *src, void *stream);
 int rldl_launch_set_range(int batch, int ld, int start, int cnt, double *dst, const double *src, const double *s, void *stream);
+int rldl_launch_polish_prep(const rldl_dev_sym *S, const rldl_dev_admm *W, void *stream);
+int rldl_launch_polish_resid(const rldl_dev_sym *S, const rldl_dev_admm *W, int add_first, void *stream);
+int rldl_launch_polish_finish(const rldl_dev_sym *S, const rldl_dev_admm *W, int add_last, void *stream);
 int rldl_launch_admm_iters(const rldl_dev_sym *S, const rldl_dev_num *Nn, const rldl_dev_admm *W, int iters, void *stream);
 int rldl_launch_admm_check(const rldl_dev_sym *S, const rldl_dev_admm *W, int iter, int approximate, int final_pass,
                            void *stream);

@@ -26,6 +26,7 @@ struct osqp_batch {
   c_int batch, n, m, nnzP, nnzA;
   OSQPBatchSettings st;
   rldl_batch *ls;
+  rldl_batch *pls;               /* polish = 1 backend on the same patterns (delta-regularised reduced KKT), or NULL */
   rldl_dev_admm W;
   double *Px, *Ax, *q, *l, *u;   /* owned device copies of the problem data (osqp.c:106-114) */
   void *stream;

@@ -545,6 +545,103 @@ __global__ __launch_bounds__(WAVE) void k_admm_check(rldl_dev_sym S, rldl_dev_ad
 }
 
 // ------------------------------------------------------------------------------------------------
+// Polish (src/polish.c) for every instance whose status is OSQP_SOLVED, one wave per instance.  The reference builds a
+// reduced matrix Ared from the rows guessed active and factorises [P + delta I, Ared'; Ared, -delta I] from scratch.
+// Here the reduced system keeps the SHARED pattern: the rows of A that are not active are zeroed (pol_Ax), their
+// right-hand side is 0, so they decouple (-delta y_i = 0) and the backend's polish = 1 mode factorises all instances
+// with one symbolic analysis.  k_polish_prep: form_Ared + form_rhs_red (:19-121); k_polish_resid: the right-hand side
+// b - K z of one refinement step (:134-181, K without the delta terms); k_polish_finish: polished (x, z, y), normal
+// cone projection (proj.c:16-29), residuals and objective at that point (update_info, auxil.c:567-626), acceptance
+// test and commit (polish.c:283-325) plus store_solution for the accepted instances.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WAVE) void k_polish_prep(rldl_dev_sym S, rldl_dev_admm W) {
+  const int inst = blockIdx.x, lane = threadIdx.x, n = S.n, m = S.m;
+  const int go = W.status[inst] == ST_SOLVED;
+  if (lane == 0) { W.pol_mask[inst] = go; W.status_polish[inst] = 0; }
+  if (!go) return;
+  extern __shared__ double sh[];
+  int *act = reinterpret_cast<int *>(sh);
+  const double *z = W.z + (size_t)inst * m, *y = W.y + (size_t)inst * m, *l = W.l + (size_t)inst * m, *u = W.u + (size_t)inst * m;
+  const double *q = W.q + (size_t)inst * n, *Av = W.Ax + (size_t)inst * S.nnzA;
+  double *b = W.pol_b + (size_t)inst * S.N, *z0 = W.pol_z + (size_t)inst * S.N, *Ar = W.pol_Ax + (size_t)inst * S.nnzA;
+  for (int i = lane; i < m; i += WAVE) {
+    const int a = (z[i] - l[i] < -y[i]) ? 1 : ((u[i] - z[i] < y[i]) ? 2 : 0);      // lower-active / upper-active / free
+    act[i] = a;
+    const double v = a == 1 ? l[i] : (a == 2 ? u[i] : 0.0);
+    b[n + i] = v; z0[n + i] = v;
+  }
+  for (int j = lane; j < n; j += WAVE) { const double v = -q[j]; b[j] = v; z0[j] = v; }
+  __syncthreads();
+  for (int p = lane; p < S.nnzA; p += WAVE) Ar[p] = act[S.Ai[p]] ? Av[p] : 0.0;
+}
+
+__global__ __launch_bounds__(WAVE) void k_polish_resid(rldl_dev_sym S, rldl_dev_admm W, int add_first) {
+  const int inst = blockIdx.x, lane = threadIdx.x, n = S.n, m = S.m;
+  if (!W.pol_mask[inst]) return;
+  extern __shared__ double sh[];
+  double *zx = sh, *zy = zx + n, *t1 = zy + m, *t2 = t1 + n, *t3 = t2 + n;
+  const double *Pv = W.Px + (size_t)inst * S.nnzP, *Ar = W.pol_Ax + (size_t)inst * S.nnzA, *b = W.pol_b + (size_t)inst * S.N;
+  double *z = W.pol_z + (size_t)inst * S.N, *r = W.pol_r + (size_t)inst * S.N;
+  for (int j = lane; j < S.N; j += WAVE) {
+    const double v = add_first ? z[j] + r[j] : z[j];                               // z <- z + dz of the previous step
+    if (add_first) z[j] = v;
+    if (j < n) zx[j] = v; else zy[j - n] = v;
+  }
+  __syncthreads();
+  spmv_Psym(S, Pv, zx, t1, lane);
+  spmv_At(S, Ar, zy, t2, lane);
+  spmv_A(S, Ar, zx, t3, lane);
+  __syncthreads();
+  for (int j = lane; j < n; j += WAVE) r[j] = (b[j] - t1[j]) - t2[j];
+  for (int i = lane; i < m; i += WAVE) r[n + i] = b[n + i] - t3[i];
+}
+
+__global__ __launch_bounds__(WAVE) void k_polish_finish(rldl_dev_sym S, rldl_dev_admm W, int add_last) {
+  const int inst = blockIdx.x, lane = threadIdx.x, n = S.n, m = S.m;
+  if (!W.pol_mask[inst]) return;
+  extern __shared__ double sh[];
+  double *px = sh, *py = px + n, *pz = py + m, *vAx = pz + m, *vPx = vAx + m, *vAty = vPx + n, *t_n = vAty + n, *t_m = t_n + n;
+  const double *Pv = W.Px + (size_t)inst * S.nnzP, *Av = W.Ax + (size_t)inst * S.nnzA;
+  const double *q = W.q + (size_t)inst * n, *l = W.l + (size_t)inst * m, *u = W.u + (size_t)inst * m;
+  const double *zs = W.pol_z + (size_t)inst * S.N, *r = W.pol_r + (size_t)inst * S.N;
+  for (int j = lane; j < n; j += WAVE) px[j] = add_last ? zs[j] + r[j] : zs[j];
+  for (int i = lane; i < m; i += WAVE) py[i] = add_last ? zs[n + i] + r[n + i] : zs[n + i];     // rows that are not active carry 0
+  __syncthreads();
+  spmv_A(S, Av, px, vAx, lane);                                                     // pol->z = A pol->x
+  __syncthreads();
+  for (int i = lane; i < m; i += WAVE) {                                            // project_normalcone
+    const double t = vAx[i] + py[i];
+    const double zi = fmin(fmax(t, l[i]), u[i]);
+    pz[i] = zi; py[i] = t - zi;
+  }
+  __syncthreads();
+  spmv_Psym(S, Pv, px, vPx, lane);
+  spmv_At(S, Av, py, vAty, lane);
+  __syncthreads();
+  for (int i = lane; i < m; i += WAVE) t_m[i] = vAx[i] - pz[i];
+  for (int j = lane; j < n; j += WAVE) t_n[j] = q[j] + vPx[j] + vAty[j];
+  __syncthreads();
+  const bool uns = W.scaling && !W.scaled_termination;
+  const double *sDinv = uns ? W.sDinv + (size_t)inst * n : nullptr, *sEinv = uns ? W.sEinv + (size_t)inst * m : nullptr;
+  const double scinv = W.scaling ? W.scinv[inst] : 1.0;
+  const double ppri = m ? norm_inf_s(sEinv, t_m, m, lane) : 0.0;
+  const double pdua = (uns ? scinv : 1.0) * norm_inf_s(sDinv, t_n, n, lane);
+  double o = 0.0;
+  for (int j = lane; j < n; j += WAVE) o += (0.5 * vPx[j] + q[j]) * px[j];
+  o = wave_sum(o) * (W.scaling ? scinv : 1.0);
+  const double ipri = W.pri_res[inst], idua = W.dua_res[inst];
+  const bool ok = (ppri < ipri && pdua < idua) || (ppri < ipri && idua < 1e-10) || (pdua < idua && ipri < 1e-10);
+  if (lane == 0) W.status_polish[inst] = ok ? 1 : -1;
+  if (!ok) return;
+  if (lane == 0) { W.obj[inst] = o; W.pri_res[inst] = ppri; W.dua_res[inst] = pdua; }
+  double *x = W.x + (size_t)inst * n, *z = W.z + (size_t)inst * m, *y = W.y + (size_t)inst * m;
+  double *sx = W.sol_x + (size_t)inst * n, *sy = W.sol_y + (size_t)inst * m;
+  const double *D = W.scaling ? W.sD + (size_t)inst * n : nullptr, *E = W.scaling ? W.sE + (size_t)inst * m : nullptr;
+  for (int j = lane; j < n; j += WAVE) { x[j] = px[j]; sx[j] = D ? D[j] * px[j] : px[j]; }
+  for (int i = lane; i < m; i += WAVE) { z[i] = pz[i]; y[i] = py[i]; sy[i] = E ? E[i] * py[i] * scinv : py[i]; }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Ruiz equilibration of one instance per wave (scale_data, src/scaling.c:44-156): `iters` passes of
 // D, E <- 1/sqrt(inf-norm of the KKT columns) applied to P, A, q, followed by the cost normalisation
 // step; ends with Dinv, Einv, cinv and the scaling of l, u.  Works in place on the workspace's own
@@ -2158,6 +2255,24 @@ extern "C" int rldl_launch_set_rho_vec(const rldl_dev_sym *S, const rldl_dev_adm
   return launch_status();
 }
 
+
+extern "C" int rldl_launch_polish_prep(const rldl_dev_sym *S, const rldl_dev_admm *W, void *stream) {
+  if (W->batch <= 0) return 0;
+  hipLaunchKernelGGL(k_polish_prep, dim3(W->batch), dim3(WAVE), sizeof(int) * (size_t)(S->m + 2), (hipStream_t)stream, *S, *W);
+  return launch_status();
+}
+extern "C" int rldl_launch_polish_resid(const rldl_dev_sym *S, const rldl_dev_admm *W, int add_first, void *stream) {
+  if (W->batch <= 0) return 0;
+  hipLaunchKernelGGL(k_polish_resid, dim3(W->batch), dim3(WAVE), sizeof(double) * (size_t)(3 * S->n + 2 * S->m + 2), (hipStream_t)stream,
+                     *S, *W, add_first);
+  return launch_status();
+}
+extern "C" int rldl_launch_polish_finish(const rldl_dev_sym *S, const rldl_dev_admm *W, int add_last, void *stream) {
+  if (W->batch <= 0) return 0;
+  hipLaunchKernelGGL(k_polish_finish, dim3(W->batch), dim3(WAVE), sizeof(double) * (size_t)(4 * S->n + 5 * S->m + 2), (hipStream_t)stream,
+                     *S, *W, add_last);
+  return launch_status();
+}
 
 extern "C" int rldl_launch_scale_data(const rldl_dev_sym *S, const rldl_dev_admm *W, double *Px, double *Ax, double *q, double *l,
                                       double *u, int iters, void *stream) {

@@ -136,6 +136,9 @@ class OSQPBatch:
         _lib.lib().osqp_batch_get_iterates(self.h, *[C.byref(t) for t in it])
         out.update(x_iter=self._view(it[0].value, (B, n), torch.float64), y_iter=self._view(it[1].value, (B, m), torch.float64),
                    delta_x=self._view(it[3].value, (B, n), torch.float64), delta_y=self._view(it[4].value, (B, m), torch.float64))
+        ps = C.c_void_p()
+        _lib.lib().osqp_batch_get_polish_status(self.h, C.byref(ps))
+        out["status_polish"] = self._view(ps.value, (B,), torch.int32)
         if clone:
             out = {k: v.clone() for k, v in out.items()}
         return out

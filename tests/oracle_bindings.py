@@ -28,12 +28,13 @@ class Settings(C.Structure):
                 ("eps_rel", c_float), ("eps_prim_inf", c_float), ("eps_dual_inf", c_float),
                 ("max_iter", c_int), ("check_termination", c_int), ("warm_start", c_int),
                 ("scaling", c_int), ("scaled_termination", c_int), ("adaptive_rho", c_int),
-                ("adaptive_rho_interval", c_int), ("adaptive_rho_tolerance", c_float)]
+                ("adaptive_rho_interval", c_int), ("adaptive_rho_tolerance", c_float),
+                ("polish", c_int), ("polish_refine_iter", c_int), ("delta", c_float)]
 
 
 class Info(C.Structure):
     _fields_ = [("iter", c_int), ("status_val", c_int), ("rho_updates", c_int), ("obj_val", c_float),
-                ("pri_res", c_float), ("dua_res", c_float), ("rho_estimate", c_float)]
+                ("pri_res", c_float), ("dua_res", c_float), ("rho_estimate", c_float), ("status_polish", c_int)]
 
 
 def build(force=False):
@@ -223,7 +224,7 @@ class OracleOSQP:
         info = lib().orc_ws_info(self.h).contents
         return dict(flag=flag, x=self._vec(lib().orc_ws_sol_x, self.n), y=self._vec(lib().orc_ws_sol_y, self.m),
                     iter=info.iter, status=info.status_val, obj=info.obj_val, pri_res=info.pri_res,
-                    dua_res=info.dua_res, rho_updates=info.rho_updates,
+                    dua_res=info.dua_res, rho_updates=info.rho_updates, status_polish=info.status_polish,
                     x_iter=self._vec(lib().orc_ws_x, self.n), y_iter=self._vec(lib().orc_ws_y, self.m),
                     z_iter=self._vec(lib().orc_ws_z, self.m), delta_x=self._vec(lib().orc_ws_delta_x, self.n),
                     delta_y=self._vec(lib().orc_ws_delta_y, self.m))

@@ -230,3 +230,36 @@ def test_infeasibility_certificates_with_scaling(R):
             assert relerr(r["x"][0].cpu().numpy(), ro["x"]) < 1e-7
         w.cleanup()
     assert {1, -3, -4} <= seen
+
+
+@pytest.mark.parametrize("scaling", [0, 10])
+def test_polish_matches_oracle_and_fixture(R, scaling):
+    """Batched polish (src/polish.c) on the shared pattern: status_polish, polished x / y / obj / residuals vs the oracle's
+    reduced-matrix polish, and the basic_qp optimum to 1e-9 from eps = 1e-3 ADMM iterates."""
+    d = load_golden("basic_qp"); s = d["sols"]
+    kw = dict(eps_abs=1e-3, eps_rel=1e-3, max_iter=4000, check_termination=25, scaling=scaling, adaptive_rho=1, adaptive_rho_interval=100,
+              polish=1, polish_refine_iter=3, delta=1e-6)
+    w, Pc, Ac = _golden_batch(R, d["P"], d["q"], d["A"], d["l"], d["u"], **kw)
+    r = w.solve()
+    assert int(r["status"][0]) == 1 and int(r["status_polish"][0]) == 1
+    assert np.max(np.abs(r["x"][0].cpu().numpy() - s["x_test"])) < 1e-9
+    assert np.max(np.abs(r["y"][0].cpu().numpy() - s["y_test"])) < 1e-9
+    assert abs(float(r["obj"][0]) - s["obj_value_test"]) < 1e-9
+    w.cleanup()
+    # metric shape: per-instance comparison with the oracle (which removes the inactive rows instead of zeroing them)
+    wl = R.workloads.SharedPatternQPs()
+    B = 6
+    Px, Ax, q, l, u = wl.values(B)
+    w = R.OSQPBatch(wl.P_pattern, wl.A_pattern, dev(Px), dev(Ax), dev(q), dev(l), dev(u), **kw)
+    r = w.solve()
+    perm = w.linsys().export_symbolic()["perm"]
+    for b in range(B):
+        P, qq, A, ll, uu = wl.instance(b)
+        ro = ob.OracleOSQP(P, qq, A, ll, uu, perm=perm, **kw).solve()
+        assert int(r["status"][b]) == ro["status"] and int(r["iter"][b]) == ro["iter"]
+        assert int(r["status_polish"][b]) == ro["status_polish"]
+        assert relerr(r["x"][b].cpu().numpy(), ro["x"]) < 1e-8 and relerr(r["y"][b].cpu().numpy(), ro["y"]) < 1e-8
+        assert abs(float(r["obj"][b]) - ro["obj"]) < 1e-8 * max(1, abs(ro["obj"]))
+        if ro["status_polish"] == 1:
+            assert float(r["pri_res"][b]) < 1e-9 and float(r["dua_res"][b]) < 1e-9
+    w.cleanup()

@@ -274,3 +274,21 @@ def test_etree_rejects_lower_entries():
     assert ob.lib().orc_qdldl_etree(2, ob.ip(Ap), ob.ip(Ai), ob.ip(w), ob.ip(Lnz), ob.ip(et)) < 0
     Ap = np.array([0, 1, 1], np.int64); Ai = np.array([0], np.int64)  # empty column
     assert ob.lib().orc_qdldl_etree(2, ob.ip(Ap), ob.ip(Ai), ob.ip(w), ob.ip(Lnz), ob.ip(et)) < 0
+
+
+def test_polish_recovers_the_fixture_optimum_to_machine_precision():
+    """src/polish.c restated in the oracle: with loose ADMM tolerances (eps 1e-3) the unpolished iterate is ~1e-3 away
+    from the reference's known optimum of basic_qp; the polished one hits it (the reference's own test runs this
+    fixture with polish = 1, tests/basic_qp/test_basic_qp.h:32, and checks x, y, obj at 1e-4)."""
+    from scipy import sparse
+    d = load_golden("basic_qp"); s = d["sols"]
+    inf = lambda v: np.clip(np.asarray(v, float), -1e30, 1e30)
+    kw = dict(eps_abs=1e-3, eps_rel=1e-3, max_iter=4000, check_termination=25, scaling=10, adaptive_rho=1, adaptive_rho_interval=100)
+    P, A = sparse.triu(sparse.csc_matrix(d["P"]), format="csc"), sparse.csc_matrix(d["A"])
+    plain = ob.OracleOSQP(P, d["q"], A, inf(d["l"]), inf(d["u"]), polish=0, **kw).solve()
+    pol = ob.OracleOSQP(P, d["q"], A, inf(d["l"]), inf(d["u"]), polish=1, **kw).solve()
+    assert plain["status"] == pol["status"] == 1 and plain["status_polish"] == 0 and pol["status_polish"] == 1
+    assert np.max(np.abs(plain["x"] - s["x_test"])) > 1e-4
+    assert np.max(np.abs(pol["x"] - s["x_test"])) < 1e-9 and np.max(np.abs(pol["y"] - s["y_test"])) < 1e-9
+    assert abs(pol["obj"] - s["obj_value_test"]) < 1e-9
+    assert pol["pri_res"] < 1e-12 and pol["dua_res"] < 1e-12
