@@ -98,6 +98,11 @@ def metric_shape():
     emit(name="metric_shape_batch4096_default_termination_scaling10", batch=B, ms_per_solve=ms, qp_solves_per_sec=B / (ms * 1e-3),
          mean_iterations=float(r["iter"].double().mean()), solved=int((r["status"] == 1).sum()))
     w.cleanup()
+    w = R.OSQPBatch(wl.P_pattern, wl.A_pattern, dPx, dAx, t(q), t(l), t(u), polish=1, **kwd)
+    ms = timed(stepd, reps=5)
+    emit(name="metric_shape_batch4096_default_termination_scaling10_polish", batch=B, ms_per_solve=ms, qp_solves_per_sec=B / (ms * 1e-3),
+         polished=int((r["status_polish"] == 1).sum()), max_pri_res=float(r["pri_res"].max()), max_dua_res=float(r["dua_res"].max()))
+    w.cleanup()
 
 
 def pattern_groups():
