@@ -154,6 +154,9 @@ c_int osqp_batch_wait(osqp_batch *w);
 c_int osqp_batch_update_lin_cost(osqp_batch *w, const c_float *d_q);   /* osqp.c:752-790 */
 c_int osqp_batch_update_bounds(osqp_batch *w, const c_float *d_l, const c_float *d_u); /* osqp.c:792-841 */
 c_int osqp_batch_update_rho(osqp_batch *w, c_float rho_new);           /* osqp.c:1268-1319 */
+/* osqp_update_max_iter, _eps_abs, _eps_rel, _eps_prim_inf, _eps_dual_inf, _alpha, _warm_start, _scaled_termination,
+ * _check_termination, _polish_refine_iter, _delta (osqp.c:1321-1560) in one call; other fields of `s` are ignored */
+c_int osqp_batch_update_settings(osqp_batch *w, const OSQPBatchSettings *s);
 c_int osqp_batch_update_P_A(osqp_batch *w, const c_float *d_Px, const c_float *d_Ax); /* osqp.c:1158-1266 */
 c_int osqp_batch_warm_start(osqp_batch *w, const c_float *d_x, const c_float *d_y);   /* osqp.c:929-948 */
 /* results: device pointers owned by the workspace (valid until cleanup).  x, y are the OSQPSolution of

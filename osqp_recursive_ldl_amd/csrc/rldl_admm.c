@@ -373,6 +373,27 @@ c_int osqp_batch_update_recursive(osqp_batch *w, c_int first_stage, const c_floa
   return rldl_batch_update_from_stage(w->ls, first_stage, d_Px ? w->Px : 0, d_Ax ? w->Ax : 0, 0);
 }
 
+/* osqp_update_max_iter / _eps_abs / _eps_rel / _eps_prim_inf / _eps_dual_inf / _alpha / _warm_start / _scaled_termination /
+ * _check_termination / _polish_refine_iter / _delta (src/osqp.c:1321-1560) in one call: the fields listed are taken from
+ * `s` after the reference's range checks; rho, sigma, scaling, adaptive-rho and polish on/off are fixed at setup
+ * (rho has osqp_batch_update_rho). */
+c_int osqp_batch_update_settings(osqp_batch *w, const OSQPBatchSettings *s) {
+  if (!w) return 7;
+  if (!s || s->max_iter <= 0 || s->eps_abs < 0 || s->eps_rel < 0 || (s->eps_abs == 0 && s->eps_rel == 0) || s->eps_prim_inf <= 0 ||
+      s->eps_dual_inf <= 0 || s->alpha <= 0 || s->alpha >= 2 || (s->warm_start != 0 && s->warm_start != 1) ||
+      (s->scaled_termination != 0 && s->scaled_termination != 1) || s->check_termination < 0 || s->polish_refine_iter < 0 ||
+      (w->st.polish && s->delta <= 0))
+    return 1;
+  w->st.max_iter = s->max_iter; w->st.eps_abs = s->eps_abs; w->st.eps_rel = s->eps_rel; w->st.eps_prim_inf = s->eps_prim_inf;
+  w->st.eps_dual_inf = s->eps_dual_inf; w->st.alpha = s->alpha; w->st.warm_start = s->warm_start;
+  w->st.scaled_termination = s->scaled_termination; w->st.check_termination = s->check_termination;
+  w->st.polish_refine_iter = s->polish_refine_iter;
+  if (w->st.polish && s->delta != w->st.delta) { w->st.delta = s->delta; w->pls->num.sigma = s->delta; }
+  w->W.alpha = w->st.alpha; w->W.eps_abs = w->st.eps_abs; w->W.eps_rel = w->st.eps_rel; w->W.eps_prim_inf = w->st.eps_prim_inf;
+  w->W.eps_dual_inf = w->st.eps_dual_inf; w->W.scaled_termination = (int)w->st.scaled_termination;
+  return 0;
+}
+
 c_int osqp_batch_update_rho(osqp_batch *w, c_float rho_new) {
   if (!w) return 7;
   if (rho_new <= 0) return 1;

@@ -160,6 +160,21 @@ class OSQPBatch:
         _dev_f64(l, (self.batch, self.m), "l"); _dev_f64(u, (self.batch, self.m), "u")
         return int(_lib.lib().osqp_batch_update_bounds(self.h, _dptr(l), _dptr(u)))
 
+    def update_settings(self, **kw):
+        """osqp_update_max_iter / _eps_* / _alpha / _warm_start / _scaled_termination / _check_termination /
+        _polish_refine_iter / _delta: returns the C return code (1 = a value failed the reference's range check)."""
+        for k, v in kw.items():
+            if not hasattr(self.settings, k):
+                raise KeyError("unknown setting %r" % k)
+        new = type(self.settings)()
+        C.memmove(C.byref(new), C.byref(self.settings), C.sizeof(new))
+        for k, v in kw.items():
+            setattr(new, k, v)
+        rc = int(_lib.lib().osqp_batch_update_settings(self.h, C.byref(new)))
+        if rc == 0:
+            self.settings = new
+        return rc
+
     def update_rho(self, rho):
         return int(_lib.lib().osqp_batch_update_rho(self.h, float(rho)))
 

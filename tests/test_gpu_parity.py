@@ -517,3 +517,19 @@ def test_pattern_groups_solve_mixed_sparsity_batches(R):
     ro = ob.OracleOSQP(P, q, A, l, u, perm=w.linsys().export_symbolic()["perm"], **kw2).solve()
     assert int(r2["iter"][4]) == ro["iter"] and int(r2["status"][4]) == ro["status"]
     g.cleanup(); g2.cleanup()
+
+
+def test_update_settings_mirrors_the_reference_setters(R):
+    """osqp_update_max_iter / _eps_abs / ... (src/osqp.c:1321-1560): range checks as in test_basic_qp.h:88-160, and the
+    new values take effect (tighter eps -> more iterations, same count as a fresh workspace with those settings)."""
+    d = load_golden("basic_qp")
+    w = _solve_golden(R, d["P"], d["q"], d["A"], d["l"], d["u"], reps=2, eps_abs=1e-3, eps_rel=1e-3, check_termination=1, adaptive_rho=0)
+    it0 = int(w.solve()["iter"][0])
+    assert w.update_settings(max_iter=-1) == 1 and w.update_settings(eps_abs=-1.0) == 1 and w.update_settings(alpha=2.0) == 1
+    assert w.update_settings(warm_start=2) == 1 and w.update_settings(check_termination=-1) == 1 and w.update_settings(eps_prim_inf=0.0) == 1
+    assert w.update_settings(eps_abs=1e-7, eps_rel=1e-7, warm_start=0) == 0
+    it1 = int(w.solve()["iter"][0])
+    fresh = _solve_golden(R, d["P"], d["q"], d["A"], d["l"], d["u"], reps=2, eps_abs=1e-7, eps_rel=1e-7, check_termination=1, warm_start=0,
+                          adaptive_rho=0)
+    assert it1 == int(fresh.solve()["iter"][0]) > it0
+    w.cleanup(); fresh.cleanup()
