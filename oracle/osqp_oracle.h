@@ -4,7 +4,8 @@
  * Plain-C restatement of the single-instance CPU path of laperss/osqp-recursive-ldl
  * (OSQP v0.6.0): KKT assembly, symmetric permutation, the QDLDL contract
  * (etree / factor / solve), the `linsys_solver` backend (init / solve /
- * update_rho_vec / update_matrices) and the ADMM loop around it.
+ * update_rho_vec / update_matrices) and the ADMM loop around it, incl. Ruiz scaling
+ * (src/scaling.c) and polish (src/polish.c).
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use anything
  * in this directory, and only as the checker / the CPU number reported beside the GPU one.
@@ -14,7 +15,10 @@
  *   - pinned: form_KKT / update_KKT_* (tests/golden/update_matrices.json), init+solve incl. the
  *     z-tilde epilogue (tests/golden/solve_linsys.json), ADMM known answers (basic_qp, basic_qp2,
  *     unconstrained, update_matrices, non_cvx, primal_dual_infeasibility fixtures), all produced by
- *     importing the reference's own Python generators (tests/golden/make_golden.py).
+ *     importing the reference's own Python generators (tests/golden/make_golden.py).  Those fixtures
+ *     were generated with the reference's default scaling = 10, which pins the scaling restatement at the
+ *     fixtures' 1e-4; polish is pinned by basic_qp (the reference runs it with polish = 1): the polished
+ *     point reproduces the fixture's optimum to 1e-9 from eps = 1e-3 iterates.
  *   - NOT pinned by any reference fixture: L, D, Dinv, etree, Lnz (no reference test inspects
  *     them; checked here by the identity P K P' = L D L' and an independent dense symbolic
  *     factorisation), the fill-reducing permutation (the reference's vendored AMD needs the
