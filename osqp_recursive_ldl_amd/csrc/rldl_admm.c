@@ -6,7 +6,7 @@
  * osqp_update_P_A :1158-1266, osqp_update_rho :1268-1319, osqp_cleanup :646-744.
  * The host only sequences kernel launches; every vector lives on the device for the whole solve and
  * the only device->host traffic inside the loop is one 4-byte "instances still active" counter per
- * termination check.
+ * termination check, read back asynchronously.
  *
  * Documented divergences from the reference:
  *   - scaling (Ruiz equilibration, src/scaling.c) runs on the device, one wavefront per instance; the mean of the
@@ -96,6 +96,9 @@ void osqp_batch_cleanup(osqp_batch *w) {
   FR(w->W.pol_Ax); FR(w->W.pol_b); FR(w->W.pol_z); FR(w->W.pol_r); FR(w->W.pol_mask); FR(w->W.status_polish);
   FR(w->W.sD); FR(w->W.sDinv); FR(w->W.sE); FR(w->W.sEinv); FR(w->W.sc); FR(w->W.scinv); FR(w->W.sol_x); FR(w->W.sol_y);
 #undef FR
+  if (w->evn[0]) (void)hipEventDestroy((hipEvent_t)w->evn[0]);
+  if (w->evn[1]) (void)hipEventDestroy((hipEvent_t)w->evn[1]);
+  if (w->h_nact) (void)hipHostFree(w->h_nact);
   if (w->ev0) (void)hipEventDestroy((hipEvent_t)w->ev0);
   if (w->ev1) (void)hipEventDestroy((hipEvent_t)w->ev1);
   free(w->h_tmp_i); free(w->h_tmp_d);
@@ -160,7 +163,9 @@ c_int osqp_batch_setup(osqp_batch **wp, c_int batch, const csc *P, const csc *A,
     w->W.sE = (double *)dmalloc(sizeof(double) * B * (size_t)m, &ok); w->W.sEinv = (double *)dmalloc(sizeof(double) * B * (size_t)m, &ok);
     w->W.sc = (double *)dmalloc(sizeof(double) * B, &ok); w->W.scinv = (double *)dmalloc(sizeof(double) * B, &ok);
   }
-  if (!ok || !HIP_OK(hipEventCreate((hipEvent_t *)&w->ev0)) || !HIP_OK(hipEventCreate((hipEvent_t *)&w->ev1))) {
+  if (!ok || !HIP_OK(hipEventCreate((hipEvent_t *)&w->ev0)) || !HIP_OK(hipEventCreate((hipEvent_t *)&w->ev1)) ||
+      !HIP_OK(hipEventCreate((hipEvent_t *)&w->evn[0])) || !HIP_OK(hipEventCreate((hipEvent_t *)&w->evn[1])) ||
+      !HIP_OK(hipHostMalloc((void **)&w->h_nact, 2 * sizeof(int), hipHostMallocDefault))) {
     osqp_batch_cleanup(w);
     return RLDL_MEM_ALLOC_ERROR;
   }
@@ -211,12 +216,6 @@ c_int osqp_batch_setup(osqp_batch **wp, c_int batch, const csc *P, const csc *A,
   return 0;
 }
 
-static int read_active(osqp_batch *w) {
-  int v = -1;
-  if (!HIP_OK(hipMemcpyAsync(&v, w->W.n_active, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)w->stream))) return -1;
-  if (!HIP_OK(hipStreamSynchronize((hipStream_t)w->stream))) return -1;
-  return v;
-}
 
 static c_int solve_impl(osqp_batch *w, int wait);
 
@@ -257,7 +256,7 @@ c_int osqp_batch_wait(osqp_batch *w) {
 }
 
 static c_int solve_impl(osqp_batch *w, int wait) {
-  c_int iter, last_iter = 0, launches = 0, groups = 0;
+  c_int iter, last_iter = 0, launches = 0, groups = 0, nchecks = 0;
   int can_check = 0, nact;
   size_t B;
   hipStream_t st;
@@ -300,9 +299,18 @@ static c_int solve_impl(osqp_batch *w, int wait) {
         (void)hipMemsetAsync(w->W.refactor, 0, sizeof(int) * B, st);
       }
       if (can_check) {
-        nact = read_active(w);
-        if (nact < 0) return 1;
-        if (nact == 0) break;
+        /* The active-instance count comes back asynchronously and is looked at one check later: the next group is
+         * already queued while this one is still running.  Instances that are done leave the kernels at their first
+         * instruction, so the one speculative group after everybody has finished costs next to nothing, and the host
+         * never stalls the stream between groups. */
+        const int slot = (int)(nchecks & 1);
+        if (!HIP_OK(hipMemcpyAsync(&w->h_nact[slot], w->W.n_active, sizeof(int), hipMemcpyDeviceToHost, st))) return 1;
+        (void)hipEventRecord((hipEvent_t)w->evn[slot], st);
+        if (nchecks > 0) {
+          if (!HIP_OK(hipEventSynchronize((hipEvent_t)w->evn[slot ^ 1]))) return 1;
+          if (w->h_nact[slot ^ 1] == 0) break;
+        }
+        nchecks++;
       }
     }
   }

@@ -31,6 +31,8 @@ struct osqp_batch {
   double *Px, *Ax, *q, *l, *u;   /* owned device copies of the problem data (osqp.c:106-114) */
   void *stream;
   void *ev0, *ev1;
+  void *evn[2];                  /* events behind the asynchronous reads of the active-instance counter */
+  int *h_nact;                   /* [2] pinned */
   int *h_tmp_i;                  /* [batch] host scratch */
   double *h_tmp_d;               /* [batch] host scratch */
   int loop_pending;              /* a solve loop was enqueued and its event pair not read yet */
