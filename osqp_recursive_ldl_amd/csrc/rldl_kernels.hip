@@ -953,7 +953,7 @@ __device__ __forceinline__ void plan_tri_solve(const rldl_dev_sym &S, const int 
             const int ts = ok ? t + u : 0;
             const int base = __builtin_amdgcn_readlane(vb, ts), cnt = __builtin_amdgcn_readlane(vc, ts);
             const bool on = ok && lane < cnt;
-            v[u] = Sv[on ? base + lane : zs];
+            v[u] = Sv[(unsigned)(on ? base + lane : zs)];
             xv[u] = xs[fcol[on ? base + lane : 0]];
           }
 #pragma unroll
@@ -1000,7 +1000,7 @@ __device__ __forceinline__ void plan_tri_solve(const rldl_dev_sym &S, const int 
             const int base = __builtin_amdgcn_readlane(vb, ts), cnt = __builtin_amdgcn_readlane(vc, ts);
             const bool on = ok && lane < cnt;
             const unsigned rs = (unsigned)w[S.po_brs + (on ? base + lane : 0)];   // row | slot << 16
-            v[u] = Sv[on ? (int)(rs >> 16) : zs];
+            v[u] = Sv[on ? (rs >> 16) : (unsigned)zs];
             xv[u] = xs[rs & 0xffffu];
           }
 #pragma unroll
