@@ -170,6 +170,9 @@ c_int osqp_batch_get_iterates(osqp_batch *w, c_float **d_x, c_float **d_y, c_flo
 c_int osqp_batch_get_scaling(osqp_batch *w, c_float **d_D, c_float **d_E, c_float **d_c);
 /* info->status_polish per instance (types.h:95): 0 not performed, 1 successful, -1 unsuccessful */
 c_int osqp_batch_get_polish_status(osqp_batch *w, int **d_status_polish);
+/* settings->rho as each instance currently runs it (adapt_rho -> osqp_update_rho, src/auxil.c:41-77, src/osqp.c:1268-1319),
+ * info->rho_estimate and info->rho_updates (types.h:100-101): [batch] each */
+c_int osqp_batch_get_rho(osqp_batch *w, c_float **d_rho, c_float **d_rho_estimate, int **d_rho_updates);
 rldl_batch *osqp_batch_linsys(osqp_batch *w);
 /* timing of the fused ADMM-iteration kernel (HIP events on the workspace stream), for the roofline:
  * reps == 0: device time per ITERATION of the last solve loop; reps > 0: time `reps` single-iteration launches now */
@@ -211,7 +214,7 @@ c_int rldl_batch_update_from_stage(rldl_batch *h, c_int first_stage, const c_flo
  *   osqp_solve_recursive (:2867-...)                            -> osqp_batch_solve
  *   osqp_partial_update_bounds (:119-200)                       -> osqp_batch_partial_update_bounds
  *   get_L_dimensions (:1334-1342) / cleanup_rldl (:15-60)       -> rldl_batch_dims(osqp_batch_linsys(w)) / osqp_batch_cleanup
- * NOT built: osqp_update_recursive (:1973-2016), which CHANGES the horizon N.
+ *   osqp_update_recursive (:1973-2016, changes the horizon N)   -> osqp_horizon_update (section 5)
  * The stage blocks carry the NOMINAL values, replicated to every instance; per-instance values follow through
  * osqp_batch_update_P_A / osqp_batch_update_recursive in the value order of *P_out / *A_out (free with rldl_csc_free). */
 c_int osqp_batch_setup_recursive(osqp_batch **wp, c_int batch, const rldl_stage_dims *dims, const csc *Q0, const csc *Qi,
@@ -225,6 +228,34 @@ c_int rldl_setup_AP_matrices(const rldl_stage_dims *dims, const csc *Q0, const c
                              const csc *Ai, const csc *Aij, const csc *AN, csc **P_out, csc **A_out, c_int *P_kind,
                              c_int *P_stage, c_int *P_entry, c_int *A_kind, c_int *A_stage, c_int *A_entry);
 void rldl_csc_free(csc *M);
+
+/* =====================================================================================
+ * 5. Variable horizon (osqp_setup_recursive with Nmax + osqp_update_recursive, src/recursive_ldl.c:2018-2230, :1973-2016)
+ * ===================================================================================== */
+typedef struct osqp_horizon osqp_horizon;
+
+/* osqp_setup_recursive(workp, data, settings, Nmax, N, nx, nu, ny, nt): the problem is set up at horizon dims->N and may
+ * later move anywhere in 1..Nmax.  The seven stage blocks are copied (nominal values); d_q/d_l/d_u: [batch][n(N)], [batch][m(N)].
+ * Returns 0 or the codes of osqp_batch_setup; 1 when N is outside 1..Nmax. */
+c_int osqp_horizon_setup(osqp_horizon **hp, c_int batch, const rldl_stage_dims *dims, c_int Nmax, const csc *Q0, const csc *Qi,
+                         const csc *QN, const csc *A0, const csc *Ai, const csc *Aij, const csc *AN, const c_float *d_q,
+                         const c_float *d_l, const c_float *d_u, const OSQPBatchSettings *settings, void *stream);
+/* osqp_update_recursive(work, data, N) (:1973-2016): move every instance to horizon Nnew.  Returns -1 when Nnew is outside
+ * 1..Nmax (as the reference), 0 when Nnew is the current horizon (nothing happens) or on success.  d_q/d_l/d_u are the vectors
+ * of the NEW problem ([batch][Nnew (nx+nu)], [batch][Nnew (nx+ny) + nt]; the reference leaves their refresh to the caller).
+ * P / A: stages before min(N, Nnew) keep each instance's values, later stages are the nominal blocks again (update_AP_matrices,
+ * :1675-1778; upload per-instance values for them afterwards with osqp_batch_update_recursive).  The factor of the shared stages is
+ * copied from the old horizon and the stage recursion restarts at stage min(N, Nnew) (LDL_update_from_pivot, :946-1110);
+ * rho stays per instance; x / y carry over on the shared stages (terminal multipliers to the terminal rows) when
+ * warm_start is set.  The workspace handle of the new horizon is osqp_horizon_workspace(h): solve, update and read
+ * results through the osqp_batch_* calls; it stays owned by h (do not osqp_batch_cleanup it). */
+c_int osqp_horizon_update(osqp_horizon *h, c_int Nnew, const c_float *d_q, const c_float *d_l, const c_float *d_u);
+osqp_batch *osqp_horizon_workspace(osqp_horizon *h);
+c_int osqp_horizon_N(const osqp_horizon *h);
+/* what the last osqp_horizon_update did: the first stage that was refactorised, how many instances restarted there (the others
+ * were factorised from the first block), and whether the workspace of that horizon had to be created (first visit) */
+c_int osqp_horizon_last_update(const osqp_horizon *h, c_int *pivot_stage, c_int *instances_reused, c_int *workspace_created);
+void osqp_horizon_free(osqp_horizon *h);
 
 const char *rldl_version(void);
 

@@ -9,9 +9,9 @@ from ._lib import build, lib  # noqa: F401
 lib()  # fail at import time when the HIP extension is missing: there is no CPU fallback
 
 from .linsys import BatchLinsys, CscPattern, HipLDLSolver, symbolic_analyze  # noqa: E402,F401
-from .osqp_batch import OSQPBatch, STATUS_NAMES, default_settings  # noqa: E402,F401
+from .osqp_batch import OSQPBatch, OSQPHorizon, STATUS_NAMES, default_settings  # noqa: E402,F401
 from .groups import OSQPBatchGroups  # noqa: E402,F401
 from . import workloads  # noqa: E402,F401
 
-__all__ = ["BatchLinsys", "CscPattern", "HipLDLSolver", "OSQPBatch", "OSQPBatchGroups", "STATUS_NAMES", "default_settings",
+__all__ = ["BatchLinsys", "CscPattern", "HipLDLSolver", "OSQPBatch", "OSQPBatchGroups", "OSQPHorizon", "STATUS_NAMES", "default_settings",
            "symbolic_analyze", "workloads", "build", "lib"]

@@ -65,10 +65,12 @@ EXPORTED = [
     "rldl_batch_factor_status", "rldl_batch_time_solve",
     "osqp_batch_set_default_settings", "osqp_batch_setup", "osqp_batch_solve", "osqp_batch_update_lin_cost",
     "osqp_batch_update_bounds", "osqp_batch_update_rho", "osqp_batch_update_settings", "osqp_batch_update_P_A", "osqp_batch_warm_start",
-    "osqp_batch_get", "osqp_batch_get_iterates", "osqp_batch_get_scaling", "osqp_batch_get_polish_status", "osqp_batch_linsys", "osqp_batch_solve_async", "osqp_batch_wait", "osqp_batch_setup_recursive", "osqp_batch_update_recursive", "osqp_batch_partial_update_bounds",
+    "osqp_batch_get", "osqp_batch_get_iterates", "osqp_batch_get_scaling", "osqp_batch_get_polish_status", "osqp_batch_get_rho", "osqp_batch_linsys", "osqp_batch_solve_async", "osqp_batch_wait", "osqp_batch_setup_recursive", "osqp_batch_update_recursive", "osqp_batch_partial_update_bounds",
     "osqp_batch_time_iteration", "osqp_batch_last_loop", "osqp_batch_trace_iteration", "osqp_batch_cleanup",
     "rldl_batch_init_recursive", "rldl_batch_update_from_stage", "rldl_version",
     "rldl_symbolic_analyze", "rldl_stage_permutation", "rldl_plan_export", "rldl_setup_AP_matrices", "rldl_csc_free",
+    "osqp_horizon_setup", "osqp_horizon_update", "osqp_horizon_workspace", "osqp_horizon_N", "osqp_horizon_last_update",
+    "osqp_horizon_free",
 ]
 
 
@@ -181,6 +183,21 @@ def _declare(L):
     L.rldl_csc_free.argtypes = [PC]
     L.rldl_csc_free.restype = None
     L.rldl_device_available.restype = C.c_int
+    L.osqp_batch_get_rho.argtypes = [VP, C.POINTER(VP), C.POINTER(VP), C.POINTER(VP)]
+    L.osqp_batch_get_rho.restype = c_int
+    L.osqp_horizon_setup.argtypes = [C.POINTER(VP), c_int, C.POINTER(StageDims), c_int] + [PC] * 7 + [VP, VP, VP,
+                                     C.POINTER(OSQPBatchSettings), VP]
+    L.osqp_horizon_setup.restype = c_int
+    L.osqp_horizon_update.argtypes = [VP, c_int, VP, VP, VP]
+    L.osqp_horizon_update.restype = c_int
+    L.osqp_horizon_workspace.argtypes = [VP]
+    L.osqp_horizon_workspace.restype = VP
+    L.osqp_horizon_N.argtypes = [VP]
+    L.osqp_horizon_N.restype = c_int
+    L.osqp_horizon_last_update.argtypes = [VP, IP, IP, IP]
+    L.osqp_horizon_last_update.restype = c_int
+    L.osqp_horizon_free.argtypes = [VP]
+    L.osqp_horizon_free.restype = None
 
 
 _lib = None

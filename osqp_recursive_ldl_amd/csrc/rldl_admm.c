@@ -83,6 +83,8 @@ static void reset_info(osqp_batch *w) { /* auxil.c:628-645 */
   (void)hipMemsetAsync(w->W.rho_updates, 0, sizeof(int) * (size_t)w->batch, (hipStream_t)w->stream);
 }
 
+void osqp_batch_reset_info(osqp_batch *w) { reset_info(w); }
+
 void osqp_batch_cleanup(osqp_batch *w) {
   if (!w) return;
   (void)hipStreamSynchronize((hipStream_t)w->stream);
@@ -466,6 +468,16 @@ c_int osqp_batch_get_iterates(osqp_batch *w, c_float **d_x, c_float **d_y, c_flo
   if (d_z) *d_z = w->W.z;
   if (d_delta_x) *d_delta_x = w->W.delta_x;
   if (d_delta_y) *d_delta_y = w->W.delta_y;
+  return 0;
+}
+
+/* OSQPInfo.rho_updates / rho_estimate and the rho each instance currently runs with (settings->rho after osqp_update_rho,
+ * src/osqp.c:1268-1319, which adapt_rho calls per instance) */
+c_int osqp_batch_get_rho(osqp_batch *w, c_float **d_rho, c_float **d_rho_estimate, int **d_rho_updates) {
+  if (!w) return 1;
+  if (d_rho) *d_rho = w->W.rho_cur;
+  if (d_rho_estimate) *d_rho_estimate = w->W.rho_est;
+  if (d_rho_updates) *d_rho_updates = w->W.rho_updates;
   return 0;
 }
 

@@ -1287,9 +1287,11 @@ __global__ __launch_bounds__(1024) void k_plan_admm_loop(rldl_dev_sym S, rldl_de
 // kernels, the restart logic and export see no difference to k_factor.  first block b0 > 0: blocks < b0 keep
 // their L and D (LDL_update_from_pivot, :946-1110); L(b0,b0-1) and D_{b0-1} are read back from the factor.
 // ================================================================================================
-__global__ __launch_bounds__(WAVE) void k_stage_factor(rldl_dev_sym S, rldl_dev_num Nn, const int *__restrict__ mask, int b0) {
+__global__ __launch_bounds__(WAVE) void k_stage_factor(rldl_dev_sym S, rldl_dev_num Nn, const int *__restrict__ mask, int b0,
+                                                       const int *__restrict__ b0v) {
   const int inst = blockIdx.x, lane = threadIdx.x;
   if (mask && !mask[inst]) return;
+  if (b0v) b0 = b0v[inst];                                       // per-instance restart block (horizon change)
   const rldl_dev_stage &G = S.stage;
   const int ld = G.ld, nb = G.nb;
   extern __shared__ double sh[];
@@ -1388,9 +1390,11 @@ __device__ __forceinline__ double recip_nr(double d) {
 }
 
 template <int SM>
-__global__ __launch_bounds__(WAVE) void k_stage_factor_r(rldl_dev_sym S, rldl_dev_num Nn, const int *__restrict__ mask, int b0) {
+__global__ __launch_bounds__(WAVE) void k_stage_factor_r(rldl_dev_sym S, rldl_dev_num Nn, const int *__restrict__ mask, int b0,
+                                                         const int *__restrict__ b0v) {
   const int inst = blockIdx.x, lane = threadIdx.x;
   if (mask && !mask[inst]) return;
+  if (b0v) b0 = __builtin_amdgcn_readfirstlane(b0v[inst]);      // per-instance restart block (horizon change)
   const rldl_dev_stage &G = S.stage;
   const int ld = G.ld, nb = G.nb;
   extern __shared__ double sh[];
@@ -1922,6 +1926,60 @@ __global__ __launch_bounds__(256, 4) void k_arrow_admm(rldl_dev_sym S, rldl_dev_
   if (tr && lane == 0 && W.trace_iter < 0) tr[6] = wall_clock64();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Horizon change (osqp_update_recursive, src/recursive_ldl.c:1973-2016; update_AP_matrices :1675-1778;
+// LDL_update_from_pivot :946-1110).  Every horizon N <= Nmax has its own resident workspace; moving from one to another
+//   k_horizon_values : carries the per-instance P / A values of the stages before the pivot (unscaled on the way),
+//   k_horizon_state  : maps the unscaled iterates (x prefix; y of the kept row blocks; terminal rows -> terminal rows),
+//   k_horizon_adopt  : copies the factor columns of the blocks before the pivot from the old horizon's factor (both
+//                      patterns share that prefix of L) and names, per instance, the block the recursion restarts at.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WAVE) void k_horizon_values(rldl_dev_sym So, rldl_dev_admm Wo, const double *__restrict__ oPx,
+                                                         const double *__restrict__ oAx, int col_keep, double *__restrict__ nPx, int ldP,
+                                                         double *__restrict__ nAx, int ldA) {
+  const int inst = blockIdx.x, lane = threadIdx.x;
+  const double *P = oPx + (size_t)inst * So.nnzP, *A = oAx + (size_t)inst * So.nnzA;
+  double *Pn = nPx + (size_t)inst * ldP, *An = nAx + (size_t)inst * ldA;
+  const bool sc = Wo.scaling != 0;
+  const double *Dinv = sc ? Wo.sDinv + (size_t)inst * So.n : nullptr, *Einv = sc ? Wo.sEinv + (size_t)inst * So.m : nullptr;
+  const double cinv = sc ? Wo.scinv[inst] : 1.0;
+  for (int j = lane; j < col_keep; j += WAVE) {
+    for (int p = So.Pp[j]; p < So.Pp[j + 1]; p++) Pn[p] = sc ? ((P[p] * cinv) * Dinv[So.Pi[p]]) * Dinv[j] : P[p];   // k_unscale_data's order
+    for (int p = So.Ap[j]; p < So.Ap[j + 1]; p++) An[p] = sc ? (A[p] * Einv[So.Ai[p]]) * Dinv[j] : A[p];
+  }
+}
+
+__global__ __launch_bounds__(WAVE) void k_horizon_state(rldl_dev_sym So, rldl_dev_admm Wo, int n_new, int m_new, int n_keep, int m_keep,
+                                                        int nt, double *__restrict__ xs, double *__restrict__ ys) {
+  const int inst = blockIdx.x, lane = threadIdx.x, n = So.n, m = So.m;
+  const double *x = Wo.x + (size_t)inst * n, *y = Wo.y + (size_t)inst * m;
+  const bool sc = Wo.scaling != 0;
+  const double *D = sc ? Wo.sD + (size_t)inst * n : nullptr, *E = sc ? Wo.sE + (size_t)inst * m : nullptr;
+  const double cinv = sc ? Wo.scinv[inst] : 1.0;
+  for (int i = lane; i < n_new; i += WAVE) xs[(size_t)inst * n_new + i] = i < n_keep ? (sc ? D[i] * x[i] : x[i]) : 0.0;
+  for (int i = lane; i < m_new; i += WAVE) {
+    const int src = i < m_keep ? i : (i >= m_new - nt ? m - nt + (i - (m_new - nt)) : -1);
+    ys[(size_t)inst * m_new + i] = src < 0 ? 0.0 : (sc ? (E[src] * y[src]) * cinv : y[src]);    // store_solution's unscaling (auxil.c:527-565)
+  }
+}
+
+__global__ __launch_bounds__(WAVE) void k_horizon_adopt(rldl_dev_sym So, rldl_dev_num No, rldl_dev_sym Sn, rldl_dev_num Nn,
+                                                        const double *__restrict__ rvo, const double *__restrict__ rvn, int m_keep, int c0,
+                                                        int b_pivot, int *__restrict__ b0v, int *__restrict__ n_reused) {
+  const int inst = blockIdx.x, lane = threadIdx.x;
+  const double *ro = rvo + (size_t)inst * So.m, *rn = rvn + (size_t)inst * Sn.m;
+  int differ = No.status[inst] < 0 ? 1 : 0;                      // an old factor with a zero pivot is not adopted
+  for (int i = lane; i < m_keep; i += WAVE) differ |= ro[i] != rn[i] ? 1 : 0;
+  differ = wave_any(differ);
+  if (lane == 0) { b0v[inst] = differ ? 0 : b_pivot; if (!differ) atomicAdd(n_reused, 1); }
+  if (differ) return;
+  const double *Fo = No.F + (size_t)inst * So.ldF, *Do = No.D + (size_t)inst * So.N;
+  double *Fn = Nn.F + (size_t)inst * Sn.ldF, *Dn = Nn.D + (size_t)inst * Sn.N;
+  const int nl = So.Lp[c0];                                      // the two L patterns agree on columns < c0 (host check)
+  for (int p = lane; p < nl; p += WAVE) Fn[Sn.LtoS[p]] = Fo[So.LtoS[p]];
+  for (int j = lane; j < c0; j += WAVE) { Dn[j] = Do[j]; Fn[Sn.nS + j] = Fo[So.nS + j]; }
+}
+
 }  // namespace
 
 // ================================================================================================
@@ -2152,22 +2210,30 @@ static int launch_factor(const rldl_dev_sym *S, const rldl_dev_num *Nn, const in
   return launch_status();
 }
 
-extern "C" int rldl_launch_stage_factor(const rldl_dev_sym *S, const rldl_dev_num *Nn, const int *d_mask, int first_block, void *stream) {
+static int launch_stage_factor(const rldl_dev_sym *S, const rldl_dev_num *Nn, const int *d_mask, int first_block, const int *d_b0v,
+                               void *stream) {
   if (Nn->batch <= 0) return 0;
   const rldl_dev_stage *G = &S->stage;
   if (G->nb <= 0 || first_block < 0 || first_block >= G->nb) return -1;
   if (getenv("RLDL_STAGE_LDS") || G->smax > 32) {                // LDS-resident panel (reference version of the same recursion)
     const size_t lds = sizeof(double) * (size_t)(3 * G->smax * G->ld + 2 * G->ld);
-    hipLaunchKernelGGL(k_stage_factor, dim3(Nn->batch), dim3(WAVE), lds, (hipStream_t)stream, *S, *Nn, d_mask, first_block);
+    hipLaunchKernelGGL(k_stage_factor, dim3(Nn->batch), dim3(WAVE), lds, (hipStream_t)stream, *S, *Nn, d_mask, first_block, d_b0v);
     return launch_status();
   }
   const size_t lds = sizeof(double) * (size_t)(3 * G->smax * G->ld + 2 * G->ld + 128);
   const dim3 grid(Nn->batch), blk(WAVE);
-  if (G->smax <= 8) hipLaunchKernelGGL(k_stage_factor_r<8>, grid, blk, lds, (hipStream_t)stream, *S, *Nn, d_mask, first_block);
-  else if (G->smax <= 16) hipLaunchKernelGGL(k_stage_factor_r<16>, grid, blk, lds, (hipStream_t)stream, *S, *Nn, d_mask, first_block);
-  else if (G->smax <= 24) hipLaunchKernelGGL(k_stage_factor_r<24>, grid, blk, lds, (hipStream_t)stream, *S, *Nn, d_mask, first_block);
-  else hipLaunchKernelGGL(k_stage_factor_r<32>, grid, blk, lds, (hipStream_t)stream, *S, *Nn, d_mask, first_block);
+  if (G->smax <= 8) hipLaunchKernelGGL(k_stage_factor_r<8>, grid, blk, lds, (hipStream_t)stream, *S, *Nn, d_mask, first_block, d_b0v);
+  else if (G->smax <= 16) hipLaunchKernelGGL(k_stage_factor_r<16>, grid, blk, lds, (hipStream_t)stream, *S, *Nn, d_mask, first_block, d_b0v);
+  else if (G->smax <= 24) hipLaunchKernelGGL(k_stage_factor_r<24>, grid, blk, lds, (hipStream_t)stream, *S, *Nn, d_mask, first_block, d_b0v);
+  else hipLaunchKernelGGL(k_stage_factor_r<32>, grid, blk, lds, (hipStream_t)stream, *S, *Nn, d_mask, first_block, d_b0v);
   return launch_status();
+}
+extern "C" int rldl_launch_stage_factor(const rldl_dev_sym *S, const rldl_dev_num *Nn, const int *d_mask, int first_block, void *stream) {
+  return launch_stage_factor(S, Nn, d_mask, first_block, 0, stream);
+}
+// every instance restarts at its own block d_b0v[inst] (0 = full factorisation)
+extern "C" int rldl_launch_stage_factor_each(const rldl_dev_sym *S, const rldl_dev_num *Nn, const int *d_b0v, void *stream) {
+  return d_b0v ? launch_stage_factor(S, Nn, 0, 0, d_b0v, stream) : -1;
 }
 
 extern "C" int rldl_launch_factor(const rldl_dev_sym *S, const rldl_dev_num *Nn, const int *d_mask, void *stream) {
@@ -2316,3 +2382,27 @@ extern "C" int rldl_launch_matvec_A(const rldl_dev_sym *S, const rldl_dev_admm *
 }
 
 extern "C" const char *rldl_kernel_arch(void) { return "gfx950"; }
+
+extern "C" int rldl_launch_horizon_values(const rldl_dev_sym *So, const rldl_dev_admm *Wo, const double *oPx, const double *oAx,
+                                          int col_keep, double *nPx, int ldP, double *nAx, int ldA, void *stream) {
+  if (Wo->batch <= 0 || col_keep <= 0) return 0;
+  if (col_keep > So->n) return -1;
+  hipLaunchKernelGGL(k_horizon_values, dim3(Wo->batch), dim3(WAVE), 0, (hipStream_t)stream, *So, *Wo, oPx, oAx, col_keep, nPx, ldP, nAx, ldA);
+  return launch_status();
+}
+extern "C" int rldl_launch_horizon_state(const rldl_dev_sym *So, const rldl_dev_admm *Wo, int n_new, int m_new, int n_keep, int m_keep,
+                                         int nt, double *xs, double *ys, void *stream) {
+  if (Wo->batch <= 0) return 0;
+  if (n_keep > So->n || n_keep > n_new || m_keep + nt > So->m || m_keep + nt > m_new) return -1;
+  hipLaunchKernelGGL(k_horizon_state, dim3(Wo->batch), dim3(WAVE), 0, (hipStream_t)stream, *So, *Wo, n_new, m_new, n_keep, m_keep, nt, xs, ys);
+  return launch_status();
+}
+extern "C" int rldl_launch_horizon_adopt(const rldl_dev_sym *So, const rldl_dev_num *No, const rldl_dev_sym *Sn, const rldl_dev_num *Nn,
+                                         const double *rvo, const double *rvn, int m_keep, int c0, int b_pivot, int *d_b0v,
+                                         int *d_n_reused, void *stream) {
+  if (Nn->batch <= 0) return 0;
+  if (No->batch != Nn->batch || c0 <= 0 || c0 > So->N || c0 > Sn->N || m_keep > So->m || m_keep > Sn->m) return -1;
+  hipLaunchKernelGGL(k_horizon_adopt, dim3(Nn->batch), dim3(WAVE), 0, (hipStream_t)stream, *So, *No, *Sn, *Nn, rvo, rvn, m_keep, c0, b_pivot,
+                     d_b0v, d_n_reused);
+  return launch_status();
+}

@@ -139,6 +139,10 @@ class OSQPBatch:
         ps = C.c_void_p()
         _lib.lib().osqp_batch_get_polish_status(self.h, C.byref(ps))
         out["status_polish"] = self._view(ps.value, (B,), torch.int32)
+        rh = [C.c_void_p() for _ in range(3)]
+        _lib.lib().osqp_batch_get_rho(self.h, *[C.byref(t) for t in rh])
+        out.update(rho=self._view(rh[0].value, (B,), torch.float64), rho_estimate=self._view(rh[1].value, (B,), torch.float64),
+                   rho_updates=self._view(rh[2].value, (B,), torch.int32))
         if clone:
             out = {k: v.clone() for k, v in out.items()}
         return out
@@ -207,12 +211,107 @@ class OSQPBatch:
         return out
 
     def cleanup(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and getattr(self, "_owned", True):
             _lib.lib().osqp_batch_cleanup(self.h)
         self.h = C.c_void_p()
 
     def __del__(self):
         try:
             self.cleanup()
+        except Exception:
+            pass
+
+
+def _csc_to_scipy(M):
+    from scipy import sparse
+    n, m = M.n, M.m
+    p = np.array([M.p[i] for i in range(n + 1)]); nz = int(p[-1])
+    i = np.array([M.i[k] for k in range(nz)]); x = np.array([M.x[k] for k in range(nz)])
+    return sparse.csc_matrix((x, i, p), shape=(m, n))
+
+
+class OSQPHorizon:
+    """Variable-horizon MPC (osqp_setup_recursive with Nmax + osqp_update_recursive, src/recursive_ldl.c:2018-2230,
+    :1973-2016): the batch is set up at horizon dims[0] and moves anywhere in 1..Nmax with `update`.  `workspace` is the
+    OSQPBatch of the current horizon (owned by this object)."""
+
+    def __init__(self, dims, Nmax, Q0, Qi, QN, A0, Ai, Aij, AN, q, l, u, **settings):
+        from scipy import sparse
+        L = _lib.lib()
+        self._blocks = [CscPattern(sparse.triu(sparse.csc_matrix(b), format="csc")) for b in (Q0, Qi, QN)] + \
+                       [CscPattern(sparse.csc_matrix(b)) for b in (A0, Ai, Aij, AN)]
+        self.dims = tuple(int(v) for v in dims)
+        self.Nmax = int(Nmax)
+        self.batch = int(q.shape[0])
+        self.settings = default_settings(**settings)
+        self._device = q.device
+        self._views = {}
+        sd = _lib.StageDims(*self.dims)
+        self.h = C.c_void_p()
+        _lib.check(L.osqp_horizon_setup(C.byref(self.h), self.batch, C.byref(sd), self.Nmax, *[b.ref for b in self._blocks],
+                                        _dptr(q), _dptr(l), _dptr(u), C.byref(self.settings), None), "osqp_horizon_setup")
+
+    @property
+    def N(self):
+        return int(_lib.lib().osqp_horizon_N(self.h))
+
+    def sizes(self, N=None):
+        """(n, m) of horizon N (default: the current one)."""
+        N = self.N if N is None else int(N)
+        _, nx, nu, ny, nt = self.dims
+        return N * (nx + nu), N * (nx + ny) + nt
+
+    def patterns(self, N):
+        """Assembled P (upper triangular) and A of horizon N with the nominal values: the value order of update_P_A."""
+        L = _lib.lib()
+        sd = _lib.StageDims(int(N), *self.dims[1:])
+        Pp, Ap = C.POINTER(_lib.Csc)(), C.POINTER(_lib.Csc)()
+        _lib.check(L.rldl_setup_AP_matrices(C.byref(sd), *[b.ref for b in self._blocks], C.byref(Pp), C.byref(Ap),
+                                            None, None, None, None, None, None), "rldl_setup_AP_matrices")
+        P, A = _csc_to_scipy(Pp.contents), _csc_to_scipy(Ap.contents)
+        L.rldl_csc_free(Pp); L.rldl_csc_free(Ap)
+        return P, A
+
+    @property
+    def workspace(self):
+        N = self.N
+        if N not in self._views:
+            w = OSQPBatch.__new__(OSQPBatch)
+            w._owned = False
+            w._stream = None
+            w.h = C.c_void_p(_lib.lib().osqp_horizon_workspace(self.h))
+            P, A = self.patterns(N)
+            w.P, w.A = CscPattern(P), CscPattern(A)
+            w.n, w.m = w.P.shape[0], w.A.shape[0]
+            w.batch, w._device = self.batch, self._device
+            w.settings = default_settings()
+            C.memmove(C.byref(w.settings), C.byref(self.settings), C.sizeof(self.settings))
+            w.status = 0
+            self._views[N] = w
+        return self._views[N]
+
+    def update(self, N, q, l, u):
+        """osqp_update_recursive: move to horizon N with the new problem's q, l, u.  Returns the C return code
+        (-1: N outside 1..Nmax, as the reference)."""
+        n, m = self.sizes(N)
+        if 1 <= int(N) <= self.Nmax:
+            _dev_f64(q, (self.batch, n), "q"); _dev_f64(l, (self.batch, m), "l"); _dev_f64(u, (self.batch, m), "u")
+        return int(_lib.lib().osqp_horizon_update(self.h, int(N), _dptr(q), _dptr(l), _dptr(u)))
+
+    def last_update(self):
+        a, b, c = _lib.c_int(0), _lib.c_int(0), _lib.c_int(0)
+        _lib.lib().osqp_horizon_last_update(self.h, C.byref(a), C.byref(b), C.byref(c))
+        return dict(pivot_stage=int(a.value), instances_reused=int(b.value), workspace_created=bool(c.value))
+
+    def free(self):
+        if getattr(self, "h", None):
+            for w in self._views.values():
+                w.h = C.c_void_p()
+            _lib.lib().osqp_horizon_free(self.h)
+        self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
         except Exception:
             pass
