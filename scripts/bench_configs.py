@@ -8,6 +8,8 @@
                  refactor on a rho change, restart from stage k, tri-solve
   config5        update_matrices on the metric shape (full numeric refactor) and, on the MPC shape,
                  restart-from-first-modified-stage vs full refactor
+  horizon        horizon change 19 <-> 20 on the MPC shape (osqp_update_recursive): first visit, cached, with / without
+                 adopting the shared factor columns, against setting the problem up from scratch
 """
 import json
 import os
@@ -158,6 +160,48 @@ def mpc_shape():
     w.cleanup()
 
 
+def horizon_change():
+    import time
+    B, Nmax = 4096, 20
+    wl = {N: R.workloads.MPCStageQPs(N=N) for N in (19, 20)}
+    data = {}
+    for N in (19, 20):
+        _, _, q, l, u = wl[N].values(8)
+        data[N] = [t(np.tile(a, (B // 8, 1))) for a in (q, l, u)]
+    Px, Ax = wl[19].values(8)[:2]
+    kw = dict(rho=0.1, sigma=1e-6, alpha=1.6, max_iter=200, check_termination=0, adaptive_rho=0, warm_start=1, scaling=0)
+    blocks = lambda w: (w.Q0, w.Qi, w.QN, w.A0, w.Ai, w.Aij, w.AN)
+    t0 = time.perf_counter()
+    fresh = R.OSQPBatch.recursive(wl[20].dims, *blocks(wl[20]), *data[20], **kw)
+    torch.cuda.synchronize()
+    emit(name="horizon_setup_from_scratch_N20", batch=B, wall_ms=1e3 * (time.perf_counter() - t0))
+    fresh.cleanup()
+    hz = R.OSQPHorizon(wl[19].dims, Nmax, *blocks(wl[19]), *data[19], **kw)
+    hz.workspace.update_P_A(t(np.tile(Px, (B // 8, 1))), t(np.tile(Ax, (B // 8, 1))))
+    hz.workspace.solve(clone=False)
+
+    def change(N):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        rc = hz.update(N, *data[N])
+        torch.cuda.synchronize()
+        assert rc == 0
+        return 1e3 * (time.perf_counter() - t0)
+    first = change(20)
+    emit(name="horizon_change_first_visit", frm=19, to=20, batch=B, wall_ms=first, **hz.last_update())
+    for mode in ("adopt", "full"):
+        if mode == "full":
+            os.environ["RLDL_HORIZON_FULL"] = "1"
+        ts = {19: [], 20: []}
+        for _ in range(5):
+            ts[19].append(change(19)); info19 = hz.last_update()
+            ts[20].append(change(20)); info20 = hz.last_update()
+        emit(name="horizon_change_cached", mode=mode, batch=B, wall_ms_20_to_19=min(ts[19]), wall_ms_19_to_20=min(ts[20]),
+             reused_19=info19["instances_reused"], reused_20=info20["instances_reused"])
+    os.environ.pop("RLDL_HORIZON_FULL", None)
+    hz.free()
+
+
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     if which in ("all", "metric"):
@@ -166,3 +210,5 @@ if __name__ == "__main__":
         pattern_groups()
     if which in ("all", "mpc"):
         mpc_shape()
+    if which in ("all", "horizon"):
+        horizon_change()
