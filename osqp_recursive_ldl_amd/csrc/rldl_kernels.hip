@@ -1019,6 +1019,121 @@ __device__ __forceinline__ void plan_tri_solve(const rldl_dev_sym &S, const int 
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// stage_tri_solve -- the same L D L' solve for block-tridiagonal (MPC) patterns, by dense stage blocks (what
+// QDLDL_solve does on the factor of LDL_factorize_recursive, src/recursive_ldl.c:1139-1318): one tile at a time,
+// the entries of a coupling block C = L(b, b-1) / L(b+1, b) or of a diagonal block D = L_bb travel from the factor's
+// slots into an LDS tile (host-built table, rldl_recursive.c: build_solve_tiles), then every lane owns one row
+// (forward) or one column (backward) of the tile:
+//   forward   y_b = b_b - L(b, b-1) y_{b-1}     one fma per column of the coupling tile, y_{b-1}[c] as an LDS broadcast
+//             y_b <- L_bb^-1 y_b                 column sweep: pivot by v_readlane, one fma per column
+//   backward  x_b = D_b^-1 y_b - L(b+1, b)' x_{b+1},  x_b <- L_bb^-T x_b      the same with the tile read by columns
+// SM = compile-time bound on the block width: all inner loops run to SM without range checks or lane masks -- the
+// tile is zeroed before it is filled, so whatever lies outside the live block contributes exact zeros.
+// Two register sets hold the entries of the next C and the next D tile while the current ones are in use (a set is
+// refilled as soon as it has been written to LDS): two tiles of global loads are in flight per wave at any time.
+// F: factor row in global memory [nS slots | N Dinv], xs: [N] permuted rhs in / solution out (LDS), T: tile (LDS)
+// ------------------------------------------------------------------------------------------------
+#define SV_PF 6
+struct SvTile { double v[SV_PF]; unsigned p[SV_PF]; int e0, e1; };
+
+__device__ __forceinline__ void sv_prefetch(const rldl_dev_stage &G, const double *F, int e0, int e1, SvTile &P, int lane) {
+  P.e0 = e0; P.e1 = e1;
+#pragma unroll
+  for (int r = 0; r < SV_PF; r++)
+    if (e0 + r * WAVE < e1) {                                    // uniform
+      const int e = e0 + r * WAVE + lane;
+      P.p[r] = G.sv_pk[e < e1 ? e : e1 - 1];
+    }
+#pragma unroll
+  for (int r = 0; r < SV_PF; r++)
+    if (e0 + r * WAVE < e1) P.v[r] = F[P.p[r] & 0xffffu];
+}
+template <int SM>
+__device__ __forceinline__ void sv_commit(const rldl_dev_stage &G, const double *F, double *T, const SvTile &P, int lane) {
+  double2 *T2 = reinterpret_cast<double2 *>(T);
+#pragma unroll
+  for (int i = 0; i < (SM * (SM + 1) / 2 + WAVE - 1) / WAVE; i++)
+    if (i * WAVE + lane < (SM * (SM + 1) + 1) / 2) T2[i * WAVE + lane] = make_double2(0.0, 0.0);
+  wave_sync();
+#pragma unroll
+  for (int r = 0; r < SV_PF; r++)
+    if (P.e0 + r * WAVE < P.e1) T[P.p[r] >> 16] = P.v[r];        // (lanes past the end rewrite the last entry with its own value)
+  for (int e = P.e0 + SV_PF * WAVE + lane; e < P.e1; e += WAVE) { const unsigned w = G.sv_pk[e]; T[w >> 16] = F[w & 0xffffu]; }
+  wave_sync();
+}
+
+// per (direction, block): sv_prog[8 k ..] = { c0, s, o0 (first index of the block the coupling tile connects to), eC0, eC1, eD0, eD1, 0 }
+template <int SM>
+__device__ __forceinline__ void stage_tri_solve(const rldl_dev_sym &S, const double *F, double *xs, double *T, int lane) {
+  const rldl_dev_stage &G = S.stage;
+  const int nb = G.nb;
+  constexpr int ld = SM + 1;
+  const double *Dinv = F + S.nS;
+  SvTile PC, PD;
+  const int4 *prog = reinterpret_cast<const int4 *>(G.sv_prog);
+  int4 qa = prog[0], qb = prog[1];
+  sv_prefetch(G, F, qa.w, qb.x, PC, lane);
+  sv_prefetch(G, F, qb.y, qb.z, PD, lane);
+  // ================= forward: L y = b =================
+  for (int k = 0; k < nb; k++) {
+    const int c0 = qa.x, s = qa.y, o0 = qa.z;
+    const bool has_c = PC.e1 > PC.e0, has_d = PD.e1 > PD.e0;
+    qa = prog[2 * (k + 1)]; qb = prog[2 * (k + 1) + 1];          // next block (the table ends with the first backward block)
+    const int lr = lane < s ? lane : 0;
+    double acc = xs[c0 + lr];
+    const double *row = T + lr * ld;
+    if (has_c) {
+      sv_commit<SM>(G, F, T, PC, lane);
+      sv_prefetch(G, F, qa.w, qb.x, PC, lane);
+      const double *xp = xs + o0;
+#pragma unroll
+      for (int c = 0; c < SM; c++) acc = fma(-row[c], xp[c], acc);
+    } else sv_prefetch(G, F, qa.w, qb.x, PC, lane);
+    if (has_d) {
+      sv_commit<SM>(G, F, T, PD, lane);
+      sv_prefetch(G, F, qb.y, qb.z, PD, lane);
+#pragma unroll
+      for (int j = 0; j < SM - 1; j++) acc = fma(-row[j], readlane_f64(acc, j), acc);
+    } else sv_prefetch(G, F, qb.y, qb.z, PD, lane);
+    if ((has_c || has_d) && lane < s) xs[c0 + lane] = acc;
+    wave_sync();
+  }
+  // ================= D^-1 =================
+  for (int j0 = 0; j0 < S.N; j0 += 4 * WAVE) {
+    double d[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) { const int j = j0 + u * WAVE + lane; d[u] = j < S.N ? Dinv[j] : 0.0; }
+#pragma unroll
+    for (int u = 0; u < 4; u++) { const int j = j0 + u * WAVE + lane; if (j < S.N) xs[j] *= d[u]; }
+  }
+  wave_sync();
+  // ================= backward: L' x = y =================
+  for (int k = 0; k < nb; k++) {
+    const int c0 = qa.x, s = qa.y, o0 = qa.z;
+    const bool has_c = PC.e1 > PC.e0, has_d = PD.e1 > PD.e0;
+    qa = prog[2 * (nb + k + 1)]; qb = prog[2 * (nb + k + 1) + 1];  // (one all-zero entry closes the table)
+    const int lr = lane < s ? lane : 0;
+    double acc = xs[c0 + lr];
+    const double *col = T + lr;
+    if (has_c) {
+      sv_commit<SM>(G, F, T, PC, lane);
+      sv_prefetch(G, F, qa.w, qb.x, PC, lane);
+      const double *xn = xs + o0;
+#pragma unroll
+      for (int c = 0; c < SM; c++) acc = fma(-col[c * ld], xn[c], acc);
+    } else sv_prefetch(G, F, qa.w, qb.x, PC, lane);
+    if (has_d) {
+      sv_commit<SM>(G, F, T, PD, lane);
+      sv_prefetch(G, F, qb.y, qb.z, PD, lane);
+#pragma unroll
+      for (int j = SM - 1; j >= 1; j--) acc = fma(-col[j * ld], readlane_f64(acc, j), acc);
+    } else sv_prefetch(G, F, qb.y, qb.z, PD, lane);
+    if ((has_c || has_d) && lane < s) xs[c0 + lane] = acc;
+    wave_sync();
+  }
+}
+
 // cooperative staging: plan blob -> LDS by LDS-DMA, 16-byte pieces spread over the workgroup's waves
 // (the device copy of the blob is padded to a multiple of 4 words)
 __device__ __forceinline__ void stage_plan(const rldl_dev_sym &S, int *wl) {
@@ -1048,7 +1163,8 @@ __device__ __forceinline__ void wait_dma() { asm volatile("s_waitcnt vmcnt(0)" :
 // STAGE: the factor row is copied to LDS (small patterns); otherwise the sweeps and gathers read it straight from
 // global memory / L2 (their addresses do not depend on x, so the batched reads still pipeline) and only the
 // plan and x live in LDS -- the variant for patterns whose row would leave one wave per CU.
-template <bool STAGE>
+// BLK > 0: block-tridiagonal pattern solved by stage_tri_solve<BLK> (no plan blob; LDS per wave = x + one tile)
+template <bool STAGE, int BLK = 0>
 __global__ __launch_bounds__(1024) void k_plan_solve(rldl_dev_sym S, rldl_dev_num Nn, double *__restrict__ b_all, int per_wave) {
   extern __shared__ __attribute__((aligned(16))) double sh[];
   const int lane = threadIdx.x & (WAVE - 1), wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wpb = blockDim.x >> 6;
@@ -1059,7 +1175,7 @@ __global__ __launch_bounds__(1024) void k_plan_solve(rldl_dev_sym S, rldl_dev_nu
   const bool live = inst < Nn.batch;
   const double *Sv = STAGE ? Sl : Nn.F + (size_t)(live ? inst : 0) * S.ldF;
   double *b = b_all + (size_t)(live ? inst : 0) * S.N;
-  stage_plan(S, wl);
+  if (!BLK) stage_plan(S, wl);
   if (live) {
     if (STAGE) stage_factor_dma(S, Nn.F + (size_t)inst * S.ldF, Sl, lane);
     const int *permg = S.plan + S.po_perm;                     // global copy: lets the rhs gather start before the barrier
@@ -1074,8 +1190,9 @@ __global__ __launch_bounds__(1024) void k_plan_solve(rldl_dev_sym S, rldl_dev_nu
   wait_dma();
   __syncthreads();
   if (!live) return;
-  const int *perm = wl + S.po_perm;
-  plan_tri_solve(S, wl, Sv, xs, lane);
+  const int *perm = BLK ? S.plan + S.po_perm : wl + S.po_perm;
+  if constexpr (BLK > 0) stage_tri_solve<BLK>(S, Sv, xs, xs + ((S.N + 1) & ~1), lane);
+  else plan_tri_solve(S, wl, Sv, xs, lane);
   if (S.polish) {
     for (int j = lane; j < S.N; j += WAVE) b[perm[j]] = xs[j];  // permutet_x :544-547, raw solution :563-565
   } else {
@@ -1187,7 +1304,7 @@ __global__ __launch_bounds__(1024) void k_plan_admm(rldl_dev_sym S, rldl_dev_num
 
 // Large-N variant of the fused iteration: the per-position vectors do not fit in registers, so the right-hand side is
 // built and the x/z/y update applied in batches of four positions per lane (two extra memory latencies per batch).
-template <bool STAGE>
+template <bool STAGE, int BLK = 0>
 __global__ __launch_bounds__(1024) void k_plan_admm_loop(rldl_dev_sym S, rldl_dev_num Nn, rldl_dev_admm W, int per_wave) {
   extern __shared__ __attribute__((aligned(16))) double sh[];
   const int lane = threadIdx.x & (WAVE - 1), wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wpb = blockDim.x >> 6;
@@ -1196,7 +1313,7 @@ __global__ __launch_bounds__(1024) void k_plan_admm_loop(rldl_dev_sym S, rldl_de
   double *Sl = sh + (size_t)wv * per_wave;
   double *xs = STAGE ? Sl + S.ldF : Sl;
   const int st = inst < Nn.batch ? W.status[inst] : 0;
-  stage_plan(S, wl);
+  if (!BLK) stage_plan(S, wl);
   const bool live = inst < Nn.batch && st == ST_UNSOLVED;
   const int n = S.n, m = S.m;
   const size_t io = (size_t)(live ? inst : 0);
@@ -1231,10 +1348,11 @@ __global__ __launch_bounds__(1024) void k_plan_admm_loop(rldl_dev_sym S, rldl_de
   wait_dma();
   __syncthreads();
   if (!live) return;
-  plan_tri_solve(S, wl, Sv, xs, lane);
+  if constexpr (BLK > 0) stage_tri_solve<BLK>(S, Sv, xs, xs + ((S.N + 1) & ~1), lane);
+  else plan_tri_solve(S, wl, Sv, xs, lane);
   const double alpha = W.alpha;
   double *dx = W.delta_x + io * n, *dy = W.delta_y + io * m;
-  const int *perm = wl + S.po_perm;
+  const int *perm = BLK ? permg : wl + S.po_perm;
   for (int j0 = 0; j0 < S.N; j0 += 4 * WAVE) {
     int oo[4];
     double va[4], vb[4], vr[4], vl[4], vu[4], vrho[4];
@@ -2037,6 +2155,39 @@ static int plan_pick_wpb(const rldl_dev_sym *S) {   // feasibility only: the glo
 static bool plan_usable(const rldl_dev_sym *S) { return S->plan_ok && S->ngroups > 0 && plan_pick_wpb(S) > 0; }
 static bool plan_admm_usable(const rldl_dev_sym *S) { return plan_usable(S); }
 
+// ---- block tri-solve on stage patterns: LDS per wave = x (N, even) + one tile (SM rows of SM + 1) ----
+static int blk_per_wave_doubles(const rldl_dev_sym *S) { return ((S->N + 1) & ~1) + (S->stage.sv_ld - 1) * S->stage.sv_ld; }
+static int blk_pick_wpb(const rldl_dev_sym *S) {
+  const size_t pw = sizeof(double) * (size_t)blk_per_wave_doubles(S);
+  for (int wpb = 4; wpb >= 1; wpb >>= 1)
+    if (pw * wpb <= 64 * 1024) return wpb;
+  return 0;
+}
+static bool blk_usable(const rldl_dev_sym *S) {
+  return S->stage.nb > 0 && S->stage.sv_ok && !S->polish && blk_pick_wpb(S) > 0 && !getenv("RLDL_NO_STAGE_SOLVE") && !getenv("RLDL_NO_STAGE_FACTOR");
+}
+#define BLK_DISPATCH(KERNEL, ...)                                                                                              \
+  switch (S->stage.sv_ld - 1) {                                                                                                \
+    case 8: hipLaunchKernelGGL((KERNEL<false, 8>), dim3(grid), dim3(wpb * WAVE), lds, (hipStream_t)stream, __VA_ARGS__); break;   \
+    case 16: hipLaunchKernelGGL((KERNEL<false, 16>), dim3(grid), dim3(wpb * WAVE), lds, (hipStream_t)stream, __VA_ARGS__); break; \
+    case 22: hipLaunchKernelGGL((KERNEL<false, 22>), dim3(grid), dim3(wpb * WAVE), lds, (hipStream_t)stream, __VA_ARGS__); break; \
+    case 24: hipLaunchKernelGGL((KERNEL<false, 24>), dim3(grid), dim3(wpb * WAVE), lds, (hipStream_t)stream, __VA_ARGS__); break; \
+    case 32: hipLaunchKernelGGL((KERNEL<false, 32>), dim3(grid), dim3(wpb * WAVE), lds, (hipStream_t)stream, __VA_ARGS__); break; \
+    default: return -1;                                                                                                        \
+  }
+static int launch_blk_solve(const rldl_dev_sym *S, const rldl_dev_num *Nn, double *d_b, void *stream) {
+  const int wpb = blk_pick_wpb(S), pw = blk_per_wave_doubles(S), grid = (Nn->batch + wpb - 1) / wpb;
+  const size_t lds = sizeof(double) * (size_t)pw * wpb;
+  BLK_DISPATCH(k_plan_solve, *S, *Nn, d_b, pw)
+  return launch_status();
+}
+static int launch_blk_admm(const rldl_dev_sym *S, const rldl_dev_num *Nn, const rldl_dev_admm *W, void *stream) {
+  const int wpb = blk_pick_wpb(S), pw = blk_per_wave_doubles(S), grid = (Nn->batch + wpb - 1) / wpb;
+  const size_t lds = sizeof(double) * (size_t)pw * wpb;
+  BLK_DISPATCH(k_plan_admm_loop, *S, *Nn, *W, pw)
+  return launch_status();
+}
+
 static int launch_plan_solve(const rldl_dev_sym *S, const rldl_dev_num *Nn, double *d_b, void *stream) {
   const PlanGeom g = plan_geometry(S, (const void *)k_plan_solve<true>, (const void *)k_plan_solve<false>);
   if (g.wpb <= 0) return -1;
@@ -2249,6 +2400,7 @@ extern "C" int rldl_launch_factor_from(const rldl_dev_sym *S, const rldl_dev_num
 extern "C" int rldl_launch_solve(const rldl_dev_sym *S, const rldl_dev_num *Nn, double *d_b, void *stream) {
   if (Nn->batch <= 0) return 0;
   if (arrow_usable(S)) return launch_arrow_solve(S, Nn, d_b, stream);
+  if (blk_usable(S)) return launch_blk_solve(S, Nn, d_b, stream);
   if (plan_usable(S)) return launch_plan_solve(S, Nn, d_b, stream);
   const size_t lds = sizeof(double) * (size_t)(S->nS + S->N);
   if (lds <= RLDL_LDS_LIMIT)
@@ -2285,6 +2437,7 @@ extern "C" int rldl_launch_admm_iters(const rldl_dev_sym *S, const rldl_dev_num 
 extern "C" int rldl_launch_admm_iter(const rldl_dev_sym *S, const rldl_dev_num *Nn, const rldl_dev_admm *W, void *stream) {
   if (Nn->batch <= 0) return 0;
   if (arrow_usable(S) && S->N <= 8 * WAVE) return launch_arrow_admm(S, Nn, W, 1, stream);
+  if (blk_usable(S)) return launch_blk_admm(S, Nn, W, stream);
   if (plan_admm_usable(S)) return launch_plan_admm(S, Nn, W, stream);
   const size_t lds = sizeof(double) * (size_t)(S->nS + S->N);
   if (lds <= RLDL_LDS_LIMIT)

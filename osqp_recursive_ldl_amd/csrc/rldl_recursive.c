@@ -45,9 +45,52 @@ void rldl_stage_maps_free(rldl_batch *h) {
 #define FRI(p) if (p) (void)hipFree((void *)(p))
   FRI(G->bs); FRI(G->kd_ptr); FRI(G->kd_src); FRI(G->kd_pos); FRI(G->kc_ptr); FRI(G->kc_src); FRI(G->kc_pos);
   FRI(G->ld_ptr); FRI(G->ld_slot); FRI(G->ld_pos); FRI(G->lc_ptr); FRI(G->lc_slot); FRI(G->lc_pos);
+  FRI(G->sv_pk); FRI(G->sv_prog);
 #undef FRI
   memset(G, 0, sizeof(*G));
   free(h->rec); h->rec = 0;
+}
+
+/* Tables of the block tri-solve (k_plan_solve<.., true> and friends): per stage block the L entries of the diagonal block
+ * and of the coupling block below it as (tile position << 16 | factor slot), sorted by slot so that consecutive lanes read
+ * neighbouring factor entries, plus one table entry per (direction, block) naming the block and its two tiles:
+ * forward  C = L(b, b-1), D = L_bb for b = 0..nb-1, backward  C = L(b+1, b), D = L_bb for b = nb-1..0 (empty ranges allowed). */
+static int cmp_slot(const void *x, const void *y) {
+  const unsigned a = *(const unsigned *)x & 0xffffu, b = *(const unsigned *)y & 0xffffu;
+  return a < b ? -1 : (a > b ? 1 : 0);
+}
+static void build_solve_tiles(rldl_batch *h, const int *bs, int nb, int ld, const int *dptr, const int *dslot, const int *dpos, int dtot,
+                              const int *cptr, const int *cslot, const int *cpos, int ctot) {
+  static const int widths[] = {8, 16, 22, 24, 32};               /* instantiated block-width bounds SM of the solve kernels */
+  rldl_dev_stage *G = &h->dsym.stage;
+  unsigned *pk = 0;
+  int *prog = 0, b, e, k, lds = 0;
+  for (k = 0; k < 5 && !lds; k++) if (G->smax <= widths[k]) lds = widths[k] + 1;   /* tile rows SM + 1 wide (odd: conflict-free) */
+  if (!lds || h->sym->nS + h->sym->N >= 65536) return;
+  pk = (unsigned *)malloc(sizeof(unsigned) * (size_t)(dtot + ctot + 1));
+  prog = (int *)calloc((size_t)8 * (size_t)(2 * nb + 2), sizeof(int));
+  if (!pk || !prog) goto out;
+  for (e = 0; e < dtot; e++) pk[e] = ((unsigned)((dpos[e] / ld) * lds + dpos[e] % ld) << 16) | (unsigned)dslot[e];
+  for (e = 0; e < ctot; e++) pk[dtot + e] = ((unsigned)((cpos[e] / ld) * lds + cpos[e] % ld) << 16) | (unsigned)cslot[e];
+  for (b = 0; b < nb; b++) {
+    qsort(pk + dptr[b], (size_t)(dptr[b + 1] - dptr[b]), sizeof(unsigned), cmp_slot);
+    qsort(pk + dtot + cptr[b], (size_t)(cptr[b + 1] - cptr[b]), sizeof(unsigned), cmp_slot);
+  }
+  /* entry k: { c0, s, o0, eC0, eC1, eD0, eD1, 0 }; forward blocks 0..nb-1, backward blocks nb-1..0, one all-zero entry */
+  for (k = 0; k < 2 * nb; k++) {
+    int *q = prog + 8 * k;
+    const int fwd = k < nb;
+    b = fwd ? k : 2 * nb - 1 - k;
+    q[0] = bs[b]; q[1] = bs[b + 1] - bs[b];
+    if (fwd && b > 0) { q[2] = bs[b - 1]; q[3] = dtot + cptr[b - 1]; q[4] = dtot + cptr[b]; }
+    if (!fwd && b + 1 < nb) { q[2] = bs[b + 1]; q[3] = dtot + cptr[b]; q[4] = dtot + cptr[b + 1]; }
+    q[5] = dptr[b]; q[6] = dptr[b + 1];
+  }
+  G->sv_pk = (const unsigned *)upload_ints((const int *)pk, (size_t)(dtot + ctot));
+  G->sv_prog = upload_ints(prog, (size_t)8 * (size_t)(2 * nb + 2));
+  if (G->sv_pk && G->sv_prog) { G->sv_ok = 1; G->sv_ld = lds; G->sv_coff = dtot; G->sv_ntiles = 2 * nb; }
+out:
+  free(pk); free(prog);
 }
 
 /* 0: maps built and uploaded (h->dsym.stage.nb > 0); 1: the pattern does not qualify (generic kernels stay in use) */
@@ -136,6 +179,7 @@ static int build_stage_maps(rldl_batch *h) {
   h->dsym.stage = G;
   if (!G.bs || !G.kd_ptr || !G.kd_src || !G.kd_pos || !G.kc_ptr || !G.kc_src || !G.kc_pos || !G.ld_ptr || !G.ld_slot || !G.ld_pos ||
       !G.lc_ptr || !G.lc_slot || !G.lc_pos) { rldl_stage_maps_free(h); goto out; }
+  build_solve_tiles(h, bs, nb, ld, ptr[2], a[2], b[2], tot[2], ptr[3], a[3], b[3], tot[3]);   /* optional: sv_ok stays 0 on failure */
   h->rec = malloc(sizeof(int) * (size_t)(nb + 2));
   if (!h->rec) { rldl_stage_maps_free(h); goto out; }
   ((int *)h->rec)[0] = nb;

@@ -80,7 +80,8 @@ def test_setup_recursive_from_stage_blocks_equals_assembled_setup():
     nomP = np.tile(wr.P.x, (B, 1)); nomA = np.tile(wr.A.x, (B, 1))
     wa = R.OSQPBatch(wl.P_pattern, wl.A_pattern, dev(nomP), dev(nomA), dev(q), dev(l), dev(u), perm=perm, **kw)
     ra, rr = wa.solve(), wr.solve()
-    assert torch.equal(ra["x"], rr["x"]) and torch.equal(ra["y"], rr["y"])          # same kernels, same inputs
+    # (the recursive workspace solves by stage blocks, the assembled one with the grouped plan: same math, other order)
+    assert relerr(rr["x"].cpu().numpy(), ra["x"].cpu().numpy()) < 1e-9 and relerr(rr["y"].cpu().numpy(), ra["y"].cpu().numpy()) < 1e-9
     # per-instance values: only stages >= 4 differ from the nominal problem
     first = 4
     col0 = wl.nu + (first - 1) * (wl.nx + wl.nu)
@@ -103,3 +104,36 @@ def test_setup_recursive_from_stage_blocks_equals_assembled_setup():
     assert relerr(rr["x"].cpu().numpy(), ra["x"].cpu().numpy()) < 1e-9
     assert wr.partial_update_bounds(3, 3, dev(l2[:, :0]), dev(u2[:, :0])) == 1         # start >= stop (recursive_ldl.c:126)
     wa.cleanup(); wr.cleanup()
+
+
+@pytest.mark.parametrize("N", [1, 2, 7, 20])
+def test_block_tri_solve_and_fused_iteration_match_oracle(N):
+    """Stage-structured handles solve by dense stage blocks (stage_tri_solve: tiles of L_bb and L(b+1, b) staged through
+    LDS, row per lane): the plugin `solve` and the fused ADMM iteration built on it against the oracle's QDLDL_solve /
+    ADMM on the same permuted KKT matrix.  N = 1 has no interior stage, N = 20 is the BASELINE config 3 shape."""
+    import osqp_recursive_ldl_amd as R
+    wl = R.workloads.MPCStageQPs(N=N)
+    B = 5                                                        # not a multiple of the 4 waves per workgroup
+    Px, Ax, q, l, u = wl.values(B)
+    perm = R.workloads.stage_permutation(*wl.dims)
+    rho = np.where(l == u, 100.0, 0.1)
+    ls = R.BatchLinsys.recursive(wl.dims, wl.P_pattern, wl.A_pattern, dev(Px), dev(Ax), 1e-6, dev(rho))
+    assert ls.status == 0
+    rhs = np.random.default_rng(11).standard_normal((B, wl.n + wl.m))
+    sol = ls.solve(dev(rhs)).cpu().numpy()
+    for b in range(B):
+        P, qq, A, ll, uu = wl.instance(b)
+        o = ob.OracleLinsys(P, A, 1e-6, rho[b], perm=perm)
+        assert relerr(sol[b], o.solve(rhs[b])) < 1e-9
+    ls.free()
+    kw = dict(rho=0.1, sigma=1e-6, alpha=1.6, max_iter=40, check_termination=0, adaptive_rho=0, warm_start=0, scaling=0)
+    w = R.OSQPBatch.recursive(wl.dims, wl.Q0, wl.Qi, wl.QN, wl.A0, wl.Ai, wl.Aij, wl.AN, dev(q), dev(l), dev(u), **kw)
+    assert w.update_P_A(dev(Px), dev(Ax)) == 0
+    r = w.solve()
+    for b in range(B):
+        P, qq, A, ll, uu = wl.instance(b)
+        ro = ob.OracleOSQP(P, qq, A, ll, uu, perm=perm, **kw).solve()
+        assert relerr(r["x"][b].cpu().numpy(), ro["x_iter"]) < 1e-8
+        assert relerr(r["y"][b].cpu().numpy(), ro["y_iter"]) < 1e-8
+        assert relerr(r["z"][b].cpu().numpy(), ro["z_iter"]) < 1e-8
+    w.cleanup()
