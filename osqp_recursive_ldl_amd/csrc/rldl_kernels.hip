@@ -1034,103 +1034,102 @@ __device__ __forceinline__ void plan_tri_solve(const rldl_dev_sym &S, const int 
 // refilled as soon as it has been written to LDS): two tiles of global loads are in flight per wave at any time.
 // F: factor row in global memory [nS slots | N Dinv], xs: [N] permuted rhs in / solution out (LDS), T: tile (LDS)
 // ------------------------------------------------------------------------------------------------
-#define SV_PF 6
-struct SvTile { double v[SV_PF]; unsigned p[SV_PF]; int e0, e1; };
+#define SV_PF 6                        // rounds of 64 entries per tile (host pads every tile's table to SV_PF * 64 words)
+#define SV_TW (SV_PF * WAVE)
+typedef const __attribute__((address_space(4))) int *sv_cptr_t;   // constant address space: uniform reads become s_load
 
-__device__ __forceinline__ void sv_prefetch(const rldl_dev_stage &G, const double *F, int e0, int e1, SvTile &P, int lane) {
-  P.e0 = e0; P.e1 = e1;
+struct SvTile { double v[SV_PF]; unsigned p[SV_PF]; };
+
+// table words: (byte offset inside the tile << 16) | factor slot; padding words point at the row's spare zero slot and
+// at the pad column of tile row 0, so no lane needs a predicate anywhere
+__device__ __forceinline__ void sv_load_map(const unsigned *__restrict__ pk, int tile, unsigned (&m)[SV_PF], int lane) {
 #pragma unroll
-  for (int r = 0; r < SV_PF; r++)
-    if (e0 + r * WAVE < e1) {                                    // uniform
-      const int e = e0 + r * WAVE + lane;
-      P.p[r] = G.sv_pk[e < e1 ? e : e1 - 1];
-    }
+  for (int r = 0; r < SV_PF; r++) m[r] = pk[(unsigned)(tile * SV_TW + r * WAVE + lane)];
+}
+__device__ __forceinline__ void sv_load_val(const double *F, const unsigned (&m)[SV_PF], SvTile &P) {
 #pragma unroll
-  for (int r = 0; r < SV_PF; r++)
-    if (e0 + r * WAVE < e1) P.v[r] = F[P.p[r] & 0xffffu];
+  for (int r = 0; r < SV_PF; r++) { P.p[r] = m[r]; P.v[r] = F[m[r] & 0xffffu]; }
 }
 template <int SM>
-__device__ __forceinline__ void sv_commit(const rldl_dev_stage &G, const double *F, double *T, const SvTile &P, int lane) {
+__device__ __forceinline__ void sv_commit(double *T, const SvTile &P, int lane) {
   double2 *T2 = reinterpret_cast<double2 *>(T);
 #pragma unroll
   for (int i = 0; i < (SM * (SM + 1) / 2 + WAVE - 1) / WAVE; i++)
-    if (i * WAVE + lane < (SM * (SM + 1) + 1) / 2) T2[i * WAVE + lane] = make_double2(0.0, 0.0);
+    if (i * WAVE + lane < SM * (SM + 1) / 2) T2[i * WAVE + lane] = make_double2(0.0, 0.0);
   wave_sync();
+  char *Tb = reinterpret_cast<char *>(T);
 #pragma unroll
-  for (int r = 0; r < SV_PF; r++)
-    if (P.e0 + r * WAVE < P.e1) T[P.p[r] >> 16] = P.v[r];        // (lanes past the end rewrite the last entry with its own value)
-  for (int e = P.e0 + SV_PF * WAVE + lane; e < P.e1; e += WAVE) { const unsigned w = G.sv_pk[e]; T[w >> 16] = F[w & 0xffffu]; }
+  for (int r = 0; r < SV_PF; r++) *reinterpret_cast<double *>(Tb + (P.p[r] >> 16)) = P.v[r];
   wave_sync();
 }
 
-// per (direction, block): sv_prog[8 k ..] = { c0, s, o0 (first index of the block the coupling tile connects to), eC0, eC1, eD0, eD1, 0 }
+// per (direction, block): sv_prog[8 k ..] = { c0, s, o0 (first index of the block the coupling tile connects to), tile id of
+// the coupling tile or -1, tile id of the diagonal tile or -1, 0, 0, 0 }; forward blocks, backward blocks, 3 closing entries of -1 tiles
 template <int SM>
 __device__ __forceinline__ void stage_tri_solve(const rldl_dev_sym &S, const double *F, double *xs, double *T, int lane) {
   const rldl_dev_stage &G = S.stage;
   const int nb = G.nb;
   constexpr int ld = SM + 1;
   const double *Dinv = F + S.nS;
-  SvTile PC, PD;
-  const int4 *prog = reinterpret_cast<const int4 *>(G.sv_prog);
-  int4 qa = prog[0], qb = prog[1];
-  sv_prefetch(G, F, qa.w, qb.x, PC, lane);
-  sv_prefetch(G, F, qb.y, qb.z, PD, lane);
-  // ================= forward: L y = b =================
-  for (int k = 0; k < nb; k++) {
-    const int c0 = qa.x, s = qa.y, o0 = qa.z;
-    const bool has_c = PC.e1 > PC.e0, has_d = PD.e1 > PD.e0;
-    qa = prog[2 * (k + 1)]; qb = prog[2 * (k + 1) + 1];          // next block (the table ends with the first backward block)
+  const unsigned *pk = G.sv_pk;
+  sv_cptr_t prog = (sv_cptr_t)(unsigned long long)G.sv_prog;
+  SvTile PC, PD;                                               // entries of the current block's tiles (values + table words)
+  unsigned mC[SV_PF], mD[SV_PF];                               // table words of the next block's tiles
+  // pipeline: table words two blocks ahead of their use, factor values one block ahead
+  int c0 = prog[0], s = prog[1], o0 = prog[2], tc = prog[3], td = prog[4];
+  int n_c0 = prog[8], n_s = prog[9], n_o0 = prog[10], n_tc = prog[11], n_td = prog[12];
+  if (tc >= 0) { sv_load_map(pk, tc, mC, lane); sv_load_val(F, mC, PC); }
+  if (td >= 0) { sv_load_map(pk, td, mD, lane); sv_load_val(F, mD, PD); }
+  if (n_tc >= 0) sv_load_map(pk, n_tc, mC, lane);
+  if (n_td >= 0) sv_load_map(pk, n_td, mD, lane);
+  for (int k = 0; k < 2 * nb; k++) {
+    if (k == nb) {                                               // ================= D^-1 between the passes =================
+      for (int j0 = 0; j0 < S.N; j0 += 4 * WAVE) {
+        double d[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int j = j0 + u * WAVE + lane; d[u] = j < S.N ? Dinv[j] : 0.0; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int j = j0 + u * WAVE + lane; if (j < S.N) xs[j] *= d[u]; }
+      }
+      wave_sync();
+    }
+    const bool fwd = k < nb;
+    const int nn_tc = prog[8 * (k + 2) + 3], nn_td = prog[8 * (k + 2) + 4];
     const int lr = lane < s ? lane : 0;
     double acc = xs[c0 + lr];
-    const double *row = T + lr * ld;
-    if (has_c) {
-      sv_commit<SM>(G, F, T, PC, lane);
-      sv_prefetch(G, F, qa.w, qb.x, PC, lane);
-      const double *xp = xs + o0;
+    if (tc >= 0) sv_commit<SM>(T, PC, lane);
+    if (n_tc >= 0) sv_load_val(F, mC, PC);                       // values of the next block's coupling tile ...
+    if (nn_tc >= 0) sv_load_map(pk, nn_tc, mC, lane);            // ... and the table words of the one after
+    if (tc >= 0) {
+      const double *xo = xs + o0;
+      if (fwd) {                                                 // y_b -= L(b, b-1) y_{b-1}: own row of the tile
+        const double *row = T + lr * ld;
 #pragma unroll
-      for (int c = 0; c < SM; c++) acc = fma(-row[c], xp[c], acc);
-    } else sv_prefetch(G, F, qa.w, qb.x, PC, lane);
-    if (has_d) {
-      sv_commit<SM>(G, F, T, PD, lane);
-      sv_prefetch(G, F, qb.y, qb.z, PD, lane);
+        for (int c = 0; c < SM; c++) acc = fma(-row[c], xo[c], acc);
+      } else {                                                   // x_b -= L(b+1, b)' x_{b+1}: own column
+        const double *col = T + lr;
 #pragma unroll
-      for (int j = 0; j < SM - 1; j++) acc = fma(-row[j], readlane_f64(acc, j), acc);
-    } else sv_prefetch(G, F, qb.y, qb.z, PD, lane);
-    if ((has_c || has_d) && lane < s) xs[c0 + lane] = acc;
+        for (int c = 0; c < SM; c++) acc = fma(-col[c * ld], xo[c], acc);
+      }
+    }
+    if (td >= 0) sv_commit<SM>(T, PD, lane);
+    if (n_td >= 0) sv_load_val(F, mD, PD);
+    if (nn_td >= 0) sv_load_map(pk, nn_td, mD, lane);
+    if (td >= 0) {
+      if (fwd) {
+        const double *row = T + lr * ld;
+#pragma unroll
+        for (int j = 0; j < SM - 1; j++) acc = fma(-row[j], readlane_f64(acc, j), acc);
+      } else {
+        const double *col = T + lr;
+#pragma unroll
+        for (int j = SM - 1; j >= 1; j--) acc = fma(-col[j * ld], readlane_f64(acc, j), acc);
+      }
+    }
+    if ((tc >= 0 || td >= 0) && lane < s) xs[c0 + lane] = acc;
     wave_sync();
-  }
-  // ================= D^-1 =================
-  for (int j0 = 0; j0 < S.N; j0 += 4 * WAVE) {
-    double d[4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) { const int j = j0 + u * WAVE + lane; d[u] = j < S.N ? Dinv[j] : 0.0; }
-#pragma unroll
-    for (int u = 0; u < 4; u++) { const int j = j0 + u * WAVE + lane; if (j < S.N) xs[j] *= d[u]; }
-  }
-  wave_sync();
-  // ================= backward: L' x = y =================
-  for (int k = 0; k < nb; k++) {
-    const int c0 = qa.x, s = qa.y, o0 = qa.z;
-    const bool has_c = PC.e1 > PC.e0, has_d = PD.e1 > PD.e0;
-    qa = prog[2 * (nb + k + 1)]; qb = prog[2 * (nb + k + 1) + 1];  // (one all-zero entry closes the table)
-    const int lr = lane < s ? lane : 0;
-    double acc = xs[c0 + lr];
-    const double *col = T + lr;
-    if (has_c) {
-      sv_commit<SM>(G, F, T, PC, lane);
-      sv_prefetch(G, F, qa.w, qb.x, PC, lane);
-      const double *xn = xs + o0;
-#pragma unroll
-      for (int c = 0; c < SM; c++) acc = fma(-col[c * ld], xn[c], acc);
-    } else sv_prefetch(G, F, qa.w, qb.x, PC, lane);
-    if (has_d) {
-      sv_commit<SM>(G, F, T, PD, lane);
-      sv_prefetch(G, F, qb.y, qb.z, PD, lane);
-#pragma unroll
-      for (int j = SM - 1; j >= 1; j--) acc = fma(-col[j * ld], readlane_f64(acc, j), acc);
-    } else sv_prefetch(G, F, qb.y, qb.z, PD, lane);
-    if ((has_c || has_d) && lane < s) xs[c0 + lane] = acc;
-    wave_sync();
+    c0 = n_c0; s = n_s; o0 = n_o0; tc = n_tc; td = n_td;
+    n_c0 = prog[8 * (k + 2)]; n_s = prog[8 * (k + 2) + 1]; n_o0 = prog[8 * (k + 2) + 2]; n_tc = nn_tc; n_td = nn_td;
   }
 }
 

@@ -59,36 +59,48 @@ static int cmp_slot(const void *x, const void *y) {
   const unsigned a = *(const unsigned *)x & 0xffffu, b = *(const unsigned *)y & 0xffffu;
   return a < b ? -1 : (a > b ? 1 : 0);
 }
+#define SV_TILE_WORDS 384                                         /* SV_PF * 64 in rldl_kernels.hip */
 static void build_solve_tiles(rldl_batch *h, const int *bs, int nb, int ld, const int *dptr, const int *dslot, const int *dpos, int dtot,
                               const int *cptr, const int *cslot, const int *cpos, int ctot) {
   static const int widths[] = {8, 16, 22, 24, 32};               /* instantiated block-width bounds SM of the solve kernels */
   rldl_dev_stage *G = &h->dsym.stage;
-  unsigned *pk = 0;
-  int *prog = 0, b, e, k, lds = 0;
-  for (k = 0; k < 5 && !lds; k++) if (G->smax <= widths[k]) lds = widths[k] + 1;   /* tile rows SM + 1 wide (odd: conflict-free) */
-  if (!lds || h->sym->nS + h->sym->N >= 65536) return;
-  pk = (unsigned *)malloc(sizeof(unsigned) * (size_t)(dtot + ctot + 1));
-  prog = (int *)calloc((size_t)8 * (size_t)(2 * nb + 2), sizeof(int));
+  unsigned *pk = 0, pad;
+  int *prog = 0, b, e, k, lds = 0, sm = 0;
+  const int zs = h->dsym.ldF - 1;                                /* spare slot of the factor row, always 0.0 */
+  (void)dtot; (void)ctot;
+  for (k = 0; k < 5 && !lds; k++) if (G->smax <= widths[k]) { sm = widths[k]; lds = sm + 1; }   /* tile rows SM + 1 wide (odd) */
+  if (!lds || zs >= 65536) return;
+  for (b = 0; b < nb; b++)
+    if (dptr[b + 1] - dptr[b] > SV_TILE_WORDS || cptr[b + 1] - cptr[b] > SV_TILE_WORDS) return;
+  pk = (unsigned *)malloc(sizeof(unsigned) * (size_t)SV_TILE_WORDS * (size_t)(2 * nb));
+  prog = (int *)calloc((size_t)8 * (size_t)(2 * nb + 4), sizeof(int));
   if (!pk || !prog) goto out;
-  for (e = 0; e < dtot; e++) pk[e] = ((unsigned)((dpos[e] / ld) * lds + dpos[e] % ld) << 16) | (unsigned)dslot[e];
-  for (e = 0; e < ctot; e++) pk[dtot + e] = ((unsigned)((cpos[e] / ld) * lds + cpos[e] % ld) << 16) | (unsigned)cslot[e];
-  for (b = 0; b < nb; b++) {
-    qsort(pk + dptr[b], (size_t)(dptr[b + 1] - dptr[b]), sizeof(unsigned), cmp_slot);
-    qsort(pk + dtot + cptr[b], (size_t)(cptr[b + 1] - cptr[b]), sizeof(unsigned), cmp_slot);
+  pad = ((unsigned)(sm * 8) << 16) | (unsigned)zs;               /* pad column of tile row 0 <- 0.0 */
+  for (b = 0; b < nb; b++) {                                       /* tile 2b = L(b+1, b), tile 2b + 1 = L_bb */
+    unsigned *tcw = pk + (size_t)SV_TILE_WORDS * (size_t)(2 * b), *tdw = tcw + SV_TILE_WORDS;
+    int nc = cptr[b + 1] - cptr[b], nd = dptr[b + 1] - dptr[b];
+    for (e = 0; e < nc; e++) tcw[e] = ((unsigned)(((cpos[cptr[b] + e] / ld) * lds + cpos[cptr[b] + e] % ld) * 8) << 16) | (unsigned)cslot[cptr[b] + e];
+    for (e = 0; e < nd; e++) tdw[e] = ((unsigned)(((dpos[dptr[b] + e] / ld) * lds + dpos[dptr[b] + e] % ld) * 8) << 16) | (unsigned)dslot[dptr[b] + e];
+    qsort(tcw, (size_t)nc, sizeof(unsigned), cmp_slot);
+    qsort(tdw, (size_t)nd, sizeof(unsigned), cmp_slot);
+    for (e = nc; e < SV_TILE_WORDS; e++) tcw[e] = pad;
+    for (e = nd; e < SV_TILE_WORDS; e++) tdw[e] = pad;
   }
-  /* entry k: { c0, s, o0, eC0, eC1, eD0, eD1, 0 }; forward blocks 0..nb-1, backward blocks nb-1..0, one all-zero entry */
-  for (k = 0; k < 2 * nb; k++) {
+  /* entry k: { c0, s, o0, coupling tile or -1, diagonal tile or -1 }; forward blocks 0..nb-1, backward blocks nb-1..0 */
+  for (k = 0; k < 2 * nb + 4; k++) {
     int *q = prog + 8 * k;
     const int fwd = k < nb;
+    q[3] = q[4] = -1;
+    if (k >= 2 * nb) continue;
     b = fwd ? k : 2 * nb - 1 - k;
     q[0] = bs[b]; q[1] = bs[b + 1] - bs[b];
-    if (fwd && b > 0) { q[2] = bs[b - 1]; q[3] = dtot + cptr[b - 1]; q[4] = dtot + cptr[b]; }
-    if (!fwd && b + 1 < nb) { q[2] = bs[b + 1]; q[3] = dtot + cptr[b]; q[4] = dtot + cptr[b + 1]; }
-    q[5] = dptr[b]; q[6] = dptr[b + 1];
+    if (fwd && b > 0) { q[2] = bs[b - 1]; if (cptr[b - 1] < cptr[b]) q[3] = 2 * (b - 1); }
+    if (!fwd && b + 1 < nb) { q[2] = bs[b + 1]; if (cptr[b] < cptr[b + 1]) q[3] = 2 * b; }
+    if (dptr[b] < dptr[b + 1]) q[4] = 2 * b + 1;
   }
-  G->sv_pk = (const unsigned *)upload_ints((const int *)pk, (size_t)(dtot + ctot));
-  G->sv_prog = upload_ints(prog, (size_t)8 * (size_t)(2 * nb + 2));
-  if (G->sv_pk && G->sv_prog) { G->sv_ok = 1; G->sv_ld = lds; G->sv_coff = dtot; G->sv_ntiles = 2 * nb; }
+  G->sv_pk = (const unsigned *)upload_ints((const int *)pk, (size_t)SV_TILE_WORDS * (size_t)(2 * nb));
+  G->sv_prog = upload_ints(prog, (size_t)8 * (size_t)(2 * nb + 4));
+  if (G->sv_pk && G->sv_prog) { G->sv_ok = 1; G->sv_ld = lds; G->sv_coff = 0; G->sv_ntiles = 2 * nb; }
 out:
   free(pk); free(prog);
 }
