@@ -22,9 +22,9 @@ typedef struct {
   const int *kc_ptr, *kc_src, *kc_pos;    /* KKT values of the coupling block (b+1, b) */
   const int *ld_ptr, *ld_slot, *ld_pos;   /* L entries inside block b: factor slot <- tile position */
   const int *lc_ptr, *lc_slot, *lc_pos;   /* L entries of L(b+1, b) */
-  /* block tri-solve (stage_tri_solve): the same L entries as (tile position << 16 | factor slot), tile rows sv_ld = SM + 1 wide,
-   * diagonal-block entries first (indexed like ld_*), coupling entries after them (lc_* + sv_coff), each block sorted by
-   * slot; sv_prog[8 k] = { c0, s, o0, eC0, eC1, eD0, eD1, 0 } per (direction, block), see rldl_recursive.c */
+  /* block tri-solve (stage_tri_solve): per tile (2b = L(b+1, b), 2b + 1 = L_bb) 384 words (tile byte offset << 16 | factor slot),
+   * tile rows sv_ld = SM + 1 wide, padded, lane-major; sv_coff = rounds per coupling tile | rounds per diagonal tile << 8;
+   * sv_prog[8 k] = { c0, s, o0, coupling tile, diagonal tile, 0, 0, 0 } per (direction, block), see rldl_recursive.c */
   const unsigned *sv_pk;
   const int *sv_prog;
   int sv_ok, sv_ld, sv_coff, sv_ntiles;

@@ -1042,16 +1042,22 @@ struct SvTile { double v[SV_PF]; unsigned p[SV_PF]; };
 
 // table words: (byte offset inside the tile << 16) | factor slot; padding words point at the row's spare zero slot and
 // at the pad column of tile row 0, so no lane needs a predicate anywhere
+// (words of a tile are stored lane-major: lane t owns words [SV_PF t, SV_PF t + SV_PF) = its entries of rounds 0..SV_PF-1, so
+//  the table comes in with two wide loads per lane; nr = rounds this kind of tile needs on this pattern, uniform)
 __device__ __forceinline__ void sv_load_map(const unsigned *__restrict__ pk, int tile, unsigned (&m)[SV_PF], int lane) {
+  const uint2 *q = reinterpret_cast<const uint2 *>(pk + (unsigned)(tile * SV_TW + lane * SV_PF));
 #pragma unroll
-  for (int r = 0; r < SV_PF; r++) m[r] = pk[(unsigned)(tile * SV_TW + r * WAVE + lane)];
+  for (int r = 0; r < SV_PF / 2; r++) { const uint2 w = q[r]; m[2 * r] = w.x; m[2 * r + 1] = w.y; }
 }
-__device__ __forceinline__ void sv_load_val(const double *F, const unsigned (&m)[SV_PF], SvTile &P) {
+__device__ __forceinline__ void sv_load_val(const double *F, const unsigned (&m)[SV_PF], SvTile &P, int nr) {
 #pragma unroll
-  for (int r = 0; r < SV_PF; r++) { P.p[r] = m[r]; P.v[r] = F[m[r] & 0xffffu]; }
+  for (int r = 0; r < SV_PF; r++) {
+    P.p[r] = m[r];
+    if (r < nr) P.v[r] = F[m[r] & 0xffffu];
+  }
 }
 template <int SM>
-__device__ __forceinline__ void sv_commit(double *T, const SvTile &P, int lane) {
+__device__ __forceinline__ void sv_commit(double *T, const SvTile &P, int lane, int nr) {
   double2 *T2 = reinterpret_cast<double2 *>(T);
 #pragma unroll
   for (int i = 0; i < (SM * (SM + 1) / 2 + WAVE - 1) / WAVE; i++)
@@ -1059,7 +1065,8 @@ __device__ __forceinline__ void sv_commit(double *T, const SvTile &P, int lane) 
   wave_sync();
   char *Tb = reinterpret_cast<char *>(T);
 #pragma unroll
-  for (int r = 0; r < SV_PF; r++) *reinterpret_cast<double *>(Tb + (P.p[r] >> 16)) = P.v[r];
+  for (int r = 0; r < SV_PF; r++)
+    if (r < nr) *reinterpret_cast<double *>(Tb + (P.p[r] >> 16)) = P.v[r];
   wave_sync();
 }
 
@@ -1078,8 +1085,9 @@ __device__ __forceinline__ void stage_tri_solve(const rldl_dev_sym &S, const dou
   // pipeline: table words two blocks ahead of their use, factor values one block ahead
   int c0 = prog[0], s = prog[1], o0 = prog[2], tc = prog[3], td = prog[4];
   int n_c0 = prog[8], n_s = prog[9], n_o0 = prog[10], n_tc = prog[11], n_td = prog[12];
-  if (tc >= 0) { sv_load_map(pk, tc, mC, lane); sv_load_val(F, mC, PC); }
-  if (td >= 0) { sv_load_map(pk, td, mD, lane); sv_load_val(F, mD, PD); }
+  const int nrc = G.sv_coff & 0xff, nrd = G.sv_coff >> 8;        // rounds per coupling / diagonal tile
+  if (tc >= 0) { sv_load_map(pk, tc, mC, lane); sv_load_val(F, mC, PC, nrc); }
+  if (td >= 0) { sv_load_map(pk, td, mD, lane); sv_load_val(F, mD, PD, nrd); }
   if (n_tc >= 0) sv_load_map(pk, n_tc, mC, lane);
   if (n_td >= 0) sv_load_map(pk, n_td, mD, lane);
   for (int k = 0; k < 2 * nb; k++) {
@@ -1097,23 +1105,25 @@ __device__ __forceinline__ void stage_tri_solve(const rldl_dev_sym &S, const dou
     const int nn_tc = prog[8 * (k + 2) + 3], nn_td = prog[8 * (k + 2) + 4];
     const int lr = lane < s ? lane : 0;
     double acc = xs[c0 + lr];
-    if (tc >= 0) sv_commit<SM>(T, PC, lane);
-    if (n_tc >= 0) sv_load_val(F, mC, PC);                       // values of the next block's coupling tile ...
+    if (tc >= 0) sv_commit<SM>(T, PC, lane, nrc);
+    if (n_tc >= 0) sv_load_val(F, mC, PC, nrc);                       // values of the next block's coupling tile ...
     if (nn_tc >= 0) sv_load_map(pk, nn_tc, mC, lane);            // ... and the table words of the one after
     if (tc >= 0) {
-      const double *xo = xs + o0;
+      // the neighbour block's vector sits in one register (lane c = entry c) and is broadcast by v_readlane: the LDS
+      // pipe, shared by all waves of the CU, is what bounds this kernel, the VALU has room
+      const double xo = xs[o0 + (lane < SM ? lane : SM - 1)];     // (lanes past the block read finite junk that meets zero tile entries)
       if (fwd) {                                                 // y_b -= L(b, b-1) y_{b-1}: own row of the tile
         const double *row = T + lr * ld;
 #pragma unroll
-        for (int c = 0; c < SM; c++) acc = fma(-row[c], xo[c], acc);
+        for (int c = 0; c < SM; c++) acc = fma(-row[c], readlane_f64(xo, c), acc);
       } else {                                                   // x_b -= L(b+1, b)' x_{b+1}: own column
         const double *col = T + lr;
 #pragma unroll
-        for (int c = 0; c < SM; c++) acc = fma(-col[c * ld], xo[c], acc);
+        for (int c = 0; c < SM; c++) acc = fma(-col[c * ld], readlane_f64(xo, c), acc);
       }
     }
-    if (td >= 0) sv_commit<SM>(T, PD, lane);
-    if (n_td >= 0) sv_load_val(F, mD, PD);
+    if (td >= 0) sv_commit<SM>(T, PD, lane, nrd);
+    if (n_td >= 0) sv_load_val(F, mD, PD, nrd);
     if (nn_td >= 0) sv_load_map(pk, nn_td, mD, lane);
     if (td >= 0) {
       if (fwd) {
@@ -1180,8 +1190,12 @@ __global__ __launch_bounds__(1024) void k_plan_solve(rldl_dev_sym S, rldl_dev_nu
     const int *permg = S.plan + S.po_perm;                     // global copy: lets the rhs gather start before the barrier
     for (int j0 = 0; j0 < S.N; j0 += 4 * WAVE) {               // permute_x  qdldl_interface.c:538-541
       double v[4];
+      int o[4];
+      // clamped indices instead of conditional loads: the four index loads, then the four value loads, are in flight together
 #pragma unroll
-      for (int t = 0; t < 4; t++) { const int j = j0 + t * WAVE + lane; v[t] = j < S.N ? b[permg[j]] : 0.0; }
+      for (int t = 0; t < 4; t++) o[t] = permg[min(j0 + t * WAVE + lane, S.N - 1)];
+#pragma unroll
+      for (int t = 0; t < 4; t++) v[t] = b[o[t]];
 #pragma unroll
       for (int t = 0; t < 4; t++) { const int j = j0 + t * WAVE + lane; if (j < S.N) xs[j] = v[t]; }
     }
@@ -1196,16 +1210,18 @@ __global__ __launch_bounds__(1024) void k_plan_solve(rldl_dev_sym S, rldl_dev_nu
     for (int j = lane; j < S.N; j += WAVE) b[perm[j]] = xs[j];  // permutet_x :544-547, raw solution :563-565
   } else {
     const double *ri = Nn.rho_inv + (size_t)inst * S.m;
+    const double *rsafe = S.m > 0 ? ri : b;                     // m == 0: no row is a constraint, the load just needs a valid address
     for (int j0 = 0; j0 < S.N; j0 += 4 * WAVE) {
       double bo[4], rr[4];
       int oo[4];
 #pragma unroll
       for (int t = 0; t < 4; t++) {
         const int j = j0 + t * WAVE + lane;
-        oo[t] = j < S.N ? perm[j] : -1;
-        const bool con = oo[t] >= S.n;
-        bo[t] = con ? b[oo[t]] : 0.0;
-        rr[t] = con ? ri[oo[t] - S.n] : 0.0;
+        const int o = perm[min(j, S.N - 1)];
+        oo[t] = j < S.N ? o : -1;
+        const bool con = o >= S.n;                              // (unconditional loads from clamped addresses, selected afterwards)
+        bo[t] = b[o];
+        rr[t] = rsafe[con ? o - S.n : 0];
       }
 #pragma unroll
       for (int t = 0; t < 4; t++) {

@@ -64,8 +64,8 @@ static void build_solve_tiles(rldl_batch *h, const int *bs, int nb, int ld, cons
                               const int *cptr, const int *cslot, const int *cpos, int ctot) {
   static const int widths[] = {8, 16, 22, 24, 32};               /* instantiated block-width bounds SM of the solve kernels */
   rldl_dev_stage *G = &h->dsym.stage;
-  unsigned *pk = 0, pad;
-  int *prog = 0, b, e, k, lds = 0, sm = 0;
+  unsigned *pk = 0, pad, tmp[SV_TILE_WORDS];
+  int *prog = 0, b, e, k, lds = 0, sm = 0, rc = 0, rd = 0;
   const int zs = h->dsym.ldF - 1;                                /* spare slot of the factor row, always 0.0 */
   (void)dtot; (void)ctot;
   for (k = 0; k < 5 && !lds; k++) if (G->smax <= widths[k]) { sm = widths[k]; lds = sm + 1; }   /* tile rows SM + 1 wide (odd) */
@@ -85,6 +85,14 @@ static void build_solve_tiles(rldl_batch *h, const int *bs, int nb, int ld, cons
     qsort(tdw, (size_t)nd, sizeof(unsigned), cmp_slot);
     for (e = nc; e < SV_TILE_WORDS; e++) tcw[e] = pad;
     for (e = nd; e < SV_TILE_WORDS; e++) tdw[e] = pad;
+    if ((nc + 63) / 64 > rc) rc = (nc + 63) / 64;
+    if ((nd + 63) / 64 > rd) rd = (nd + 63) / 64;
+    /* entry i (slot order) belongs to lane i % 64, round i / 64; stored lane-major: word [lane][round] */
+    for (k = 0; k < 2; k++) {
+      unsigned *w = k ? tdw : tcw;
+      for (e = 0; e < SV_TILE_WORDS; e++) tmp[(e % 64) * (SV_TILE_WORDS / 64) + e / 64] = w[e];
+      memcpy(w, tmp, sizeof(tmp));
+    }
   }
   /* entry k: { c0, s, o0, coupling tile or -1, diagonal tile or -1 }; forward blocks 0..nb-1, backward blocks nb-1..0 */
   for (k = 0; k < 2 * nb + 4; k++) {
@@ -100,7 +108,7 @@ static void build_solve_tiles(rldl_batch *h, const int *bs, int nb, int ld, cons
   }
   G->sv_pk = (const unsigned *)upload_ints((const int *)pk, (size_t)SV_TILE_WORDS * (size_t)(2 * nb));
   G->sv_prog = upload_ints(prog, (size_t)8 * (size_t)(2 * nb + 4));
-  if (G->sv_pk && G->sv_prog) { G->sv_ok = 1; G->sv_ld = lds; G->sv_coff = 0; G->sv_ntiles = 2 * nb; }
+  if (G->sv_pk && G->sv_prog) { G->sv_ok = 1; G->sv_ld = lds; G->sv_coff = rc | (rd << 8); G->sv_ntiles = 2 * nb; }
 out:
   free(pk); free(prog);
 }
