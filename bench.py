@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--batch", type=int, default=4096, help="instances per GPU")
     ap.add_argument("--iters", type=int, default=200, help="ADMM iterations per solve")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sync-steps", action="store_true", help="blocking update_P_A / solve calls (host round trips inside a step)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -82,10 +83,19 @@ def main():
     assert w.status == 0, "setup failed: %s" % w.status
     dims = w.linsys().dims()
 
+    # A step is enqueued on the workspace's stream without host synchronisation (osqp_batch_update_P_A_async +
+    # osqp_batch_solve_async): the GPU goes from one step's final check straight into the next step's refactorisation.
+    # --sync-steps uses the blocking calls instead (one host round trip after the refactorisation, one after the solve).
     def step():
-        if w.update_P_A(dPx, dAx):                           # KKT value scatter + numeric factor of every instance
-            raise RuntimeError("refactor failed")
-        res = w.solve(clone=False)                           # 200 fused ADMM iterations + final info (views, no copies)
+        if args.sync_steps:
+            if w.update_P_A(dPx, dAx):                       # KKT value scatter + numeric factor of every instance
+                raise RuntimeError("refactor failed")
+            res = w.solve(clone=False)                       # 200 fused ADMM iterations + final info (views, no copies)
+        else:
+            if w.update_P_A(dPx, dAx, wait=False):
+                raise RuntimeError("refactor could not be enqueued")
+            w.solve_async()
+            res = w.results(clone=False)                     # views of the workspace's result arrays (stream-ordered)
         if world > 1:
             res = rdist.gather_results(res, n, m)            # the path's only collective
         return res
@@ -97,12 +107,17 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    w.wait(clone=False)
     sync()
     t0 = time.perf_counter()
     loops = []
     for _ in range(args.steps):
         res = step()
-        loops.append(w.last_loop())                          # HIP events around the step's ADMM loop: (ms, iterations, launches)
+        if args.sync_steps:
+            loops.append(w.last_loop())                      # HIP events around the step's ADMM loop: (ms, iterations, launches)
+    if not args.sync_steps:
+        w.wait(clone=False)                                  # raises if any refactorisation of the timed steps failed
+        loops.append(w.last_loop())                          # (the event pair of the last step's loop)
     sync()
     elapsed = time.perf_counter() - t0
     tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)

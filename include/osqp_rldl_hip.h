@@ -158,6 +158,8 @@ c_int osqp_batch_update_rho(osqp_batch *w, c_float rho_new);           /* osqp.c
  * _check_termination, _polish_refine_iter, _delta (osqp.c:1321-1560) in one call; other fields of `s` are ignored */
 c_int osqp_batch_update_settings(osqp_batch *w, const OSQPBatchSettings *s);
 c_int osqp_batch_update_P_A(osqp_batch *w, const c_float *d_Px, const c_float *d_Ax); /* osqp.c:1158-1266 */
+/* the same, only enqueued: a failed refactorisation is reported by the next osqp_batch_wait / osqp_batch_solve (RLDL_NONCVX_ERROR) */
+c_int osqp_batch_update_P_A_async(osqp_batch *w, const c_float *d_Px, const c_float *d_Ax);
 c_int osqp_batch_warm_start(osqp_batch *w, const c_float *d_x, const c_float *d_y);   /* osqp.c:929-948 */
 /* results: device pointers owned by the workspace (valid until cleanup).  x, y are the OSQPSolution of
  * store_solution (auxil.c:527-565: unscaled, NaN when the instance is infeasible / non-convex); z is work->z. */

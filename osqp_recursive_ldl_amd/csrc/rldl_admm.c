@@ -254,6 +254,10 @@ c_int osqp_batch_wait(osqp_batch *w) {
     (void)hipEventElapsedTime(&w->last_loop_ms, (hipEvent_t)w->ev0, (hipEvent_t)w->ev1);
     w->loop_pending = 0;
   }
+  if (w->refactor_pending) {                                     /* verdict of osqp_batch_update_P_A_async */
+    w->refactor_pending = 0;
+    if (rldl_batch_check_status(w->ls)) return RLDL_NONCVX_ERROR;
+  }
   return 0;
 }
 
@@ -432,6 +436,24 @@ c_int osqp_batch_update_P_A(osqp_batch *w, const c_float *d_Px, const c_float *d
   rc = rldl_batch_update_matrices(w->ls, d_Px ? w->Px : 0, d_Ax ? w->Ax : 0);
   reset_info(w);
   return rc;
+}
+
+/* osqp_update_P_A without the host round trip: everything is enqueued on the workspace's stream; a failed refactorisation
+ * (non-convex instance, zero pivot: the reference returns it from osqp_update_P_A, osqp.c:1246-1262) is reported by the next
+ * osqp_batch_wait / osqp_batch_solve as RLDL_NONCVX_ERROR.  With osqp_batch_solve_async this keeps a stream of
+ * update + solve steps free of host synchronisation. */
+c_int osqp_batch_update_P_A_async(osqp_batch *w, const c_float *d_Px, const c_float *d_Ax) {
+  hipStream_t st;
+  if (!w) return 7;
+  st = (hipStream_t)w->stream;
+  if (w->st.scaling && rldl_launch_unscale_data(&w->ls->dsym, &w->W, w->Px, w->Ax, w->q, w->l, w->u, w->stream)) return 1;
+  if (d_Px && !HIP_OK(hipMemcpyAsync(w->Px, d_Px, sizeof(double) * (size_t)w->batch * (size_t)w->nnzP, hipMemcpyDeviceToDevice, st))) return 1;
+  if (d_Ax && !HIP_OK(hipMemcpyAsync(w->Ax, d_Ax, sizeof(double) * (size_t)w->batch * (size_t)w->nnzA, hipMemcpyDeviceToDevice, st))) return 1;
+  if (w->st.scaling && rldl_launch_scale_data(&w->ls->dsym, &w->W, w->Px, w->Ax, w->q, w->l, w->u, (int)w->st.scaling, w->stream)) return 1;
+  if (rldl_batch_update_matrices_async(w->ls, (w->st.scaling || d_Px) ? w->Px : 0, (w->st.scaling || d_Ax) ? w->Ax : 0)) return 1;
+  reset_info(w);
+  w->refactor_pending = 1;
+  return 0;
 }
 
 c_int osqp_batch_warm_start(osqp_batch *w, const c_float *d_x, const c_float *d_y) {

@@ -143,7 +143,7 @@ void rldl_batch_free(rldl_batch *h) {
   if (h->ev0) (void)hipEventDestroy((hipEvent_t)h->ev0);
   if (h->ev1) (void)hipEventDestroy((hipEvent_t)h->ev1);
   rldl_symbolic_free(h->sym);
-  free(h->status_host);
+  if (h->status_host) (void)hipHostFree(h->status_host);
   free(h);
 }
 
@@ -187,8 +187,8 @@ static c_int batch_create(rldl_batch **hp, c_int batch, const csc *P, const csc 
   if (ok && !HIP_OK(hipMemset(h->num.F, 0, sizeof(double) * (size_t)batch * (size_t)h->dsym.ldF))) ok = 0;
   h->num.rho_inv = (double *)dev_alloc(sizeof(double) * (size_t)batch * (size_t)h->sym->m, &ok);
   h->num.status = (int *)dev_alloc(sizeof(int) * (size_t)batch, &ok);
-  h->status_host = (int *)calloc((size_t)batch, sizeof(int));
-  if (!ok || !h->status_host) { rldl_batch_free(h); return RLDL_MEM_ALLOC_ERROR; }
+  if (ok && !HIP_OK(hipHostMalloc((void **)&h->status_host, sizeof(int) * (size_t)batch, hipHostMallocDefault))) { h->status_host = 0; ok = 0; }
+  if (!ok || !h->status_host) { rldl_batch_free(h); return RLDL_MEM_ALLOC_ERROR; }   /* pinned: the status read-back can be asynchronous */
   if (!HIP_OK(hipEventCreate((hipEvent_t *)&h->ev0)) || !HIP_OK(hipEventCreate((hipEvent_t *)&h->ev1))) {
     rldl_batch_free(h);
     return RLDL_MEM_ALLOC_ERROR;
@@ -229,6 +229,13 @@ c_int rldl_batch_update_matrices(rldl_batch *h, const c_float *d_Px, const c_flo
   return factor_and_check(h, 0) ? 1 : 0; /* reference returns (QDLDL_factor < 0), :598-600 */
 }
 
+/* update_matrices without the host round trip: scatter + refactor are only enqueued; the QDLDL verdict (qdldl_interface.c:598-600)
+ * is delivered by the next rldl_batch_check_status (which synchronises the stream). */
+c_int rldl_batch_update_matrices_async(rldl_batch *h, const c_float *d_Px, const c_float *d_Ax) {
+  if (!h || h->sym->polish) return 1;
+  if (rldl_launch_kkt_assemble(&h->dsym, &h->num, d_Px, d_Ax, 0, 0, 0, h->stream)) return 1;
+  return rldl_launch_factor(&h->dsym, &h->num, 0, h->stream) ? 1 : 0;
+}
 c_int rldl_batch_update_rho_vec(rldl_batch *h, const c_float *d_rho_vec, const int *d_mask) {
   if (!h || (!d_rho_vec && h->sym->m > 0) || h->sym->polish) return 1;
   if (rldl_launch_kkt_assemble(&h->dsym, &h->num, 0, 0, d_rho_vec, 0, d_mask, h->stream)) return 1;

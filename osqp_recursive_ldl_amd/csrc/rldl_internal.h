@@ -36,6 +36,7 @@ struct osqp_batch {
   int *h_tmp_i;                  /* [batch] host scratch */
   double *h_tmp_d;               /* [batch] host scratch */
   int loop_pending;              /* a solve loop was enqueued and its event pair not read yet */
+  int refactor_pending;          /* osqp_batch_update_P_A_async: the verdict of the refactorisation has not been read yet */
   float last_loop_ms;
   c_int last_loop_launches;     /* ADMM iterations run by the last solve loop ... */
   c_int last_loop_groups;       /* ... in this many launch groups (one kernel launch each on the arrowhead path) */
@@ -45,6 +46,7 @@ int rldl_device_available(void);
 void rldl_batch_enable_stage(rldl_batch *h, const rldl_stage_dims *dims);   /* rldl_recursive.c */
 void rldl_stage_maps_free(rldl_batch *h);
 void osqp_batch_reset_info(osqp_batch *w);                                    /* rldl_admm.c: auxil.c:628-645 */
+c_int rldl_batch_update_matrices_async(rldl_batch *h, const c_float *d_Px, const c_float *d_Ax);   /* rldl_backend.c */
 c_int rldl_batch_check_status(rldl_batch *h); /* sync + qdldl_interface.c:80-92 verdict: 0 ok, 1 failed */
 
 #endif

@@ -102,8 +102,9 @@ class OSQPBatch:
             raise RuntimeError("osqp_batch_solve_async failed (%d)" % rc)
 
     def wait(self, clone=True):
-        if _lib.lib().osqp_batch_wait(self.h):
-            raise RuntimeError("osqp_batch_wait failed")
+        rc = _lib.lib().osqp_batch_wait(self.h)
+        if rc:
+            raise RuntimeError("osqp_batch_wait failed (%d)" % rc)
         return self.results(clone=clone)
 
     def _view(self, ptr, shape, dtype):
@@ -182,9 +183,12 @@ class OSQPBatch:
     def update_rho(self, rho):
         return int(_lib.lib().osqp_batch_update_rho(self.h, float(rho)))
 
-    def update_P_A(self, Px=None, Ax=None):
+    def update_P_A(self, Px=None, Ax=None, wait=True):
+        """osqp_update_P_A.  wait=False only enqueues the scatter + refactorisation (no host synchronisation); a failed
+        refactorisation then surfaces at the next wait() / solve()."""
         _dev_f64(Px, (self.batch, self.P.nnz), "Px"); _dev_f64(Ax, (self.batch, self.A.nnz), "Ax")
-        return int(_lib.lib().osqp_batch_update_P_A(self.h, _dptr(Px), _dptr(Ax)))
+        fn = _lib.lib().osqp_batch_update_P_A if wait else _lib.lib().osqp_batch_update_P_A_async
+        return int(fn(self.h, _dptr(Px), _dptr(Ax)))
 
     def warm_start(self, x, y):
         _dev_f64(x, (self.batch, self.n), "x"); _dev_f64(y, (self.batch, self.m), "y")

@@ -533,3 +533,33 @@ def test_update_settings_mirrors_the_reference_setters(R):
                           adaptive_rho=0)
     assert it1 == int(fresh.solve()["iter"][0]) > it0
     w.cleanup(); fresh.cleanup()
+
+
+def test_enqueued_update_and_solve_equal_the_blocking_calls_and_report_a_failed_refactor_at_wait(R):
+    """osqp_batch_update_P_A_async + osqp_batch_solve_async: same results as the blocking calls (same kernels, same
+    inputs -> bit-identical); a refactorisation that fails (P made indefinite: fewer than n positive pivots,
+    qdldl_interface.c:80-92) is reported by the next wait instead of by the update call."""
+    wl = R.workloads.SharedPatternQPs()
+    B = 6
+    Px, Ax, q, l, u = wl.values(B)
+    w = R.OSQPBatch(wl.P_pattern, wl.A_pattern, dev(Px), dev(Ax), dev(q), dev(l), dev(u), **FIXED)
+    Px2, Ax2 = wl.values(B, seed0=50)[:2]
+    assert w.update_P_A(dev(Px2), dev(Ax2)) == 0
+    ra = w.solve()
+    assert w.update_P_A(dev(Px), dev(Ax)) == 0                 # back to the first problem, then the enqueued path
+    assert w.update_P_A(dev(Px2), dev(Ax2), wait=False) == 0
+    w.solve_async()
+    rb = w.wait()
+    assert torch.equal(ra["x"], rb["x"]) and torch.equal(ra["y"], rb["y"]) and torch.equal(ra["iter"], rb["iter"])
+    bad = Px2.copy()
+    bad[3] = -np.abs(bad[3]) - 1.0                              # instance 3: P negative definite
+    assert w.update_P_A(dev(bad), dev(Ax2)) != 0                # blocking call: reported at once
+    assert w.update_P_A(dev(bad), dev(Ax2), wait=False) == 0    # enqueued: reported by wait
+    w.solve_async()
+    with pytest.raises(RuntimeError):
+        w.wait()
+    assert w.update_P_A(dev(Px2), dev(Ax2), wait=False) == 0    # and the workspace is usable again
+    w.solve_async()
+    rc = w.wait()
+    assert torch.equal(ra["x"], rc["x"])
+    w.cleanup()
