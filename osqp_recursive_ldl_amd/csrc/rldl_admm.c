@@ -263,19 +263,13 @@ c_int osqp_batch_wait(osqp_batch *w) {
 
 static c_int solve_impl(osqp_batch *w, int wait) {
   c_int iter, last_iter = 0, launches = 0, groups = 0, nchecks = 0;
-  int can_check = 0, nact;
+  int can_check = 0;
   size_t B;
   hipStream_t st;
   if (!w) return 7; /* OSQP_WORKSPACE_NOT_INIT_ERROR */
   B = (size_t)w->batch; st = (hipStream_t)w->stream;
-  if (!w->st.warm_start) { /* cold_start, auxil.c:158-162 */
-    (void)hipMemsetAsync(w->W.x, 0, sizeof(double) * B * (size_t)w->n, st);
-    (void)hipMemsetAsync(w->W.z, 0, sizeof(double) * B * (size_t)w->m, st);
-    (void)hipMemsetAsync(w->W.y, 0, sizeof(double) * B * (size_t)w->m, st);
-  }
-  if (fill_int(w, w->W.status, ST_UNSOLVED)) return 1;
-  nact = (int)w->batch;
-  if (!HIP_OK(hipMemsetD32Async((hipDeviceptr_t)w->W.n_active, nact, 1, st))) return 1;
+  /* cold_start (auxil.c:158-162) when warm starting is off, status = OSQP_UNSOLVED, active counter: one launch */
+  if (rldl_launch_solve_begin(&w->W, (int)w->n, (int)w->m, w->st.warm_start ? 0 : 1, 0, w->stream)) return 1;
 
   (void)hipEventRecord((hipEvent_t)w->ev0, st);
   iter = 0;
@@ -446,12 +440,15 @@ c_int osqp_batch_update_P_A_async(osqp_batch *w, const c_float *d_Px, const c_fl
   hipStream_t st;
   if (!w) return 7;
   st = (hipStream_t)w->stream;
-  if (w->st.scaling && rldl_launch_unscale_data(&w->ls->dsym, &w->W, w->Px, w->Ax, w->q, w->l, w->u, w->stream)) return 1;
-  if (d_Px && !HIP_OK(hipMemcpyAsync(w->Px, d_Px, sizeof(double) * (size_t)w->batch * (size_t)w->nnzP, hipMemcpyDeviceToDevice, st))) return 1;
-  if (d_Ax && !HIP_OK(hipMemcpyAsync(w->Ax, d_Ax, sizeof(double) * (size_t)w->batch * (size_t)w->nnzA, hipMemcpyDeviceToDevice, st))) return 1;
-  if (w->st.scaling && rldl_launch_scale_data(&w->ls->dsym, &w->W, w->Px, w->Ax, w->q, w->l, w->u, (int)w->st.scaling, w->stream)) return 1;
-  if (rldl_batch_update_matrices_async(w->ls, (w->st.scaling || d_Px) ? w->Px : 0, (w->st.scaling || d_Ax) ? w->Ax : 0)) return 1;
-  reset_info(w);
+  if (w->st.scaling) {
+    if (rldl_launch_unscale_data(&w->ls->dsym, &w->W, w->Px, w->Ax, w->q, w->l, w->u, w->stream)) return 1;
+    if (d_Px && !HIP_OK(hipMemcpyAsync(w->Px, d_Px, sizeof(double) * (size_t)w->batch * (size_t)w->nnzP, hipMemcpyDeviceToDevice, st))) return 1;
+    if (d_Ax && !HIP_OK(hipMemcpyAsync(w->Ax, d_Ax, sizeof(double) * (size_t)w->batch * (size_t)w->nnzA, hipMemcpyDeviceToDevice, st))) return 1;
+    if (rldl_launch_scale_data(&w->ls->dsym, &w->W, w->Px, w->Ax, w->q, w->l, w->u, (int)w->st.scaling, w->stream)) return 1;
+    if (rldl_batch_update_matrices_async(w->ls, w->Px, w->Ax, 0, 0)) return 1;
+  } else if (rldl_batch_update_matrices_async(w->ls, d_Px, d_Ax, w->Px, w->Ax)) return 1;   /* the workspace's copy is written by the scatter */
+  /* reset_info (auxil.c:628-645) in one launch */
+  if (rldl_launch_solve_begin(&w->W, (int)w->n, (int)w->m, 0, 1, w->stream)) return 1;
   w->refactor_pending = 1;
   return 0;
 }

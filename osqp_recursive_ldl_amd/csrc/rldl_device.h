@@ -98,6 +98,8 @@ typedef struct {
 
 int rldl_launch_kkt_assemble(const rldl_dev_sym *S, const rldl_dev_num *Nn, const double *d_Px, const double *d_Ax,
                              const double *d_rho_vec, int set_sigma_only, const int *d_mask, void *stream);
+int rldl_launch_kkt_assemble_keep(const rldl_dev_sym *S, const rldl_dev_num *Nn, const double *d_Px, const double *d_Ax, double *keepP,
+                                  double *keepA, void *stream);
 int rldl_launch_factor(const rldl_dev_sym *S, const rldl_dev_num *Nn, const int *d_mask, void *stream);
 int rldl_launch_stage_factor(const rldl_dev_sym *S, const rldl_dev_num *Nn, const int *d_mask, int first_block, void *stream);
 /* stage recursion where instance b restarts at block d_b0v[b] (0 = from the first block) */
@@ -122,6 +124,8 @@ int rldl_launch_admm_iters(const rldl_dev_sym *S, const rldl_dev_num *Nn, const 
 int rldl_launch_admm_check(const rldl_dev_sym *S, const rldl_dev_admm *W, int iter, int approximate, int final_pass,
                            void *stream);
 int rldl_launch_set_rho_vec(const rldl_dev_sym *S, const rldl_dev_admm *W, int init, void *stream);
+/* start of a solve in one launch: status = OSQP_UNSOLVED, active counter = batch, optional cold start and rho_updates = 0 */
+int rldl_launch_solve_begin(const rldl_dev_admm *W, int n, int m, int cold, int reset_rho_updates, void *stream);
 /* scale_data / unscale_data (src/scaling.c:44-173) on the workspace's own copies of P, A, q, l, u */
 int rldl_launch_scale_data(const rldl_dev_sym *S, const rldl_dev_admm *W, double *Px, double *Ax, double *q, double *l, double *u,
                            int iters, void *stream);

@@ -66,17 +66,28 @@ __device__ __forceinline__ int wave_any(int p) { return __any(p); }
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_kkt_assemble(rldl_dev_sym S, rldl_dev_num Nn, const double *__restrict__ Px,
                                                       const double *__restrict__ Ax, const double *__restrict__ rho_vec,
-                                                      int set_sigma_only, const int *__restrict__ mask) {
+                                                      int set_sigma_only, const int *__restrict__ mask,
+                                                      double *__restrict__ keepP, double *__restrict__ keepA) {
   const int inst = blockIdx.x;
   if (mask && !mask[inst]) return;
   double *K = Nn.Kx + (size_t)inst * S.nnzK;
-  if (Px) {
+  if (Px) {                                                      // keepP / keepA: the caller's own copy of the values is written on the way
     const double *p = Px + (size_t)inst * S.nnzP;
-    for (int i = threadIdx.x; i < S.nnzP; i += blockDim.x) K[S.PtoK[i]] = p[i] + (S.Pisdiag[i] ? Nn.sigma : 0.0);
+    double *kp = keepP ? keepP + (size_t)inst * S.nnzP : nullptr;
+    for (int i = threadIdx.x; i < S.nnzP; i += blockDim.x) {
+      const double v = p[i];
+      K[S.PtoK[i]] = v + (S.Pisdiag[i] ? Nn.sigma : 0.0);
+      if (kp) kp[i] = v;
+    }
   }
   if (Ax) {
     const double *a = Ax + (size_t)inst * S.nnzA;
-    for (int i = threadIdx.x; i < S.nnzA; i += blockDim.x) K[S.AtoK[i]] = a[i];
+    double *ka = keepA ? keepA + (size_t)inst * S.nnzA : nullptr;
+    for (int i = threadIdx.x; i < S.nnzA; i += blockDim.x) {
+      const double v = a[i];
+      K[S.AtoK[i]] = v;
+      if (ka) ka[i] = v;
+    }
   }
   if (set_sigma_only)
     for (int i = threadIdx.x; i < S.nsig; i += blockDim.x) K[S.sigK[i]] = Nn.sigma;
@@ -2349,7 +2360,34 @@ extern "C" int rldl_launch_kkt_assemble(const rldl_dev_sym *S, const rldl_dev_nu
                                         const int *d_mask, void *stream) {
   if (Nn->batch <= 0) return 0;
   hipLaunchKernelGGL(k_kkt_assemble, dim3(Nn->batch), dim3(256), 0, (hipStream_t)stream, *S, *Nn, d_Px, d_Ax, d_rho_vec,
-                     set_sigma_only, d_mask);
+                     set_sigma_only, d_mask, (double *)0, (double *)0);
+  return launch_status();
+}
+// the same scatter that also stores the incoming values in the caller's own arrays (osqp_update_P_A keeps a copy of the data)
+extern "C" int rldl_launch_kkt_assemble_keep(const rldl_dev_sym *S, const rldl_dev_num *Nn, const double *d_Px, const double *d_Ax,
+                                             double *keepP, double *keepA, void *stream) {
+  if (Nn->batch <= 0) return 0;
+  hipLaunchKernelGGL(k_kkt_assemble, dim3(Nn->batch), dim3(256), 0, (hipStream_t)stream, *S, *Nn, d_Px, d_Ax, (const double *)0, 0,
+                     (const int *)0, d_Px ? keepP : (double *)0, d_Ax ? keepA : (double *)0);
+  return launch_status();
+}
+// start of osqp_solve for the whole batch in one launch: status = OSQP_UNSOLVED, rho_updates = 0 (reset_info, auxil.c:628-645),
+// the active-instance counter, and cold_start (auxil.c:158-162) when warm starting is off
+__global__ __launch_bounds__(256) void k_solve_begin(rldl_dev_admm W, int n, int m, int cold, int reset_rho_updates) {
+  const int inst = blockIdx.x;
+  if (threadIdx.x == 0) {
+    W.status[inst] = ST_UNSOLVED;
+    if (reset_rho_updates) W.rho_updates[inst] = 0;
+    if (inst == 0) *W.n_active = W.batch;
+  }
+  if (cold) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) W.x[(size_t)inst * n + i] = 0.0;
+    for (int i = threadIdx.x; i < m; i += blockDim.x) { W.z[(size_t)inst * m + i] = 0.0; W.y[(size_t)inst * m + i] = 0.0; }
+  }
+}
+extern "C" int rldl_launch_solve_begin(const rldl_dev_admm *W, int n, int m, int cold, int reset_rho_updates, void *stream) {
+  if (W->batch <= 0) return 0;
+  hipLaunchKernelGGL(k_solve_begin, dim3(W->batch), dim3(256), 0, (hipStream_t)stream, *W, n, m, cold, reset_rho_updates);
   return launch_status();
 }
 
