@@ -137,3 +137,57 @@ def test_block_tri_solve_and_fused_iteration_match_oracle(N):
         assert relerr(r["y"][b].cpu().numpy(), ro["y_iter"]) < 1e-8
         assert relerr(r["z"][b].cpu().numpy(), ro["z_iter"]) < 1e-8
     w.cleanup()
+
+
+def test_full_size_mpc_batch_4096_properties():
+    """BASELINE config 3 at full size (N = 20, KKT 772, batch 4096), stage-structured handle: size-independent properties
+    instead of an oracle sweep -- linearity of the block tri-solve, residual of the permuted system on a spread sample,
+    batch position does not matter, restart from a stage == full refactorisation, horizon 20 -> 19 -> 20 returns to the
+    same factor bit for bit."""
+    import osqp_recursive_ldl_amd as R
+    from helpers import full_kkt
+    wl = R.workloads.MPCStageQPs(N=20)
+    B, rep = 4096, 16
+    Px, Ax, q, l, u = wl.values(rep)
+    tile = lambda a: np.tile(a, (B // rep, 1))
+    dPx, dAx = dev(tile(Px)), dev(tile(Ax))
+    rho = np.where(tile(l) == tile(u), 100.0, 0.1)
+    ls = R.BatchLinsys.recursive(wl.dims, wl.P_pattern, wl.A_pattern, dPx, dAx, 1e-6, dev(rho))
+    assert ls.status == 0 and (ls.factor_status() == wl.n).all()
+    N = wl.n + wl.m
+    g = torch.Generator(device="cuda:0"); g.manual_seed(1)
+    r1 = torch.randn((B, N), dtype=torch.float64, device="cuda:0", generator=g)
+    r2 = torch.randn((B, N), dtype=torch.float64, device="cuda:0", generator=g)
+    s1, s2, s3 = ls.solve(r1.clone()), ls.solve(r2.clone()), ls.solve((0.5 * r1 - r2).clone())
+    assert float((s3[:, :wl.n] - (0.5 * s1[:, :wl.n] - s2[:, :wl.n])).abs().max()) < 1e-6 * max(1.0, float(s1.abs().max()))
+    for b in range(0, B, 409):
+        P, qq, A, ll, uu = wl.instance(b % rep)
+        K = full_kkt(P, A, 1e-6, rho[b])
+        out = s1[b].cpu().numpy(); r = r1[b].cpu().numpy()
+        raw = np.concatenate([out[:wl.n], (out[wl.n:] - r[wl.n:]) * rho[b]])
+        assert np.max(np.abs(K @ raw - r)) < 1e-7 * max(1.0, np.max(np.abs(raw)))
+    assert bool(torch.isfinite(s3).all())
+    f0 = ls.export_factor(4095)["Lx"].copy()
+    assert np.array_equal(f0, ls.export_factor(4095 - rep)["Lx"])                        # same data, other batch position
+    assert ls.update_from_stage(12, dPx, dAx, None) == 0                                 # restart == what was there
+    assert np.array_equal(ls.export_factor(4095)["Lx"], f0)
+    ls.free()
+    kw = dict(rho=0.1, sigma=1e-6, alpha=1.6, max_iter=20, check_termination=0, adaptive_rho=0, warm_start=0, scaling=0)
+    w19 = R.workloads.MPCStageQPs(N=19)
+    q19, l19, u19 = [dev(np.tile(a, (B // rep, 1))) for a in w19.values(rep)[2:]]
+    hz = R.OSQPHorizon(wl.dims, 20, wl.Q0, wl.Qi, wl.QN, wl.A0, wl.Ai, wl.Aij, wl.AN, dev(tile(q)), dev(tile(l)), dev(tile(u)), **kw)
+    assert hz.workspace.update_P_A(dPx, dAx) == 0
+    ra = hz.workspace.solve()
+    fa = hz.workspace.linsys().export_factor(2049)
+    assert hz.update(19, q19, l19, u19) == 0 and hz.last_update()["instances_reused"] == B
+    r19 = hz.workspace.solve()
+    assert bool(torch.isfinite(r19["x"]).all()) and (r19["iter"] == 20).all()
+    assert hz.update(20, dev(tile(q)), dev(tile(l)), dev(tile(u))) == 0 and hz.last_update()["instances_reused"] == B
+    fb = hz.workspace.linsys().export_factor(2049)
+    # stages >= 19 are nominal again after the round trip (update_AP_matrices), stages < 19 kept the instance's values
+    sym = hz.workspace.linsys().export_symbolic()
+    c19 = wl.nu + (wl.nx + wl.ny) + 18 * (2 * wl.nx + wl.nu + wl.ny)
+    keep = sym["Lp"][c19]
+    assert np.array_equal(fa["Lx"][:keep], fb["Lx"][:keep]) and np.array_equal(fa["D"][:c19], fb["D"][:c19])
+    assert torch.equal(ra["x"][0], ra["x"][rep]) and torch.equal(r19["x"][3], r19["x"][3 + rep])
+    hz.free()
