@@ -57,6 +57,21 @@ static int upload_symbolic(rldl_batch *h) {
   UP(Pp, s->n + 1, int); UP(Pi, s->nnzP, int); UP(Prp, s->n + 1, int); UP(Prj, s->nnzP, int); UP(Prpos, s->nnzP, int);
   UP(Ap, s->n + 1, int); UP(Ai, s->nnzA, int); UP(Arp, s->m + 1, int); UP(Arj, s->nnzA, int); UP(Arpos, s->nnzA, int);
   UP(LtoS, s->nnzL, int);
+  if (s->n < 65536 && s->m < 65536) {                            /* (row | col << 16) of every P / A entry, storage order */
+    unsigned *t = (unsigned *)malloc(sizeof(unsigned) * (size_t)(s->nnzP + s->nnzA + 2));
+    if (t) {
+      unsigned *pfl = t, *afl = pfl + s->nnzP;
+      int j, q;
+      for (j = 0; j < s->n; j++) {
+        for (q = s->Pp[j]; q < s->Pp[j + 1]; q++) pfl[q] = (unsigned)s->Pi[q] | ((unsigned)j << 16);
+        for (q = s->Ap[j]; q < s->Ap[j + 1]; q++) afl[q] = (unsigned)s->Ai[q] | ((unsigned)j << 16);
+      }
+      D->Pfl = (const unsigned *)dev_upload(pfl, sizeof(unsigned) * (size_t)s->nnzP, &ok);
+      D->Afl = (const unsigned *)dev_upload(afl, sizeof(unsigned) * (size_t)s->nnzA, &ok);
+      D->flat_ok = ok && s->nnzP > 0;
+      free(t);
+    }
+  }
   D->plan = (const int *)dev_upload(s->plan, sizeof(int) * (size_t)(s->plan_ok ? ((s->plan_words + 3) & ~3) : 0), &ok); /* blob is calloc'ed with 4 words of slack */
   D->ldF = (s->nS + s->N + 2) & ~1;             /* even, and at least one spare slot that stays 0.0 (ldF-1) */
   D->nS = s->nS; D->nO = s->nO; D->ngroups = s->ngroups; D->plan_ok = s->plan_ok; D->plan_words = s->plan_ok ? s->plan_words : 0;
@@ -125,7 +140,7 @@ static void free_dev_symbolic(rldl_dev_sym *D) {
 #define FR(f) if (D->f) (void)hipFree((void *)D->f)
   FR(perm); FR(PtoK); FR(AtoK); FR(rhotoK); FR(sigK); FR(Pisdiag); FR(Lp); FR(Li); FR(Rp); FR(Rj); FR(Rpos);
   FR(KtoW); FR(Udst); FR(Uab); FR(Up); FR(Pp); FR(Pi); FR(Prp); FR(Prj); FR(Prpos); FR(Ap); FR(Ai); FR(Arp);
-  FR(Arj); FR(Arpos); FR(LtoS); FR(plan); FR(arrow_tpos); FR(arrow_pab); FR(arrow_pdc);
+  FR(Arj); FR(Arpos); FR(LtoS); FR(Pfl); FR(Afl); FR(plan); FR(arrow_tpos); FR(arrow_pab); FR(arrow_pdc);
 #undef FR
   memset(D, 0, sizeof(*D));
 }

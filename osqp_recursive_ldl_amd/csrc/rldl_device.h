@@ -38,6 +38,9 @@ typedef struct {
   const unsigned int *Uab;
   const long long *Up;
   const int *Pp, *Pi, *Prp, *Prj, *Prpos, *Ap, *Ai, *Arp, *Arj, *Arpos;
+  /* entry-parallel access for the residual kernel: (row | col << 16) per stored entry of P and A (CSC order); flat_ok = n, m < 65536 */
+  const unsigned *Pfl, *Afl;
+  int flat_ok;
   /* factor storage layout + grouped solve plan (rldl_plan.c) */
   const int *LtoS;             /* [nnzL] CSC position -> storage slot */
   const int *plan;             /* packed blob, plan_words int32 */

@@ -329,6 +329,44 @@ __device__ __forceinline__ void spmv_Psym(const rldl_dev_sym &S, const double *P
     out[j] = acc;
   }
 }
+// The three products of update_info at once, entry-parallel: every lane takes one stored entry per round and adds its
+// contributions with LDS atomics, so no lane walks a row (the row loops above cost one dependent index load per entry and
+// leave the wave waiting on memory for every one of them).  One pass per matrix in storage order -- coalesced value loads,
+// one table word (row | col << 16) per entry, four rounds of loads in flight; lanes that hit the same destination (the
+// entries of one column) are serialised by the LDS unit, which costs a few cycles against the microseconds saved.
+#define FLAT_U 4
+__device__ __forceinline__ void spmv3_flat(const rldl_dev_sym &S, const double *__restrict__ Pg, const double *__restrict__ Ag,
+                                           const double *vx, const double *vy, double *vAx, double *vPx, double *vAty, int lane) {
+  for (int i = lane; i < S.m; i += WAVE) vAx[i] = 0.0;
+  for (int i = lane; i < S.n; i += WAVE) { vPx[i] = 0.0; vAty[i] = 0.0; }
+  __syncthreads();
+  for (int p0 = 0; p0 < S.nnzA; p0 += FLAT_U * WAVE) {           // A x and A' y (mat_vec / mat_tpose_vec, lin_alg.c:241-322)
+    unsigned rc[FLAT_U];
+    double a[FLAT_U];
+#pragma unroll
+    for (int u = 0; u < FLAT_U; u++) { const int p = min(p0 + u * WAVE + lane, S.nnzA - 1); rc[u] = S.Afl[p]; a[u] = Ag[p]; }
+#pragma unroll
+    for (int u = 0; u < FLAT_U; u++)
+      if (p0 + u * WAVE + lane < S.nnzA) {
+        const unsigned r = rc[u] & 0xffffu, c = rc[u] >> 16;
+        unsafeAtomicAdd(&vAx[r], a[u] * vx[c]);
+        unsafeAtomicAdd(&vAty[c], a[u] * vy[r]);
+      }
+  }
+  for (int p0 = 0; p0 < S.nnzP; p0 += FLAT_U * WAVE) {           // P upper-tri: P x + P' x without the diagonal twice (auxil.c:299-303)
+    unsigned rc[FLAT_U];
+    double v[FLAT_U];
+#pragma unroll
+    for (int u = 0; u < FLAT_U; u++) { const int p = min(p0 + u * WAVE + lane, S.nnzP - 1); rc[u] = S.Pfl[p]; v[u] = Pg[p]; }
+#pragma unroll
+    for (int u = 0; u < FLAT_U; u++)
+      if (p0 + u * WAVE + lane < S.nnzP) {
+        const unsigned r = rc[u] & 0xffffu, c = rc[u] >> 16;
+        unsafeAtomicAdd(&vPx[r], v[u] * vx[c]);
+        if (r != c) unsafeAtomicAdd(&vPx[c], v[u] * vx[r]);
+      }
+  }
+}
 // scaled infinity norm max_i |s_i v_i| (s == nullptr: plain norm)
 __device__ __forceinline__ double norm_inf_s(const double *s, const double *v, int len, int lane) {
   double mx = 0.0;
@@ -424,9 +462,12 @@ __global__ __launch_bounds__(WAVE) void k_admm_check(rldl_dev_sym S, rldl_dev_ad
   __syncthreads();
 
   // update_info (auxil.c:567-626): residuals
-  spmv_A(S, Av, vx, vAx, lane);
-  spmv_Psym(S, Pv, vx, vPx, lane);
-  spmv_At(S, Av, vy, vAty, lane);
+  if (!STAGED && S.flat_ok) spmv3_flat(S, Pg, Ag, vx, vy, vAx, vPx, vAty, lane);
+  else {
+    spmv_A(S, Av, vx, vAx, lane);
+    spmv_Psym(S, Pv, vx, vPx, lane);
+    spmv_At(S, Av, vy, vAty, lane);
+  }
   __syncthreads();
   for (int i = lane; i < m; i += WAVE) t_m[i] = vAx[i] - vz[i];                     // primal residual vector (z_prev in the reference)
   for (int i = lane; i < n; i += WAVE) t_n[i] = q[i] + vPx[i] + vAty[i];            // dual residual vector (x_prev in the reference)
@@ -2513,7 +2554,8 @@ extern "C" int rldl_launch_admm_check(const rldl_dev_sym *S, const rldl_dev_admm
   if (approximate & 2) mode |= CHK_ADAPT;
   if (final_pass) mode |= CHK_FINAL;
   if (final_pass == 2) mode |= CHK_FINAL_NEEDS_INFO;
-  if (check_lds_staged(S) <= 40 * 1024)
+  // entry-parallel products straight from global memory when the tables exist; else the row loops, on LDS copies of P / A if they fit
+  if ((!S->flat_ok || getenv("RLDL_CHECK_STAGED")) && check_lds_staged(S) <= 40 * 1024)
     hipLaunchKernelGGL(k_admm_check<true>, dim3(W->batch), dim3(WAVE), check_lds_staged(S), (hipStream_t)stream, *S, *W, iter, mode);
   else
     hipLaunchKernelGGL(k_admm_check<false>, dim3(W->batch), dim3(WAVE), check_lds(S), (hipStream_t)stream, *S, *W, iter, mode);
