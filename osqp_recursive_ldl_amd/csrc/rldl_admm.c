@@ -148,7 +148,7 @@ c_int osqp_batch_setup(osqp_batch **wp, c_int batch, const csc *P, const csc *A,
   w->W.rho_est = (double *)dmalloc(sizeof(double) * B, &ok);
   w->W.status = (int *)dmalloc(sizeof(int) * B, &ok); w->W.iter = (int *)dmalloc(sizeof(int) * B, &ok);
   w->W.rho_updates = (int *)dmalloc(sizeof(int) * B, &ok); w->W.refactor = (int *)dmalloc(sizeof(int) * B, &ok);
-  w->W.n_active = (int *)dmalloc(sizeof(int), &ok);
+  w->W.n_active = (int *)dmalloc(sizeof(int) * RLDL_NACT_SLOTS, &ok);
   w->W.status_polish = (int *)dmalloc(sizeof(int) * B, &ok);
   if (w->st.polish) {
     w->W.pol_Ax = (double *)dmalloc(sizeof(double) * B * (size_t)w->nnzA, &ok);
@@ -167,7 +167,7 @@ c_int osqp_batch_setup(osqp_batch **wp, c_int batch, const csc *P, const csc *A,
   }
   if (!ok || !HIP_OK(hipEventCreate((hipEvent_t *)&w->ev0)) || !HIP_OK(hipEventCreate((hipEvent_t *)&w->ev1)) ||
       !HIP_OK(hipEventCreate((hipEvent_t *)&w->evn[0])) || !HIP_OK(hipEventCreate((hipEvent_t *)&w->evn[1])) ||
-      !HIP_OK(hipHostMalloc((void **)&w->h_nact, 2 * sizeof(int), hipHostMallocDefault))) {
+      !HIP_OK(hipHostMalloc((void **)&w->h_nact, 2 * RLDL_NACT_SLOTS * sizeof(int), hipHostMallocDefault))) {
     osqp_batch_cleanup(w);
     return RLDL_MEM_ALLOC_ERROR;
   }
@@ -304,11 +304,13 @@ static c_int solve_impl(osqp_batch *w, int wait) {
          * instruction, so the one speculative group after everybody has finished costs next to nothing, and the host
          * never stalls the stream between groups. */
         const int slot = (int)(nchecks & 1);
-        if (!HIP_OK(hipMemcpyAsync(&w->h_nact[slot], w->W.n_active, sizeof(int), hipMemcpyDeviceToHost, st))) return 1;
+        if (!HIP_OK(hipMemcpyAsync(&w->h_nact[slot * RLDL_NACT_SLOTS], w->W.n_active, sizeof(int) * RLDL_NACT_SLOTS, hipMemcpyDeviceToHost, st))) return 1;
         (void)hipEventRecord((hipEvent_t)w->evn[slot], st);
         if (nchecks > 0) {
           if (!HIP_OK(hipEventSynchronize((hipEvent_t)w->evn[slot ^ 1]))) return 1;
-          if (w->h_nact[slot ^ 1] == 0) break;
+          int left = 0, k;
+          for (k = 0; k < RLDL_NACT_SLOTS; k++) left += w->h_nact[(slot ^ 1) * RLDL_NACT_SLOTS + k];
+          if (left == 0) break;
         }
         nchecks++;
       }

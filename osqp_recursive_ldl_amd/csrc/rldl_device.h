@@ -82,7 +82,7 @@ typedef struct {
   double *pri_res, *dua_res, *obj, *rho_cur, *rho_est; /* [batch] */
   int *status, *iter, *rho_updates;                    /* [batch] */
   int *refactor;                                       /* [batch] mask written by the adapt-rho step */
-  int *n_active;                                       /* [1] instances still iterating */
+  int *n_active;                                       /* [RLDL_NACT_SLOTS] instances still iterating, counted per slot inst % RLDL_NACT_SLOTS (one counter would serialise the batch's atomics in L2) */
   int write_delta;                                     /* 1: this iteration also stores delta_x / delta_y (a check follows) */
   /* polish (src/polish.c): masked copy of A (inactive rows zeroed), rhs / solution / refinement vectors [batch][n+m] */
   double *pol_Ax, *pol_b, *pol_z, *pol_r;
@@ -98,6 +98,7 @@ typedef struct {
 /* shared-memory footprint (bytes) of the LDS-resident variants; the launchers pick the global-memory
  * variant by themselves when this exceeds RLDL_LDS_LIMIT */
 #define RLDL_LDS_LIMIT (64 * 1024)
+#define RLDL_NACT_SLOTS 64
 
 int rldl_launch_kkt_assemble(const rldl_dev_sym *S, const rldl_dev_num *Nn, const double *d_Px, const double *d_Ax,
                              const double *d_rho_vec, int set_sigma_only, const int *d_mask, void *stream);

@@ -32,7 +32,7 @@ struct osqp_batch {
   void *stream;
   void *ev0, *ev1;
   void *evn[2];                  /* events behind the asynchronous reads of the active-instance counter */
-  int *h_nact;                   /* [2] pinned */
+  int *h_nact;                   /* [2][RLDL_NACT_SLOTS] pinned */
   int *h_tmp_i;                  /* [batch] host scratch */
   double *h_tmp_d;               /* [batch] host scratch */
   int loop_pending;              /* a solve loop was enqueued and its event pair not read yet */

@@ -334,36 +334,42 @@ __device__ __forceinline__ void spmv_Psym(const rldl_dev_sym &S, const double *P
 // leave the wave waiting on memory for every one of them).  One pass per matrix in storage order -- coalesced value loads,
 // one table word (row | col << 16) per entry, four rounds of loads in flight; lanes that hit the same destination (the
 // entries of one column) are serialised by the LDS unit, which costs a few cycles against the microseconds saved.
-#define FLAT_U 4
+#define FLAT_U 16                       // rounds of loads in flight: 1024 entries per batch (the metric shape needs one batch per matrix)
+struct FlatBatch { unsigned rc[FLAT_U]; double v[FLAT_U]; };
+__device__ __forceinline__ void flat_load(const unsigned *__restrict__ tab, const double *__restrict__ val, int nnz, int p0, FlatBatch &B, int lane) {
+#pragma unroll
+  for (int u = 0; u < FLAT_U; u++)
+    if (p0 + u * WAVE < nnz) {                                   // uniform
+      const int p = min(p0 + u * WAVE + lane, nnz - 1);
+      B.rc[u] = tab[p]; B.v[u] = val[p];
+    }
+}
 __device__ __forceinline__ void spmv3_flat(const rldl_dev_sym &S, const double *__restrict__ Pg, const double *__restrict__ Ag,
                                            const double *vx, const double *vy, double *vAx, double *vPx, double *vAty, int lane) {
+  FlatBatch A, P;
+  flat_load(S.Afl, Ag, S.nnzA, 0, A, lane);                      // both first batches are on their way before anything waits
+  flat_load(S.Pfl, Pg, S.nnzP, 0, P, lane);
   for (int i = lane; i < S.m; i += WAVE) vAx[i] = 0.0;
   for (int i = lane; i < S.n; i += WAVE) { vPx[i] = 0.0; vAty[i] = 0.0; }
   __syncthreads();
   for (int p0 = 0; p0 < S.nnzA; p0 += FLAT_U * WAVE) {           // A x and A' y (mat_vec / mat_tpose_vec, lin_alg.c:241-322)
-    unsigned rc[FLAT_U];
-    double a[FLAT_U];
-#pragma unroll
-    for (int u = 0; u < FLAT_U; u++) { const int p = min(p0 + u * WAVE + lane, S.nnzA - 1); rc[u] = S.Afl[p]; a[u] = Ag[p]; }
+    if (p0) flat_load(S.Afl, Ag, S.nnzA, p0, A, lane);
 #pragma unroll
     for (int u = 0; u < FLAT_U; u++)
       if (p0 + u * WAVE + lane < S.nnzA) {
-        const unsigned r = rc[u] & 0xffffu, c = rc[u] >> 16;
-        unsafeAtomicAdd(&vAx[r], a[u] * vx[c]);
-        unsafeAtomicAdd(&vAty[c], a[u] * vy[r]);
+        const unsigned r = A.rc[u] & 0xffffu, c = A.rc[u] >> 16;
+        unsafeAtomicAdd(&vAx[r], A.v[u] * vx[c]);
+        unsafeAtomicAdd(&vAty[c], A.v[u] * vy[r]);
       }
   }
   for (int p0 = 0; p0 < S.nnzP; p0 += FLAT_U * WAVE) {           // P upper-tri: P x + P' x without the diagonal twice (auxil.c:299-303)
-    unsigned rc[FLAT_U];
-    double v[FLAT_U];
-#pragma unroll
-    for (int u = 0; u < FLAT_U; u++) { const int p = min(p0 + u * WAVE + lane, S.nnzP - 1); rc[u] = S.Pfl[p]; v[u] = Pg[p]; }
+    if (p0) flat_load(S.Pfl, Pg, S.nnzP, p0, P, lane);
 #pragma unroll
     for (int u = 0; u < FLAT_U; u++)
       if (p0 + u * WAVE + lane < S.nnzP) {
-        const unsigned r = rc[u] & 0xffffu, c = rc[u] >> 16;
-        unsafeAtomicAdd(&vPx[r], v[u] * vx[c]);
-        if (r != c) unsafeAtomicAdd(&vPx[c], v[u] * vx[r]);
+        const unsigned r = P.rc[u] & 0xffffu, c = P.rc[u] >> 16;
+        unsafeAtomicAdd(&vPx[r], P.v[u] * vx[c]);
+        if (r != c) unsafeAtomicAdd(&vPx[c], P.v[u] * vx[r]);
       }
   }
 }
@@ -524,7 +530,7 @@ __global__ __launch_bounds__(WAVE) void k_admm_check(rldl_dev_sym S, rldl_dev_ad
   if (active && st != ST_UNSOLVED && lane == 0) {
     W.status[inst] = st;
     if (have_special) W.obj[inst] = obj_special;
-    atomicSub(W.n_active, 1);
+    if (!(mode & CHK_FINAL)) atomicSub(&W.n_active[inst & (RLDL_NACT_SLOTS - 1)], 1);   // (nobody reads the counters after the last pass)
   }
   if (active && (st == ST_DUAL_INFEASIBLE || st == ST_DUAL_INFEASIBLE_INACCURATE))
     for (int i = lane; i < n; i += WAVE) dxg[i] = vdx[i];
@@ -2419,7 +2425,8 @@ __global__ __launch_bounds__(256) void k_solve_begin(rldl_dev_admm W, int n, int
   if (threadIdx.x == 0) {
     W.status[inst] = ST_UNSOLVED;
     if (reset_rho_updates) W.rho_updates[inst] = 0;
-    if (inst == 0) *W.n_active = W.batch;
+    if (inst < RLDL_NACT_SLOTS) W.n_active[inst] = (W.batch - inst + RLDL_NACT_SLOTS - 1) / RLDL_NACT_SLOTS;   // instances inst, inst + SLOTS, ...
+    for (int s = W.batch + inst; s < RLDL_NACT_SLOTS; s += W.batch) W.n_active[s] = 0;                          // batch < SLOTS
   }
   if (cold) {
     for (int i = threadIdx.x; i < n; i += blockDim.x) W.x[(size_t)inst * n + i] = 0.0;
