@@ -6,12 +6,13 @@
  * permutation of compute_permutations :1350-1362, caches the per-stage pivots (X_even[], :1206/:1252)
  * and LDL_update_from_pivot :946-1110 restarts the recursion at a stage instead of refactorising.
  *
- * What this build does (round 1): the SAME permutation (bit-exact integers) is handed to the batched
- * sparse backend, whose right-looking device factorisation can RESTART at any column: the columns of
- * stages < first_stage keep their L and D, their contributions to the trailing part are replayed
- * from the stored factor, and only stages >= first_stage are eliminated again.  This reproduces the
- * reference's "continue from the saved pivot" semantics without the X_even cache.  Dense per-stage
- * block kernels (the MFMA candidate of SURVEY.md 8a-15) are the planned next step.
+ * What this build does: the SAME permutation (bit-exact integers) goes to the batched backend together with a dense
+ * stage-block view of the permuted matrix and of its factor (build_stage_maps / build_solve_tiles below).  The numeric
+ * factorisation (k_stage_factor_r) and the tri-solve (stage_tri_solve) then run the block recursion itself -- Schur
+ * complement of the previous block, dense LDL' of the block, coupling block -- on one wavefront per instance, and a
+ * restart keeps the blocks before the first modified stage: the reference's "continue from the saved pivot" without the
+ * X_even cache (L(b, b-1) and D_{b-1} are read back from the factor).  Patterns that do not qualify (blocks wider than
+ * 32, not block tridiagonal) stay on the generic sparse kernels, which restart at a column.
  */
 #include <hip/hip_runtime_api.h>
 #include <stdlib.h>
