@@ -34,8 +34,8 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICR
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=4096, help="instances per GPU")
     ap.add_argument("--iters", type=int, default=200, help="ADMM iterations per solve")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -159,10 +159,10 @@ def main():
     # HBM traffic of the same kernel comes from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE cannot
     # be read from inside the process); it is reported only when it was measured on this very configuration
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_v9_pmc_traffic.json")))
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_v12_pmc_traffic.json")))
         if B == 4096 and pmc.get("algorithmic_bytes_per_launch") == iter_bytes * B * iters_per_launch:
             out["roofline"]["traffic"] = pmc["traffic_bytes_per_launch"]
-            out["roofline"]["traffic_source"] = "profiles/r1_v9_pmc_traffic.json (rocprofv3 --pmc, separate passes)"
+            out["roofline"]["traffic_source"] = "profiles/r1_v12_pmc_traffic.json (rocprofv3 --pmc, separate passes)"
     except (OSError, ValueError):
         pass
     status = res["status"]
