@@ -1697,9 +1697,19 @@ __global__ __launch_bounds__(WAVE) void k_arrow_factor(rldl_dev_sym S, rldl_dev_
   double *Wd = sh + S.nnzL, *dih = sh + nW, *colj = dih + ((g0 + 1) & ~1);
   double *F = Nn.F + (size_t)inst * S.ldF, *Dg = Nn.D + (size_t)inst * S.N;
   const double *K = Nn.Kx + (size_t)inst * S.nnzK;
+  // Every loop below that reads an index table from global memory takes FB rounds at a time: the FB index loads (and the
+  // value loads that do not depend on them) are in flight together instead of one memory round trip per round.
+  constexpr int FB = 8;
   for (int i = lane; i < nW; i += WAVE) sh[i] = 0.0;
   wave_sync();
-  for (int k = lane; k < S.nnzK; k += WAVE) sh[S.KtoW[k]] = K[k];
+  for (int k0 = 0; k0 < S.nnzK; k0 += FB * WAVE) {
+    int ix[FB];
+    double v[FB];
+#pragma unroll
+    for (int u = 0; u < FB; u++) { const int k = min(k0 + u * WAVE + lane, S.nnzK - 1); ix[u] = S.KtoW[k]; v[u] = K[k]; }
+#pragma unroll
+    for (int u = 0; u < FB; u++) if (k0 + u * WAVE + lane < S.nnzK) sh[ix[u]] = v[u];
+  }
   wave_sync();
   int npos = 0, zero = 0;
   for (int j = lane; j < g0; j += WAVE) {                        // head pivots are final as they come
@@ -1710,15 +1720,22 @@ __global__ __launch_bounds__(WAVE) void k_arrow_factor(rldl_dev_sym S, rldl_dev_
   }
   wave_sync();
   // head: every pair (a, b) of column j adds -l_a l_b d_j to a tail entry; columns are independent -> no barrier, atomics
-#pragma unroll 4
-  for (int t = lane; t < S.arrow_npairs; t += WAVE) {            // flat over all head columns: independent iterations
-    const unsigned ab = S.arrow_pab[t], dc = S.arrow_pdc[t];
-    unsafeAtomicAdd(&sh[dc & 0xffffu], -(sh[ab & 0xffffu] * (sh[ab >> 16] * dih[dc >> 16])));
+  for (int t0 = 0; t0 < S.arrow_npairs; t0 += FB * WAVE) {       // flat over all head columns: independent iterations
+    unsigned ab[FB], dc[FB];
+#pragma unroll
+    for (int u = 0; u < FB; u++) { const int t = min(t0 + u * WAVE + lane, S.arrow_npairs - 1); ab[u] = S.arrow_pab[t]; dc[u] = S.arrow_pdc[t]; }
+#pragma unroll
+    for (int u = 0; u < FB; u++)
+      if (t0 + u * WAVE + lane < S.arrow_npairs)
+        unsafeAtomicAdd(&sh[dc[u] & 0xffffu], -(sh[ab[u] & 0xffffu] * (sh[ab[u] >> 16] * dih[dc[u] >> 16])));
   }
   wave_sync();
-  for (int q = lane; q < S.nnzL; q += WAVE) {                    // l_rc = K_rc / d_c for the head columns (row-order walk: column known)
-    const int c = S.Rj[q];
-    if (c < g0) sh[S.Rpos[q]] *= dih[c];
+  for (int q0 = 0; q0 < S.nnzL; q0 += FB * WAVE) {               // l_rc = K_rc / d_c for the head columns (row-order walk: column known)
+    int c[FB], rp[FB];
+#pragma unroll
+    for (int u = 0; u < FB; u++) { const int q = min(q0 + u * WAVE + lane, S.nnzL - 1); c[u] = S.Rj[q]; rp[u] = S.Rpos[q]; }
+#pragma unroll
+    for (int u = 0; u < FB; u++) if (q0 + u * WAVE + lane < S.nnzL && c[u] < g0) sh[rp[u]] *= dih[c[u]];
   }
   // tail: Schur complement -> registers, row per lane; positions from the [g][64] table (-1: structural zero / c >= r)
   double w[SM];
@@ -1759,7 +1776,13 @@ __global__ __launch_bounds__(WAVE) void k_arrow_factor(rldl_dev_sym S, rldl_dev_
     }
   }
   wave_sync();
-  for (int i = lane; i < S.nnzL; i += WAVE) F[S.LtoS[i]] = sh[i];
+  for (int i0 = 0; i0 < S.nnzL; i0 += FB * WAVE) {
+    int sl[FB];
+#pragma unroll
+    for (int u = 0; u < FB; u++) sl[u] = S.LtoS[min(i0 + u * WAVE + lane, S.nnzL - 1)];
+#pragma unroll
+    for (int u = 0; u < FB; u++) { const int ii = i0 + u * WAVE + lane; if (ii < S.nnzL) F[sl[u]] = sh[ii]; }
+  }
   for (int j = lane; j < S.N; j += WAVE) { const double d = Wd[j]; Dg[j] = d; F[S.nS + j] = 1.0 / d; }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { npos += __shfl_xor(npos, o); zero |= __shfl_xor(zero, o); }
