@@ -50,7 +50,7 @@ struct osqp_horizon {
   double **nomP, **nomA;         /* [Nmax + 1] device copies of the nominal P / A values of that horizon (one row) */
   signed char *prefix_ok;        /* [(Nmax + 1)^2] do the L patterns of two horizons agree on the shared blocks? -1 = not looked at */
   double *xs, *ys;               /* [batch][n(Nmax)], [batch][m(Nmax)] staging for the mapped iterates */
-  int *b0v, *n_reused;           /* [batch] first block of the restart per instance; [1] counter */
+  int *b0v, *n_reused;           /* [batch] first block of the restart per instance; [RLDL_NACT_SLOTS] counters */
   int *h_reused;                 /* pinned */
   c_int last_pivot, last_reused, last_created;
 };
@@ -138,8 +138,8 @@ c_int osqp_horizon_setup(osqp_horizon **hp, c_int batch, const rldl_stage_dims *
   nmax = (size_t)(Nmax * (dims->nx + dims->nu)); mmax = (size_t)(Nmax * (dims->nx + dims->ny) + dims->nt);
   if (!HIP_OK(hipMalloc((void **)&h->xs, sizeof(double) * (size_t)batch * nmax + 8)) ||
       !HIP_OK(hipMalloc((void **)&h->ys, sizeof(double) * (size_t)batch * mmax + 8)) ||
-      !HIP_OK(hipMalloc((void **)&h->b0v, sizeof(int) * (size_t)batch)) || !HIP_OK(hipMalloc((void **)&h->n_reused, sizeof(int))) ||
-      !HIP_OK(hipHostMalloc((void **)&h->h_reused, sizeof(int), hipHostMallocDefault))) {
+      !HIP_OK(hipMalloc((void **)&h->b0v, sizeof(int) * (size_t)batch)) || !HIP_OK(hipMalloc((void **)&h->n_reused, sizeof(int) * RLDL_NACT_SLOTS)) ||
+      !HIP_OK(hipHostMalloc((void **)&h->h_reused, sizeof(int) * RLDL_NACT_SLOTS, hipHostMallocDefault))) {
     osqp_horizon_free(h);
     return RLDL_MEM_ALLOC_ERROR;
   }
@@ -220,15 +220,15 @@ c_int osqp_horizon_update(osqp_horizon *h, c_int Nnew, const c_float *d_q, const
   adopt = !w->st.scaling && w->ls->dsym.stage.nb > 0 && o->ls->dsym.stage.nb > 0 && !getenv("RLDL_NO_STAGE_FACTOR") &&
           !getenv("RLDL_HORIZON_FULL") && prefix_agrees(h, h->N, Nnew, c0);
   if (adopt) {
-    (void)hipMemsetAsync(h->n_reused, 0, sizeof(int), st);
+    (void)hipMemsetAsync(h->n_reused, 0, sizeof(int) * RLDL_NACT_SLOTS, st);
     if (rldl_launch_horizon_adopt(&o->ls->dsym, &o->ls->num, &w->ls->dsym, &w->ls->num, o->W.rho_vec, w->W.rho_vec, (int)m_keep, c0,
                                   (int)(2 * p), h->b0v, h->n_reused, w->stream))
       return 1;
     if (rldl_launch_stage_factor_each(&w->ls->dsym, &w->ls->num, h->b0v, w->stream)) return 1;
-    if (!HIP_OK(hipMemcpyAsync(h->h_reused, h->n_reused, sizeof(int), hipMemcpyDeviceToHost, st))) return 1;
+    if (!HIP_OK(hipMemcpyAsync(h->h_reused, h->n_reused, sizeof(int) * RLDL_NACT_SLOTS, hipMemcpyDeviceToHost, st))) return 1;
   } else if (rldl_launch_factor(&w->ls->dsym, &w->ls->num, 0, w->stream)) return 1;
   if (rldl_batch_check_status(w->ls)) return RLDL_NONCVX_ERROR;   /* synchronises the stream */
-  if (adopt) h->last_reused = *h->h_reused;
+  if (adopt) { int k; for (k = 0; k < RLDL_NACT_SLOTS; k++) h->last_reused += h->h_reused[k]; }
   (void)hipMemsetAsync(w->W.refactor, 0, sizeof(int) * B, st);
 
   if (o->st.warm_start) {

@@ -71,22 +71,35 @@ __global__ __launch_bounds__(256) void k_kkt_assemble(rldl_dev_sym S, rldl_dev_n
   const int inst = blockIdx.x;
   if (mask && !mask[inst]) return;
   double *K = Nn.Kx + (size_t)inst * S.nnzK;
+  // four rounds of loads (value, slot, diagonal flag) in flight per thread before the first store
   if (Px) {                                                      // keepP / keepA: the caller's own copy of the values is written on the way
     const double *p = Px + (size_t)inst * S.nnzP;
     double *kp = keepP ? keepP + (size_t)inst * S.nnzP : nullptr;
-    for (int i = threadIdx.x; i < S.nnzP; i += blockDim.x) {
-      const double v = p[i];
-      K[S.PtoK[i]] = v + (S.Pisdiag[i] ? Nn.sigma : 0.0);
-      if (kp) kp[i] = v;
+    for (int i0 = 0; i0 < S.nnzP; i0 += 4 * blockDim.x) {
+      double v[4];
+      int k[4], dg[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) { const int i = min(i0 + u * (int)blockDim.x + (int)threadIdx.x, S.nnzP - 1); v[u] = p[i]; k[u] = S.PtoK[i]; dg[u] = S.Pisdiag[i]; }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int i = i0 + u * (int)blockDim.x + (int)threadIdx.x;
+        if (i < S.nnzP) { K[k[u]] = v[u] + (dg[u] ? Nn.sigma : 0.0); if (kp) kp[i] = v[u]; }
+      }
     }
   }
   if (Ax) {
     const double *a = Ax + (size_t)inst * S.nnzA;
     double *ka = keepA ? keepA + (size_t)inst * S.nnzA : nullptr;
-    for (int i = threadIdx.x; i < S.nnzA; i += blockDim.x) {
-      const double v = a[i];
-      K[S.AtoK[i]] = v;
-      if (ka) ka[i] = v;
+    for (int i0 = 0; i0 < S.nnzA; i0 += 4 * blockDim.x) {
+      double v[4];
+      int k[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) { const int i = min(i0 + u * (int)blockDim.x + (int)threadIdx.x, S.nnzA - 1); v[u] = a[i]; k[u] = S.AtoK[i]; }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int i = i0 + u * (int)blockDim.x + (int)threadIdx.x;
+        if (i < S.nnzA) { K[k[u]] = v[u]; if (ka) ka[i] = v[u]; }
+      }
     }
   }
   if (set_sigma_only)
@@ -2185,7 +2198,7 @@ __global__ __launch_bounds__(WAVE) void k_horizon_adopt(rldl_dev_sym So, rldl_de
   int differ = No.status[inst] < 0 ? 1 : 0;                      // an old factor with a zero pivot is not adopted
   for (int i = lane; i < m_keep; i += WAVE) differ |= ro[i] != rn[i] ? 1 : 0;
   differ = wave_any(differ);
-  if (lane == 0) { b0v[inst] = differ ? 0 : b_pivot; if (!differ) atomicAdd(n_reused, 1); }
+  if (lane == 0) { b0v[inst] = differ ? 0 : b_pivot; if (!differ) atomicAdd(&n_reused[inst & (RLDL_NACT_SLOTS - 1)], 1); }   // (slots: see rldl_dev_admm.n_active)
   if (differ) return;
   const double *Fo = No.F + (size_t)inst * So.ldF, *Do = No.D + (size_t)inst * So.N;
   double *Fn = Nn.F + (size_t)inst * Sn.ldF, *Dn = Nn.D + (size_t)inst * Sn.N;
