@@ -170,7 +170,11 @@ def test_full_size_mpc_batch_4096_properties():
     f0 = ls.export_factor(4095)["Lx"].copy()
     assert np.array_equal(f0, ls.export_factor(4095 - rep)["Lx"])                        # same data, other batch position
     assert ls.update_from_stage(12, dPx, dAx, None) == 0                                 # restart == what was there
-    assert np.array_equal(ls.export_factor(4095)["Lx"], f0)
+    import os
+    if os.environ.get("RLDL_NO_STAGE_FACTOR"):       # generic kernel: the restart replays the kept columns' updates in another order
+        assert relerr(ls.export_factor(4095)["Lx"], f0) < 1e-11
+    else:
+        assert np.array_equal(ls.export_factor(4095)["Lx"], f0)
     ls.free()
     kw = dict(rho=0.1, sigma=1e-6, alpha=1.6, max_iter=20, check_termination=0, adaptive_rho=0, warm_start=0, scaling=0)
     w19 = R.workloads.MPCStageQPs(N=19)
@@ -179,10 +183,11 @@ def test_full_size_mpc_batch_4096_properties():
     assert hz.workspace.update_P_A(dPx, dAx) == 0
     ra = hz.workspace.solve()
     fa = hz.workspace.linsys().export_factor(2049)
-    assert hz.update(19, q19, l19, u19) == 0 and hz.last_update()["instances_reused"] == B
+    nre = 0 if (os.environ.get("RLDL_HORIZON_FULL") or os.environ.get("RLDL_NO_STAGE_FACTOR")) else B
+    assert hz.update(19, q19, l19, u19) == 0 and hz.last_update()["instances_reused"] == nre
     r19 = hz.workspace.solve()
     assert bool(torch.isfinite(r19["x"]).all()) and (r19["iter"] == 20).all()
-    assert hz.update(20, dev(tile(q)), dev(tile(l)), dev(tile(u))) == 0 and hz.last_update()["instances_reused"] == B
+    assert hz.update(20, dev(tile(q)), dev(tile(l)), dev(tile(u))) == 0 and hz.last_update()["instances_reused"] == nre
     fb = hz.workspace.linsys().export_factor(2049)
     # stages >= 19 are nominal again after the round trip (update_AP_matrices), stages < 19 kept the instance's values
     sym = hz.workspace.linsys().export_symbolic()
