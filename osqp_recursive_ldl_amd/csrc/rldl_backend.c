@@ -42,6 +42,52 @@ int rldl_device_available(void) {
   return count > 0;
 }
 
+/* Deal nnz entries (rows[], cols[]) into rounds of 64 so that no round holds many entries of one target: targets are the rows
+ * and the columns, in one common index space when `same` is set (symmetric use of P: both indices address the same vector).
+ * Greedy: entries of the busiest targets first, each into the round (with a free lane) where its targets are rarest.
+ * Out: rc[rounds * 64], pos[rounds * 64] (0xffffffff = padding); returns rounds, or -1. */
+static int deal_entries(int nnz, const int *rows, const int *cols, int nr, int nc, int same, unsigned **rc_out, unsigned **pos_out) {
+  const int R = (nnz + 63) / 64 > 0 ? (nnz + 63) / 64 : 1;
+  int *cr = (int *)calloc((size_t)(nr + 1) * (size_t)R, sizeof(int)), *cc = same ? 0 : (int *)calloc((size_t)(nc + 1) * (size_t)R, sizeof(int));
+  int *fill = (int *)calloc((size_t)R, sizeof(int)), *deg = (int *)calloc((size_t)(nr + nc + 2), sizeof(int)), *ord = (int *)malloc(sizeof(int) * (size_t)(nnz + 1));
+  unsigned *rc = (unsigned *)malloc(sizeof(unsigned) * (size_t)R * 64), *pos = (unsigned *)malloc(sizeof(unsigned) * (size_t)R * 64);
+  int i, k, rv = -1;
+  if (!cr || (!same && !cc) || !fill || !deg || !ord || !rc || !pos) goto done;
+  if (same) cc = cr;
+  for (i = 0; i < nnz; i++) { deg[rows[i]]++; deg[(same ? 0 : nr) + cols[i]]++; ord[i] = i; }
+  /* insertion sort by decreasing max degree (nnz is a few thousand at most per pattern; stable) */
+  {
+    int *key = (int *)malloc(sizeof(int) * (size_t)(nnz + 1)), maxk = 0, *start;
+    if (!key) goto done;
+    for (i = 0; i < nnz; i++) { const int a = deg[rows[i]], b = deg[(same ? 0 : nr) + cols[i]]; key[i] = a > b ? a : b; if (key[i] > maxk) maxk = key[i]; }
+    start = (int *)calloc((size_t)maxk + 2, sizeof(int));
+    if (!start) { free(key); goto done; }
+    for (i = 0; i < nnz; i++) start[maxk - key[i] + 1]++;                 /* counting sort, descending */
+    for (k = 0; k < maxk + 1; k++) start[k + 1] += start[k];
+    for (i = 0; i < nnz; i++) ord[start[maxk - key[i]]++] = i;
+    free(key); free(start);
+  }
+  for (i = 0; i < R * 64; i++) { rc[i] = 0u; pos[i] = 0xffffffffu; }
+  for (k = 0; k < nnz; k++) {
+    const int e = ord[k], r = rows[e], c = cols[e];
+    int best = -1, bm = 1 << 30, bs = 1 << 30, q;
+    for (q = 0; q < R; q++) {
+      int a, b, m2;
+      if (fill[q] >= 64) continue;
+      a = cr[r * R + q]; b = cc[c * R + q];
+      m2 = a > b ? a : b;
+      if (m2 < bm || (m2 == bm && a + b < bs)) { bm = m2; bs = a + b; best = q; }
+    }
+    rc[best * 64 + fill[best]] = (unsigned)r | ((unsigned)c << 16);
+    pos[best * 64 + fill[best]] = (unsigned)e;
+    fill[best]++; cr[r * R + best]++; if (!same || c != r) cc[c * R + best]++;
+  }
+  *rc_out = rc; *pos_out = pos; rc = 0; pos = 0; rv = R;
+done:
+  free(cr); if (!same) free(cc); free(fill); free(deg); free(ord); free(rc); free(pos);
+  return rv;
+}
+
 static int upload_symbolic(rldl_batch *h) {
   const rldl_symbolic *s = h->sym;
   rldl_dev_sym *D = &h->dsym;
@@ -68,7 +114,31 @@ static int upload_symbolic(rldl_batch *h) {
       }
       D->Pfl = (const unsigned *)dev_upload(pfl, sizeof(unsigned) * (size_t)s->nnzP, &ok);
       D->Afl = (const unsigned *)dev_upload(afl, sizeof(unsigned) * (size_t)s->nnzA, &ok);
-      D->flat_ok = ok && s->nnzP > 0;
+      {
+        int *rw = (int *)malloc(sizeof(int) * (size_t)(s->nnzP + s->nnzA + 2)), *cl = (int *)malloc(sizeof(int) * (size_t)(s->nnzP + s->nnzA + 2));
+        unsigned *brc = 0, *bps = 0;
+        int fine = rw && cl;
+        if (fine) {
+          for (q = 0; q < s->nnzP; q++) { rw[q] = (int)(pfl[q] & 0xffffu); cl[q] = (int)(pfl[q] >> 16); }
+          D->Pbr = deal_entries(s->nnzP, rw, cl, s->n, s->n, 1, &brc, &bps);
+          if (D->Pbr > 0) {
+            D->Pbl = (const unsigned *)dev_upload(brc, sizeof(unsigned) * (size_t)D->Pbr * 64, &ok);
+            D->Pbp = (const unsigned *)dev_upload(bps, sizeof(unsigned) * (size_t)D->Pbr * 64, &ok);
+          } else fine = 0;
+          free(brc); free(bps); brc = bps = 0;
+        }
+        if (fine) {
+          for (q = 0; q < s->nnzA; q++) { rw[q] = (int)(afl[q] & 0xffffu); cl[q] = (int)(afl[q] >> 16); }
+          D->Abr = deal_entries(s->nnzA, rw, cl, s->m, s->n, 0, &brc, &bps);
+          if (D->Abr > 0) {
+            D->Abl = (const unsigned *)dev_upload(brc, sizeof(unsigned) * (size_t)D->Abr * 64, &ok);
+            D->Abp = (const unsigned *)dev_upload(bps, sizeof(unsigned) * (size_t)D->Abr * 64, &ok);
+          } else fine = 0;
+          free(brc); free(bps);
+        }
+        free(rw); free(cl);
+        D->flat_ok = ok && fine && s->nnzP > 0;
+      }
       free(t);
     }
   }
@@ -140,7 +210,7 @@ static void free_dev_symbolic(rldl_dev_sym *D) {
 #define FR(f) if (D->f) (void)hipFree((void *)D->f)
   FR(perm); FR(PtoK); FR(AtoK); FR(rhotoK); FR(sigK); FR(Pisdiag); FR(Lp); FR(Li); FR(Rp); FR(Rj); FR(Rpos);
   FR(KtoW); FR(Udst); FR(Uab); FR(Up); FR(Pp); FR(Pi); FR(Prp); FR(Prj); FR(Prpos); FR(Ap); FR(Ai); FR(Arp);
-  FR(Arj); FR(Arpos); FR(LtoS); FR(Pfl); FR(Afl); FR(plan); FR(arrow_tpos); FR(arrow_pab); FR(arrow_pdc);
+  FR(Arj); FR(Arpos); FR(LtoS); FR(Pfl); FR(Afl); FR(Pbl); FR(Pbp); FR(Abl); FR(Abp); FR(plan); FR(arrow_tpos); FR(arrow_pab); FR(arrow_pdc);
 #undef FR
   memset(D, 0, sizeof(*D));
 }

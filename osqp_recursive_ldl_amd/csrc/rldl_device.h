@@ -38,8 +38,13 @@ typedef struct {
   const unsigned int *Uab;
   const long long *Up;
   const int *Pp, *Pi, *Prp, *Prj, *Prpos, *Ap, *Ai, *Arp, *Arj, *Arpos;
-  /* entry-parallel access for the residual kernel: (row | col << 16) per stored entry of P and A (CSC order); flat_ok = n, m < 65536 */
-  const unsigned *Pfl, *Afl;
+  /* entry-parallel access to P and A: (row | col << 16) per stored entry in CSC order (Pfl, Afl), and a second order for the
+   * kernels that add per-row / per-column contributions with LDS atomics: the entries dealt into rounds of 64 so that a round
+   * holds as few entries of one row or one column as possible (an LDS atomic instruction costs ~6 cycles times the largest
+   * number of lanes on one address).  Pbl/Abl = row | col << 16, Pbp/Abp = CSC position (0xffffffff: padding), Pbr/Abr rounds.
+   * flat_ok = n, m < 65536 */
+  const unsigned *Pfl, *Afl, *Pbl, *Pbp, *Abl, *Abp;
+  int Pbr, Abr;
   int flat_ok;
   /* factor storage layout + grouped solve plan (rldl_plan.c) */
   const int *LtoS;             /* [nnzL] CSC position -> storage slot */

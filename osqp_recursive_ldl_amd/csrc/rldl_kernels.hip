@@ -349,6 +349,8 @@ __device__ __forceinline__ void spmv_Psym(const rldl_dev_sym &S, const double *P
 // entries of one column) are serialised by the LDS unit, which costs a few cycles against the microseconds saved.
 #define FLAT_U 16                       // rounds of loads in flight: 1024 entries per batch (the metric shape needs one batch per matrix)
 struct FlatBatch { unsigned rc[FLAT_U]; double v[FLAT_U]; };
+// (storage order: the value loads are coalesced and do not wait for a table word.  The dealt order of k_scale_data_flat would
+//  make the atomics cheaper but costs a dependent, scattered value load per entry: 58 vs 52 us for this kernel, measured.)
 __device__ __forceinline__ void flat_load(const unsigned *__restrict__ tab, const double *__restrict__ val, int nnz, int p0, FlatBatch &B, int lane) {
 #pragma unroll
   for (int u = 0; u < FLAT_U; u++)
@@ -813,10 +815,20 @@ __global__ __launch_bounds__(WAVE, WPE) void k_scale_data_flat(rldl_dev_sym S, r
   double *Dg = W.sD + (size_t)inst * n, *Dinv = W.sDinv + (size_t)inst * n, *Eg = W.sE + (size_t)inst * m, *Einv = W.sEinv + (size_t)inst * m;
   double vP[PR], vA[AR];
   unsigned rcP[PR], rcA[AR];
+  // padding entries carry 0.0 and point at a slot of their own lane (lane mod n / m), so that they do not pile up on one address
+  const unsigned padP = (unsigned)(lane % n) * 0x10001u, padA = (unsigned)(lane % (m > 0 ? m : 1)) | ((unsigned)(lane % n) << 16);
 #pragma unroll
-  for (int r = 0; r < PR; r++) { const int p = r * WAVE + lane; const unsigned pc = (unsigned)min(p, S.nnzP - 1); rcP[r] = S.Pfl[pc]; vP[r] = p < S.nnzP ? Pg[pc] : 0.0; }
+  for (int r = 0; r < PR; r++) {                                 // dealt order (few entries of a row / column per round), padding: v = 0
+    const unsigned i = (unsigned)(min(r, S.Pbr - 1) * WAVE + lane), ps = S.Pbp[i];
+    const bool on = r < S.Pbr && ps != 0xffffffffu;
+    rcP[r] = on ? S.Pbl[i] : padP; vP[r] = on ? Pg[on ? ps : 0u] : 0.0;
+  }
 #pragma unroll
-  for (int r = 0; r < AR; r++) { const int p = r * WAVE + lane; const unsigned pc = (unsigned)min(p, S.nnzA - 1); rcA[r] = S.Afl[pc]; vA[r] = p < S.nnzA ? Ag[pc] : 0.0; }
+  for (int r = 0; r < AR; r++) {
+    const unsigned i = (unsigned)(min(r, S.Abr - 1) * WAVE + lane), ps = S.Abp[i];
+    const bool on = r < S.Abr && ps != 0xffffffffu;
+    rcA[r] = on ? S.Abl[i] : padA; vA[r] = on ? Ag[on ? ps : 0u] : 0.0;
+  }
   for (int j = lane; j < n; j += WAVE) { q[j] = qg[j]; D[j] = 1.0; }
   for (int i = lane; i < m; i += WAVE) E[i] = 1.0;
   double c = 1.0;
@@ -830,7 +842,7 @@ __global__ __launch_bounds__(WAVE, WPE) void k_scale_data_flat(rldl_dev_sym S, r
     for (int j = lane; j < n; j += WAVE) Dt[j] = 0.0;
     for (int i = lane; i < m; i += WAVE) Et[i] = 0.0;
     __syncthreads();
-    // norms of the columns of [P A'; A 0] (scaling.c:27-42); entries past the end hold 0.0 and change nothing
+    // norms of the columns of [P A'; A 0] (scaling.c:27-42); padding entries hold 0.0 at (0, 0) and change nothing
 #pragma unroll
     for (int r = 0; r < PR; r++) {
       const unsigned ro = rcP[r] & 0xffffu, co = rcP[r] >> 16;
@@ -873,9 +885,11 @@ __global__ __launch_bounds__(WAVE, WPE) void k_scale_data_flat(rldl_dev_sym S, r
   int lane_o = lane;
   asm volatile("" : "+v"(lane_o));                               // (keeps the store addresses from being formed before the loop)
 #pragma unroll
-  for (int r = 0; r < PR; r++) { const int p = r * WAVE + lane_o; if (p < S.nnzP) Pg[(unsigned)p] = vP[r]; }
+  for (int r = 0; r < PR; r++)
+    if (r < S.Pbr) { const unsigned ps = S.Pbp[(unsigned)(r * WAVE + lane_o)]; if (ps != 0xffffffffu) Pg[ps] = vP[r]; }
 #pragma unroll
-  for (int r = 0; r < AR; r++) { const int p = r * WAVE + lane_o; if (p < S.nnzA) Ag[(unsigned)p] = vA[r]; }
+  for (int r = 0; r < AR; r++)
+    if (r < S.Abr) { const unsigned ps = S.Abp[(unsigned)(r * WAVE + lane_o)]; if (ps != 0xffffffffu) Ag[ps] = vA[r]; }
   for (int j = lane; j < n; j += WAVE) { const double d = D[j]; qg[j] = q[j]; Dg[j] = d; Dinv[j] = 1.0 / d; }
   for (int i = lane; i < m; i += WAVE) { const double e = E[i]; Eg[i] = e; Einv[i] = 1.0 / e; l[i] *= e; u[i] *= e; }
   if (lane == 0) { W.sc[inst] = c; W.scinv[inst] = 1.0 / c; }
@@ -2748,7 +2762,7 @@ extern "C" int rldl_launch_scale_data(const rldl_dev_sym *S, const rldl_dev_admm
   if (W->batch <= 0) return 0;
   if (S->flat_ok && S->nnzP > 0 && S->nnzA > 0 && S->nnzP <= 16 * WAVE && S->nnzA <= 16 * WAVE && !getenv("RLDL_SCALE_LOOPS")) {
     const size_t lds = sizeof(double) * (size_t)(4 * S->n + 2 * S->m + 2);   // entries in registers: up to 16 rounds of 64 per matrix
-    const int rounds = ((S->nnzP > S->nnzA ? S->nnzP : S->nnzA) + WAVE - 1) / WAVE;
+    const int rounds = S->Pbr > S->Abr ? S->Pbr : S->Abr;
     const dim3 grid(W->batch), blk(WAVE);
     if (rounds <= 8) hipLaunchKernelGGL((k_scale_data_flat<8, 8, 4>), grid, blk, lds, (hipStream_t)stream, *S, *W, Px, Ax, q, l, u, iters);
     else if (rounds <= 12) hipLaunchKernelGGL((k_scale_data_flat<12, 12, 2>), grid, blk, lds, (hipStream_t)stream, *S, *W, Px, Ax, q, l, u, iters);

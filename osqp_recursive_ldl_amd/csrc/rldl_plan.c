@@ -246,15 +246,73 @@ int rldl_plan_build(rldl_symbolic *s) {
       qsort(pieces, (size_t)np, sizeof(kv), cmp_kv_desc);
       for (l = 0; l < 64; l++) vrow[l] = 0;
       for (t = 0; t < ((vpad + 1) / 2) * 64; t++) { vmap[t] = 0xffffffffu; vcol[t] = 0u; }
-      for (l = 0; l < np; l++) {
-        const int src = pieces[l].idx, r = rows_of[src], e0 = e0_of[src], len = pieces[l].key;
-        vrow[l] = r;
-        for (t = 0; t < len; t++) {
-          const int slot = fsteps_base[f0 + e0 + t] + fpos_of_row[r];
-          const int sh = 16 * (t & 1);
-          vmap[(t >> 1) * 64 + l] = (vmap[(t >> 1) * 64 + l] & ~(0xffffu << sh)) | ((unsigned)slot << sh);
-          vcol[(t >> 1) * 64 + l] |= (unsigned)fcol[slot] << sh;
+      /* Which of its (padded) steps a lane uses for which entry is free, and it decides how the backward pass behaves: there
+       * every step is one LDS atomic add per lane into x[column], and an atomic instruction whose lanes collide on an address
+       * costs ~3 cycles per colliding lane against ~5 cycles for the whole instruction when all addresses differ (measured,
+       * scripts/ubench_ldsatomic.hip).  The entries are therefore placed by a proper edge colouring of the bipartite graph
+       * lanes x columns (Koenig: max degree colours suffice): at every step all active lanes hit different columns.  When a
+       * column has more entries than there are steps the colouring is greedy (fewest collisions). */
+      {
+        int *lane_at = (int *)malloc(sizeof(int) * (size_t)64 * (size_t)vpad);       /* [lane][colour] -> column or -1 */
+        int *col_at = (int *)malloc(sizeof(int) * (size_t)(N + 1) * (size_t)vpad);    /* [column][colour] -> lane or -1 (exact mode) / count (greedy) */
+        int *eslot = (int *)malloc(sizeof(int) * (size_t)64 * (size_t)vpad);          /* [lane][colour] -> factor slot */
+        int *pl = (int *)malloc(sizeof(int) * (size_t)3 * (size_t)(64 * vpad + N + 2));
+        int *cdeg = (int *)calloc((size_t)N + 1, sizeof(int)), maxc = 0, exact;
+        if (!lane_at || !col_at || !eslot || !pl || !cdeg) { free(lane_at); free(col_at); free(eslot); free(pl); free(cdeg); goto out; }
+        for (l = 0; l < np; l++) {
+          const int src = pieces[l].idx, r = rows_of[src], e0 = e0_of[src], len = pieces[l].key;
+          for (t = 0; t < len; t++) { const int c = fcol[fsteps_base[f0 + e0 + t] + fpos_of_row[r]]; if (++cdeg[c] > maxc) maxc = cdeg[c]; }
         }
+        exact = maxc <= vpad;
+        for (t = 0; t < 64 * vpad; t++) { lane_at[t] = -1; eslot[t] = -1; }
+        for (t = 0; t < (N + 1) * vpad; t++) col_at[t] = exact ? -1 : 0;
+        for (l = 0; l < np; l++) {
+          const int src = pieces[l].idx, r = rows_of[src], e0 = e0_of[src], len = pieces[l].key;
+          vrow[l] = r;
+          for (t = 0; t < len; t++) {
+            const int slot = fsteps_base[f0 + e0 + t] + fpos_of_row[r], c = fcol[slot];
+            int a = -1, b = -1, col = -1, k2;
+            for (k2 = 0; k2 < vpad; k2++) if (lane_at[l * vpad + k2] < 0) { a = k2; break; }
+            if (exact) {
+              for (k2 = 0; k2 < vpad; k2++) if (col_at[c * vpad + k2] < 0) { b = k2; break; }
+              if (col_at[c * vpad + a] < 0) col = a;
+              else {                                         /* free colour a at column c: swap a and b along the alternating path */
+                int npth = 0, node = c, side = 0, want = a, k3;
+                for (;;) {
+                  if (side == 0) { const int l2 = col_at[node * vpad + want]; if (l2 < 0) break; pl[3 * npth] = l2; pl[3 * npth + 1] = node; pl[3 * npth + 2] = want; npth++; node = l2; side = 1; }
+                  else { const int c2 = lane_at[node * vpad + want]; if (c2 < 0) break; pl[3 * npth] = node; pl[3 * npth + 1] = c2; pl[3 * npth + 2] = want; npth++; node = c2; side = 0; }
+                  want = want == a ? b : a;
+                }
+                for (k3 = 0; k3 < npth; k3++) {              /* take the path's edges out (remember their slots) ... */
+                  const int pl_l = pl[3 * k3], pl_c = pl[3 * k3 + 1], pc = pl[3 * k3 + 2];
+                  pl[3 * k3 + 2] = pc | (eslot[pl_l * vpad + pc] << 8);
+                  lane_at[pl_l * vpad + pc] = -1; col_at[pl_c * vpad + pc] = -1; eslot[pl_l * vpad + pc] = -1;
+                }
+                for (k3 = 0; k3 < npth; k3++) {              /* ... and put them back with the two colours exchanged */
+                  const int pl_l = pl[3 * k3], pl_c = pl[3 * k3 + 1], pc = pl[3 * k3 + 2] & 0xff, sl = pl[3 * k3 + 2] >> 8;
+                  const int nc = pc == a ? b : a;
+                  lane_at[pl_l * vpad + nc] = pl_c; col_at[pl_c * vpad + nc] = pl_l; eslot[pl_l * vpad + nc] = sl;
+                }
+                col = a;
+              }
+              col_at[c * vpad + col] = l;
+            } else {                                         /* greedy: the lane's free colour with the fewest entries of this column */
+              int best = 1 << 30;
+              for (k2 = 0; k2 < vpad; k2++)
+                if (lane_at[l * vpad + k2] < 0 && col_at[c * vpad + k2] < best) { best = col_at[c * vpad + k2]; col = k2; }
+              col_at[c * vpad + col]++;
+            }
+            lane_at[l * vpad + col] = c; eslot[l * vpad + col] = slot;
+          }
+        }
+        for (l = 0; l < np; l++)
+          for (t = 0; t < vpad; t++) {
+            const int slot = eslot[l * vpad + t], sh = 16 * (t & 1);
+            if (slot < 0) continue;
+            vmap[(t >> 1) * 64 + l] = (vmap[(t >> 1) * 64 + l] & ~(0xffffu << sh)) | ((unsigned)slot << sh);
+            vcol[(t >> 1) * 64 + l] |= (unsigned)fcol[slot] << sh;
+          }
+        free(lane_at); free(col_at); free(eslot); free(pl); free(cdeg);
       }
     }
   }

@@ -220,7 +220,9 @@ def test_solve_plan_schedule_reproduces_the_reference_substitution(case):
 def test_virtual_row_tables_cover_every_coupling_entry_once(case):
     """Arrowhead plans (csrc/rldl_plan.c, "virtual rows"): the coupling rows of the tail group are cut into pieces of
     at most T entries, one piece per lane.  Every out-of-group entry of L must appear exactly once, under its own row,
-    with its own column and storage slot; T is minimal for 64 lanes; the pieces are sorted by length."""
+    with its own column and storage slot; T is minimal for 64 lanes; the pieces are sorted by length; and the entries are
+    placed on the (padded) steps by an edge colouring: at every step the active lanes address different columns, so the
+    LDS atomic adds of the backward pass never collide (whenever no column has more entries than there are steps)."""
     from osqp_recursive_ldl_amd.linsys import plan_export
     wl = R.workloads.SharedPatternQPs() if case == "arrowhead" else R.workloads.SharedPatternQPs(n=20, m=35, density=0.2, pattern_seed=5)
     pl = plan_export(wl.P_pattern, wl.A_pattern)
@@ -228,8 +230,9 @@ def test_virtual_row_tables_cover_every_coupling_entry_once(case):
     if not pl["arrow_ok"]:
         pytest.skip("not an arrowhead plan")
     T, nv = pl["arrow_vsteps"], pl["arrow_vrows"]
+    Tp = next(v for v in (8, 12, 14, 16, 18, 24, (T + 1) & ~1) if T <= v)      # register bound the tables are padded to
     blob = pl["blob"].view(np.uint32)
-    half = (T + 1) // 2
+    half = (Tp + 1) // 2
     vmap = blob[pl["po_avmap"]:pl["po_avmap"] + half * 64].reshape(half, 64)
     vcol = blob[pl["po_avcol"]:pl["po_avcol"] + half * 64].reshape(half, 64)
     vrow = pl["blob"][pl["po_avrow"]:pl["po_avrow"] + 64]
@@ -245,19 +248,25 @@ def test_virtual_row_tables_cover_every_coupling_entry_once(case):
             if g0 <= r < g1 and not (g0 <= c < g1):
                 want[int(pl["LtoS"][p])] = (r, c)
     got, lens = {}, []
+    cols_at_step = [[] for _ in range(Tp)]
     for lane in range(64):
         ln = 0
-        for t in range(T):
+        for t in range(Tp):
             slot = int((vmap[t >> 1, lane] >> (16 * (t & 1))) & 0xffff)
             col = int((vcol[t >> 1, lane] >> (16 * (t & 1))) & 0xffff)
             if slot == 0xffff:
                 assert col == 0
                 continue
-            assert lane < nv and t == ln, "entries of a piece are contiguous from step 0"
+            assert lane < nv
             assert slot not in got
             got[slot] = (int(vrow[lane]), col)
+            cols_at_step[t].append(col)
             ln += 1
+        assert ln <= T
         lens.append(ln)
+    col_deg = np.bincount([c for _, c in want.values()])
+    if col_deg.max() <= Tp:
+        assert all(len(c) == len(set(c)) for c in cols_at_step), "two lanes address the same column in one step"
     assert got == want and len(want) == pl["nO"]
     assert lens == sorted(lens, reverse=True) and all(v > 0 for v in lens[:nv]) and all(v == 0 for v in lens[nv:])
     rows = np.bincount([r - g0 for r, _ in want.values()], minlength=g1 - g0)
