@@ -359,29 +359,33 @@ __device__ __forceinline__ void flat_load(const unsigned *__restrict__ tab, cons
       B.rc[u] = tab[p]; B.v[u] = val[p];
     }
 }
+// which: bit 0 = A x -> vAx, bit 1 = A' y -> vAty, bit 2 = P x -> vPx (uniform; products that are off are left untouched)
 __device__ __forceinline__ void spmv3_flat(const rldl_dev_sym &S, const double *__restrict__ Pg, const double *__restrict__ Ag,
-                                           const double *vx, const double *vy, double *vAx, double *vPx, double *vAty, int lane) {
+                                           const double *vx, const double *vy, double *vAx, double *vPx, double *vAty, int lane,
+                                           int which = 7) {
   FlatBatch A, P;
-  flat_load(S.Afl, Ag, S.nnzA, 0, A, lane);                      // both first batches are on their way before anything waits
-  flat_load(S.Pfl, Pg, S.nnzP, 0, P, lane);
-  for (int i = lane; i < S.m; i += WAVE) vAx[i] = 0.0;
-  for (int i = lane; i < S.n; i += WAVE) { vPx[i] = 0.0; vAty[i] = 0.0; }
+  const int nA = (which & 3) ? S.nnzA : 0, nP = (which & 4) ? S.nnzP : 0;
+  flat_load(S.Afl, Ag, nA, 0, A, lane);                          // both first batches are on their way before anything waits
+  flat_load(S.Pfl, Pg, nP, 0, P, lane);
+  if (which & 1) for (int i = lane; i < S.m; i += WAVE) vAx[i] = 0.0;
+  if (which & 2) for (int i = lane; i < S.n; i += WAVE) vAty[i] = 0.0;
+  if (which & 4) for (int i = lane; i < S.n; i += WAVE) vPx[i] = 0.0;
   __syncthreads();
-  for (int p0 = 0; p0 < S.nnzA; p0 += FLAT_U * WAVE) {           // A x and A' y (mat_vec / mat_tpose_vec, lin_alg.c:241-322)
-    if (p0) flat_load(S.Afl, Ag, S.nnzA, p0, A, lane);
+  for (int p0 = 0; p0 < nA; p0 += FLAT_U * WAVE) {               // A x and A' y (mat_vec / mat_tpose_vec, lin_alg.c:241-322)
+    if (p0) flat_load(S.Afl, Ag, nA, p0, A, lane);
 #pragma unroll
     for (int u = 0; u < FLAT_U; u++)
-      if (p0 + u * WAVE + lane < S.nnzA) {
+      if (p0 + u * WAVE + lane < nA) {
         const unsigned r = A.rc[u] & 0xffffu, c = A.rc[u] >> 16;
-        unsafeAtomicAdd(&vAx[r], A.v[u] * vx[c]);
-        unsafeAtomicAdd(&vAty[c], A.v[u] * vy[r]);
+        if (which & 1) unsafeAtomicAdd(&vAx[r], A.v[u] * vx[c]);
+        if (which & 2) unsafeAtomicAdd(&vAty[c], A.v[u] * vy[r]);
       }
   }
-  for (int p0 = 0; p0 < S.nnzP; p0 += FLAT_U * WAVE) {           // P upper-tri: P x + P' x without the diagonal twice (auxil.c:299-303)
-    if (p0) flat_load(S.Pfl, Pg, S.nnzP, p0, P, lane);
+  for (int p0 = 0; p0 < nP; p0 += FLAT_U * WAVE) {               // P upper-tri: P x + P' x without the diagonal twice (auxil.c:299-303)
+    if (p0) flat_load(S.Pfl, Pg, nP, p0, P, lane);
 #pragma unroll
     for (int u = 0; u < FLAT_U; u++)
-      if (p0 + u * WAVE + lane < S.nnzP) {
+      if (p0 + u * WAVE + lane < nP) {
         const unsigned r = P.rc[u] & 0xffffu, c = P.rc[u] >> 16;
         unsafeAtomicAdd(&vPx[r], P.v[u] * vx[c]);
         if (r != c) unsafeAtomicAdd(&vPx[c], P.v[u] * vx[r]);
@@ -661,9 +665,12 @@ __global__ __launch_bounds__(WAVE) void k_polish_resid(rldl_dev_sym S, rldl_dev_
     if (j < n) zx[j] = v; else zy[j - n] = v;
   }
   __syncthreads();
-  spmv_Psym(S, Pv, zx, t1, lane);
-  spmv_At(S, Ar, zy, t2, lane);
-  spmv_A(S, Ar, zx, t3, lane);
+  if (S.flat_ok) spmv3_flat(S, Pv, Ar, zx, zy, t3, t1, t2, lane);    // entry-parallel (see k_admm_check)
+  else {
+    spmv_Psym(S, Pv, zx, t1, lane);
+    spmv_At(S, Ar, zy, t2, lane);
+    spmv_A(S, Ar, zx, t3, lane);
+  }
   __syncthreads();
   for (int j = lane; j < n; j += WAVE) r[j] = (b[j] - t1[j]) - t2[j];
   for (int i = lane; i < m; i += WAVE) r[n + i] = b[n + i] - t3[i];
@@ -680,7 +687,8 @@ __global__ __launch_bounds__(WAVE) void k_polish_finish(rldl_dev_sym S, rldl_dev
   for (int j = lane; j < n; j += WAVE) px[j] = add_last ? zs[j] + r[j] : zs[j];
   for (int i = lane; i < m; i += WAVE) py[i] = add_last ? zs[n + i] + r[n + i] : zs[n + i];     // rows that are not active carry 0
   __syncthreads();
-  spmv_A(S, Av, px, vAx, lane);                                                     // pol->z = A pol->x
+  if (S.flat_ok) spmv3_flat(S, Pv, Av, px, py, vAx, vPx, vAty, lane, 5);             // pol->z = A pol->x (and P x, which needs px only)
+  else spmv_A(S, Av, px, vAx, lane);
   __syncthreads();
   for (int i = lane; i < m; i += WAVE) {                                            // project_normalcone
     const double t = vAx[i] + py[i];
@@ -688,8 +696,11 @@ __global__ __launch_bounds__(WAVE) void k_polish_finish(rldl_dev_sym S, rldl_dev
     pz[i] = zi; py[i] = t - zi;
   }
   __syncthreads();
-  spmv_Psym(S, Pv, px, vPx, lane);
-  spmv_At(S, Av, py, vAty, lane);
+  if (S.flat_ok) spmv3_flat(S, Pv, Av, px, py, vAx, vPx, vAty, lane, 2);             // A' y with the projected y
+  else {
+    spmv_Psym(S, Pv, px, vPx, lane);
+    spmv_At(S, Av, py, vAty, lane);
+  }
   __syncthreads();
   for (int i = lane; i < m; i += WAVE) t_m[i] = vAx[i] - pz[i];
   for (int j = lane; j < n; j += WAVE) t_n[j] = q[j] + vPx[j] + vAty[j];
