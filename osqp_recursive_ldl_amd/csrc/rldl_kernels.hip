@@ -992,6 +992,16 @@ __global__ __launch_bounds__(WAVE) void k_matvec_A(rldl_dev_sym S, rldl_dev_admm
   const int inst = blockIdx.x, lane = threadIdx.x;
   const double *Av = W.Ax + (size_t)inst * S.nnzA, *v = xin + (size_t)inst * S.n;
   double *o = out + (size_t)inst * S.m;
+  if (S.flat_ok) {                                               // entry-parallel through LDS (dynamic LDS: n + m doubles), see k_admm_check
+    extern __shared__ double sh[];
+    double *vx = sh, *vo = sh + S.n;
+    for (int j = lane; j < S.n; j += WAVE) vx[j] = v[j];
+    __syncthreads();
+    spmv3_flat(S, Av, Av, vx, vx, vo, vo, vo, lane, 1);
+    __syncthreads();
+    for (int i = lane; i < S.m; i += WAVE) o[i] = vo[i];
+    return;
+  }
   for (int i = lane; i < S.m; i += WAVE) {
     double acc = 0.0;
     for (int p = S.Arp[i]; p < S.Arp[i + 1]; p++) acc += Av[S.Arpos[p]] * v[S.Arj[p]];
@@ -2815,7 +2825,10 @@ extern "C" int rldl_launch_set_range(int batch, int ld, int start, int cnt, doub
 extern "C" int rldl_launch_matvec_A(const rldl_dev_sym *S, const rldl_dev_admm *W, const double *d_x, double *d_out,
                                     void *stream) {
   if (W->batch <= 0) return 0;
-  hipLaunchKernelGGL(k_matvec_A, dim3(W->batch), dim3(WAVE), 0, (hipStream_t)stream, *S, *W, d_x, d_out);
+  const size_t lds = sizeof(double) * (size_t)(S->n + S->m + 2);
+  rldl_dev_sym Sk = *S;
+  if (lds > 64 * 1024) Sk.flat_ok = 0;                           // vectors too long for LDS: row loops
+  hipLaunchKernelGGL(k_matvec_A, dim3(W->batch), dim3(WAVE), Sk.flat_ok ? lds : 0, (hipStream_t)stream, Sk, *W, d_x, d_out);
   return launch_status();
 }
 
