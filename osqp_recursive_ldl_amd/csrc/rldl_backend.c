@@ -191,6 +191,18 @@ static int upload_symbolic(rldl_batch *h) {
           }
           free(pab); free(pdc);
           if (!D->arrow_pab || !D->arrow_pdc) D->arrow_dense = 0;
+          if (D->arrow_dense) {                                /* write-out table in slot order (coalesced stores) */
+            unsigned *ot = (unsigned *)malloc(sizeof(unsigned) * (size_t)(s->nS + 1));
+            if (ot) {
+              for (p = 0; p < s->nS; p++) ot[p] = 0xffffffffu;
+              for (c = 0; c < s->N; c++)
+                for (p = s->Lp[c]; p < s->Lp[c + 1]; p++)
+                  ot[s->LtoS[p]] = (unsigned)p | ((unsigned)(c < D->arrow_g0 ? c : 0xffff) << 16);
+              D->arrow_out = (const unsigned *)dev_upload(ot, sizeof(unsigned) * (size_t)s->nS, &ok);
+              free(ot);
+            }
+            if (!D->arrow_out) D->arrow_dense = 0;
+          }
         } else D->arrow_dense = 0;
       }
     }
@@ -210,7 +222,7 @@ static void free_dev_symbolic(rldl_dev_sym *D) {
 #define FR(f) if (D->f) (void)hipFree((void *)D->f)
   FR(perm); FR(PtoK); FR(AtoK); FR(rhotoK); FR(sigK); FR(Pisdiag); FR(Lp); FR(Li); FR(Rp); FR(Rj); FR(Rpos);
   FR(KtoW); FR(Udst); FR(Uab); FR(Up); FR(Pp); FR(Pi); FR(Prp); FR(Prj); FR(Prpos); FR(Ap); FR(Ai); FR(Arp);
-  FR(Arj); FR(Arpos); FR(LtoS); FR(Pfl); FR(Afl); FR(Pbl); FR(Pbp); FR(Abl); FR(Abp); FR(plan); FR(arrow_tpos); FR(arrow_pab); FR(arrow_pdc);
+  FR(Arj); FR(Arpos); FR(LtoS); FR(Pfl); FR(Afl); FR(Pbl); FR(Pbp); FR(Abl); FR(Abp); FR(plan); FR(arrow_tpos); FR(arrow_pab); FR(arrow_pdc); FR(arrow_out);
 #undef FR
   memset(D, 0, sizeof(*D));
 }

@@ -62,6 +62,7 @@ typedef struct {
   const int *arrow_tpos;       /* [arrow_g][64]: CSC position of L(g0 + lane, g0 + c), or -1 */
   const unsigned *arrow_pab, *arrow_pdc;  /* head pair updates, flat: posA | posB << 16 and dst | column << 16 (workspace positions) */
   int arrow_npairs;
+  const unsigned *arrow_out;   /* [nS] per factor slot: workspace position | head column << 16 (0xffff: padding slot / tail column): write-out in slot order */
   int arrow_cnt[32];           /* per virtual-row step: number of lanes with an entry (kernarg segment -> scalar loads) */
   rldl_dev_stage stage;        /* stage.nb > 0: block-tridiagonal pattern, numeric factorisation by dense stage blocks */
 } rldl_dev_sym;

@@ -1889,14 +1889,7 @@ __global__ __launch_bounds__(WAVE) void k_arrow_factor(rldl_dev_sym S, rldl_dev_
       if (t0 + u * WAVE + lane < S.arrow_npairs)
         unsafeAtomicAdd(&sh[dc[u] & 0xffffu], -(sh[ab[u] & 0xffffu] * (sh[ab[u] >> 16] * dih[dc[u] >> 16])));
   }
-  wave_sync();
-  for (int q0 = 0; q0 < S.nnzL; q0 += FB * WAVE) {               // l_rc = K_rc / d_c for the head columns (row-order walk: column known)
-    int c[FB], rp[FB];
-#pragma unroll
-    for (int u = 0; u < FB; u++) { const int q = min(q0 + u * WAVE + lane, S.nnzL - 1); c[u] = S.Rj[q]; rp[u] = S.Rpos[q]; }
-#pragma unroll
-    for (int u = 0; u < FB; u++) if (q0 + u * WAVE + lane < S.nnzL && c[u] < g0) sh[rp[u]] *= dih[c[u]];
-  }
+  // (l_rc = K_rc / d_c of the head columns is applied on the way out: nothing below reads the head entries again)
   // tail: Schur complement -> registers, row per lane; positions from the [g][64] table (-1: structural zero / c >= r)
   double w[SM];
   int tp[SM];
@@ -1936,12 +1929,20 @@ __global__ __launch_bounds__(WAVE) void k_arrow_factor(rldl_dev_sym S, rldl_dev_
     }
   }
   wave_sync();
-  for (int i0 = 0; i0 < S.nnzL; i0 += FB * WAVE) {
-    int sl[FB];
+  // write-out in SLOT order: consecutive lanes store consecutive words of the factor row; the table names the workspace position
+  // behind every slot and, for head columns, the column whose 1/d still has to be applied (padding slots are rewritten with 0.0)
+  for (int s0 = 0; s0 < S.nS; s0 += FB * WAVE) {
+    unsigned ot[FB];
 #pragma unroll
-    for (int u = 0; u < FB; u++) sl[u] = S.LtoS[min(i0 + u * WAVE + lane, S.nnzL - 1)];
+    for (int u = 0; u < FB; u++) ot[u] = S.arrow_out[min(s0 + u * WAVE + lane, S.nS - 1)];
 #pragma unroll
-    for (int u = 0; u < FB; u++) { const int ii = i0 + u * WAVE + lane; if (ii < S.nnzL) F[sl[u]] = sh[ii]; }
+    for (int u = 0; u < FB; u++) {
+      const int sl = s0 + u * WAVE + lane;
+      const unsigned pos = ot[u] & 0xffffu, hc = ot[u] >> 16;
+      double v = pos != 0xffffu ? sh[pos] : 0.0;
+      if (hc != 0xffffu) v *= dih[hc];
+      if (sl < S.nS) F[(unsigned)sl] = v;
+    }
   }
   for (int j = lane; j < S.N; j += WAVE) { const double d = Wd[j]; Dg[j] = d; F[S.nS + j] = 1.0 / d; }
 #pragma unroll
