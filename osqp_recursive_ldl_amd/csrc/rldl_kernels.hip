@@ -1730,7 +1730,7 @@ __global__ __launch_bounds__(WAVE) void k_stage_factor(rldl_dev_sym S, rldl_dev_
 // panel; what a lane needs from other rows travels as LDS broadcast reads (one address for all lanes) or v_readlane,
 // so the LDS traffic of the LDS-resident version (which bounds it) drops by an order of magnitude.
 //   Schur   : w[k] -= sum_c (Lc[r][c] d_c) Lc[k][c]      own Lc row in registers, Lc[k][c] broadcast from LDS
-//   column j: d = w[j] of lane j (v_readlane); colj[r] = w[j] / d -> LDS; w[k] -= w[j] colj[k] for k > j (broadcast)
+//   column j: d = w[j] of lane j (v_readlane); l_r = w[j] / d; w[k] -= w[j] l_k for k > j (l_k by v_readlane from lane k)
 // Entries above the diagonal of a row pick up garbage and are never read.  1/d: v_rcp_f64 + 3 Newton steps.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ double recip_nr(double d) {
@@ -1749,8 +1749,8 @@ __global__ __launch_bounds__(WAVE) void k_stage_factor_r(rldl_dev_sym S, rldl_de
   const rldl_dev_stage &G = S.stage;
   const int ld = G.ld, nb = G.nb;
   extern __shared__ double sh[];
-  // T: staging tile of the panel (2 smax rows); Lt: L(b, b-1) as broadcast source (smax rows); colj: pivot column (x2)
-  double *T = sh, *Lt = T + 2 * G.smax * ld, *dprev = Lt + G.smax * ld, *dcur = dprev + ld, *colj = dcur + ld;
+  // T: staging tile of the panel (2 smax rows); Lt: L(b, b-1) as broadcast source (smax rows)
+  double *T = sh, *Lt = T + 2 * G.smax * ld, *dprev = Lt + G.smax * ld, *dcur = dprev + ld;
   const double *Kx = Nn.Kx + (size_t)inst * S.nnzK;
   double *F = Nn.F + (size_t)inst * S.ldF, *Dv = Nn.D + (size_t)inst * S.N;
   double w[SM], lcd[SM];
@@ -1809,12 +1809,9 @@ __global__ __launch_bounds__(WAVE) void k_stage_factor_r(rldl_dev_sym S, rldl_de
         const double dinv = recip_nr(d);
         const double a = w[j];                                   // unscaled W[r][j]
         const double l = a * dinv;
-        double *cj = colj + (j & 1) * 64;                        // two buffers: the next column's writes need no barrier
-        cj[lane] = l;
         if (lane > j) w[j] = l;
-        wave_sync();
 #pragma unroll
-        for (int k = j + 1; k < SM; k++) w[k] = fma(-a, cj[k], w[k]);   // rows <= j only touch their dead upper part; k >= s: unused registers
+        for (int k = j + 1; k < SM; k++) w[k] = fma(-a, readlane_f64(l, k), w[k]);   // pivot column broadcast by v_readlane; rows <= j only touch their dead upper part
       }
     }
     // 4. outputs: rows back to the tile, then D, Dinv, L_bb and L(b+1, b) into the factor's slots
@@ -1854,7 +1851,7 @@ __global__ __launch_bounds__(WAVE) void k_arrow_factor(rldl_dev_sym S, rldl_dev_
   if (mask && !mask[inst]) return;
   extern __shared__ double sh[];                                  // W = [L values, CSC order | D] as in k_factor, then scratch
   const int nW = S.nnzL + S.N, g0 = S.arrow_g0, g = S.arrow_g;
-  double *Wd = sh + S.nnzL, *dih = sh + nW, *colj = dih + ((g0 + 1) & ~1);
+  double *Wd = sh + S.nnzL, *dih = sh + nW;
   double *F = Nn.F + (size_t)inst * S.ldF, *Dg = Nn.D + (size_t)inst * S.N;
   const double *K = Nn.Kx + (size_t)inst * S.nnzK;
   // Every loop below that reads an index table from global memory takes FB rounds at a time: the FB index loads (and the
@@ -1912,12 +1909,10 @@ __global__ __launch_bounds__(WAVE) void k_arrow_factor(rldl_dev_sym S, rldl_dev_
       const double dinv = recip_nr(d);
       const double a = w[j];
       const double l = a * dinv;
-      double *cj = colj + (j & 1) * 64;
-      cj[lane] = lane < g ? l : 0.0;
-      if (lane > j) w[j] = l;
-      wave_sync();
+      const double lv = lane < g ? l : 0.0;                      // pivot column, one entry per lane: broadcast by v_readlane
+      if (lane > j) w[j] = l;                                    // (no LDS round trip per column; the VALUs have room at 2 waves per SIMD)
 #pragma unroll
-      for (int k = j + 1; k < SM; k++) w[k] = fma(-a, cj[k], w[k]);
+      for (int k = j + 1; k < SM; k++) w[k] = fma(-a, readlane_f64(lv, k), w[k]);
     }
   }
   // back to the CSC workspace, then the common coalesced write-out in plan slot order
