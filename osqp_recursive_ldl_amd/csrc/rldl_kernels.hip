@@ -392,6 +392,66 @@ __device__ __forceinline__ void spmv3_flat(const rldl_dev_sym &S, const double *
       }
   }
 }
+// The same products with the entries handed out in CHUNKS: lane t owns the R = ceil(nnz / 64) consecutive stored entries
+// [t R, (t + 1) R).  In storage (CSC) order a chunk lies in one or two columns, so the contributions to the per-column results
+// (A' y, the transposed part of P x) are summed in a register and leave as one or two atomics per lane, and at a given round
+// neighbouring lanes sit in different columns: the atomic instructions no longer pile ~15 lanes on one word (~100 cycles
+// each, see scripts/ubench_ldsatomic.hip).  Needs nnz <= FLAT_U * 64 per matrix; spmv3_flat is the general version.
+__device__ __forceinline__ void chunk_load(const unsigned *__restrict__ tab, const double *__restrict__ val, int nnz, int R, FlatBatch &B, int lane) {
+#pragma unroll
+  for (int u = 0; u < FLAT_U; u++)
+    if (u < R) {                                                 // uniform
+      const unsigned p = (unsigned)min(lane * R + u, nnz - 1);
+      B.rc[u] = tab[p]; B.v[u] = val[p];
+    }
+}
+__device__ __forceinline__ void spmv3_chunk(const rldl_dev_sym &S, const double *__restrict__ Pg, const double *__restrict__ Ag,
+                                            const double *vx, const double *vy, double *vAx, double *vPx, double *vAty, int lane,
+                                            int which = 7) {
+  FlatBatch A, P;
+  const int nA = (which & 3) ? S.nnzA : 0, nP = (which & 4) ? S.nnzP : 0;
+  const int RA = (nA + WAVE - 1) / WAVE, RP = (nP + WAVE - 1) / WAVE;
+  chunk_load(S.Afl, Ag, nA, RA, A, lane);
+  chunk_load(S.Pfl, Pg, nP, RP, P, lane);
+  if (which & 1) for (int i = lane; i < S.m; i += WAVE) vAx[i] = 0.0;
+  if (which & 2) for (int i = lane; i < S.n; i += WAVE) vAty[i] = 0.0;
+  if (which & 4) for (int i = lane; i < S.n; i += WAVE) vPx[i] = 0.0;
+  __syncthreads();
+  {
+    double acc = 0.0;
+    unsigned cur = 0xffffffffu;
+#pragma unroll
+    for (int u = 0; u < FLAT_U; u++)
+      if (u < RA && lane * RA + u < nA) {
+        const unsigned r = A.rc[u] & 0xffffu, c = A.rc[u] >> 16;
+        if (which & 1) unsafeAtomicAdd(&vAx[r], A.v[u] * vx[c]);
+        if (which & 2) {
+          if (c != cur) { if (cur != 0xffffffffu) unsafeAtomicAdd(&vAty[cur], acc); cur = c; acc = 0.0; }
+          acc += A.v[u] * vy[r];
+        }
+      }
+    if ((which & 2) && cur != 0xffffffffu) unsafeAtomicAdd(&vAty[cur], acc);
+  }
+  {
+    double acc = 0.0;
+    unsigned cur = 0xffffffffu;
+#pragma unroll
+    for (int u = 0; u < FLAT_U; u++)
+      if (u < RP && lane * RP + u < nP) {
+        const unsigned r = P.rc[u] & 0xffffu, c = P.rc[u] >> 16;
+        unsafeAtomicAdd(&vPx[r], P.v[u] * vx[c]);
+        if (c != cur) { if (cur != 0xffffffffu) unsafeAtomicAdd(&vPx[cur], acc); cur = c; acc = 0.0; }
+        if (r != c) acc += P.v[u] * vx[r];
+      }
+    if (cur != 0xffffffffu) unsafeAtomicAdd(&vPx[cur], acc);
+  }
+}
+__device__ __forceinline__ void spmv3_auto(const rldl_dev_sym &S, const double *__restrict__ Pg, const double *__restrict__ Ag,
+                                           const double *vx, const double *vy, double *vAx, double *vPx, double *vAty, int lane,
+                                           int which = 7) {
+  if (S.nnzA <= FLAT_U * WAVE && S.nnzP <= FLAT_U * WAVE) spmv3_chunk(S, Pg, Ag, vx, vy, vAx, vPx, vAty, lane, which);
+  else spmv3_flat(S, Pg, Ag, vx, vy, vAx, vPx, vAty, lane, which);
+}
 // scaled infinity norm max_i |s_i v_i| (s == nullptr: plain norm)
 __device__ __forceinline__ double norm_inf_s(const double *s, const double *v, int len, int lane) {
   double mx = 0.0;
@@ -456,7 +516,7 @@ __device__ __forceinline__ int dual_infeasible(const rldl_dev_sym &S, const doub
 // STAGED: the instance's P and A values are copied to LDS first (coalesced), so the three SpMVs of update_info and
 // the ones of the infeasibility tests walk LDS instead of issuing dependent global loads entry by entry.
 template <bool STAGED>
-__global__ __launch_bounds__(WAVE) void k_admm_check(rldl_dev_sym S, rldl_dev_admm W, int iter, int mode) {
+__global__ __launch_bounds__(WAVE, 4) void k_admm_check(rldl_dev_sym S, rldl_dev_admm W, int iter, int mode) {
   const int inst = blockIdx.x, lane = threadIdx.x;
   const int n = S.n, m = S.m;
   extern __shared__ double sh[];
@@ -487,7 +547,7 @@ __global__ __launch_bounds__(WAVE) void k_admm_check(rldl_dev_sym S, rldl_dev_ad
   __syncthreads();
 
   // update_info (auxil.c:567-626): residuals
-  if (!STAGED && S.flat_ok) spmv3_flat(S, Pg, Ag, vx, vy, vAx, vPx, vAty, lane);
+  if (!STAGED && S.flat_ok) spmv3_auto(S, Pg, Ag, vx, vy, vAx, vPx, vAty, lane);
   else {
     spmv_A(S, Av, vx, vAx, lane);
     spmv_Psym(S, Pv, vx, vPx, lane);
@@ -665,7 +725,7 @@ __global__ __launch_bounds__(WAVE) void k_polish_resid(rldl_dev_sym S, rldl_dev_
     if (j < n) zx[j] = v; else zy[j - n] = v;
   }
   __syncthreads();
-  if (S.flat_ok) spmv3_flat(S, Pv, Ar, zx, zy, t3, t1, t2, lane);    // entry-parallel (see k_admm_check)
+  if (S.flat_ok) spmv3_auto(S, Pv, Ar, zx, zy, t3, t1, t2, lane);    // entry-parallel (see k_admm_check)
   else {
     spmv_Psym(S, Pv, zx, t1, lane);
     spmv_At(S, Ar, zy, t2, lane);
@@ -687,7 +747,7 @@ __global__ __launch_bounds__(WAVE) void k_polish_finish(rldl_dev_sym S, rldl_dev
   for (int j = lane; j < n; j += WAVE) px[j] = add_last ? zs[j] + r[j] : zs[j];
   for (int i = lane; i < m; i += WAVE) py[i] = add_last ? zs[n + i] + r[n + i] : zs[n + i];     // rows that are not active carry 0
   __syncthreads();
-  if (S.flat_ok) spmv3_flat(S, Pv, Av, px, py, vAx, vPx, vAty, lane, 5);             // pol->z = A pol->x (and P x, which needs px only)
+  if (S.flat_ok) spmv3_auto(S, Pv, Av, px, py, vAx, vPx, vAty, lane, 5);             // pol->z = A pol->x (and P x, which needs px only)
   else spmv_A(S, Av, px, vAx, lane);
   __syncthreads();
   for (int i = lane; i < m; i += WAVE) {                                            // project_normalcone
@@ -696,7 +756,7 @@ __global__ __launch_bounds__(WAVE) void k_polish_finish(rldl_dev_sym S, rldl_dev
     pz[i] = zi; py[i] = t - zi;
   }
   __syncthreads();
-  if (S.flat_ok) spmv3_flat(S, Pv, Av, px, py, vAx, vPx, vAty, lane, 2);             // A' y with the projected y
+  if (S.flat_ok) spmv3_auto(S, Pv, Av, px, py, vAx, vPx, vAty, lane, 2);             // A' y with the projected y
   else {
     spmv_Psym(S, Pv, px, vPx, lane);
     spmv_At(S, Av, py, vAty, lane);
@@ -997,7 +1057,7 @@ __global__ __launch_bounds__(WAVE) void k_matvec_A(rldl_dev_sym S, rldl_dev_admm
     double *vx = sh, *vo = sh + S.n;
     for (int j = lane; j < S.n; j += WAVE) vx[j] = v[j];
     __syncthreads();
-    spmv3_flat(S, Av, Av, vx, vx, vo, vo, vo, lane, 1);
+    spmv3_auto(S, Av, Av, vx, vx, vo, vo, vo, lane, 1);
     __syncthreads();
     for (int i = lane; i < S.m; i += WAVE) o[i] = vo[i];
     return;
