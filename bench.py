@@ -159,10 +159,10 @@ def main():
     # HBM traffic of the same kernel comes from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE cannot
     # be read from inside the process); it is reported only when it was measured on this very configuration
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_v13_pmc_traffic.json")))
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_v14_pmc_traffic.json")))
         if B == 4096 and pmc.get("algorithmic_bytes_per_launch") == iter_bytes * B * iters_per_launch:
             out["roofline"]["traffic"] = pmc["traffic_bytes_per_launch"]
-            out["roofline"]["traffic_source"] = "profiles/r1_v13_pmc_traffic.json (rocprofv3 --pmc, separate passes)"
+            out["roofline"]["traffic_source"] = "profiles/r1_v14_pmc_traffic.json (rocprofv3 --pmc, separate passes)"
     except (OSError, ValueError):
         pass
     status = res["status"]
