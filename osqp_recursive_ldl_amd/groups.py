@@ -46,6 +46,9 @@ class OSQPBatchGroups:
                 raise RuntimeError("setup of a pattern group failed (%d)" % w.status)
             self.groups.append((torch.as_tensor(np.asarray(idx), device=dev), w))
         self._dev = dev
+        # position of every original instance in the concatenation of the groups' result arrays
+        order = np.concatenate([np.asarray(idx) for idx in buckets.values()])
+        self._inv = torch.as_tensor(np.argsort(order, kind="stable"), device=dev)
 
     @property
     def n_patterns(self):
@@ -56,14 +59,9 @@ class OSQPBatchGroups:
         import torch
         for _, w in self.groups:
             w.solve_async()
-        parts = [(idx, w.wait(clone=False)) for idx, w in self.groups]
-        out = {}
-        for key, ref in parts[0][1].items():
-            full = torch.empty((self.count,) + tuple(ref.shape[1:]), dtype=ref.dtype, device=self._dev)
-            for idx, res in parts:
-                full[idx] = res[key]
-            out[key] = full
-        return out
+        parts = [w.wait(clone=False) for _, w in self.groups]
+        # one concatenation + one gather per result field (not one indexed copy per field and group)
+        return {key: torch.cat([res[key] for res in parts], 0)[self._inv] for key in parts[0]}
 
     def cleanup(self):
         for _, w in self.groups:
