@@ -108,7 +108,8 @@ void rldl_batch_free(rldl_batch *h);
 c_int rldl_symbolic_analyze(const csc *P, const csc *A, c_int polish, const c_int *perm_in, c_int *nnzKKT,
                             c_int *nnzL, c_int *etree_height, c_int *perm, c_int *etree, c_int *Lnz, c_int *Lp,
                             c_int *Li, c_int *KKTp, c_int *KKTi, c_int *PtoKKT, c_int *AtoKKT, c_int *rhotoKKT);
-/* Host-only export of the grouped triangular-solve plan (rldl_plan.c) for inspection / CPU emulation in tests. */
+/* Host-only export of the grouped triangular-solve plan (rldl_plan.c) for inspection / CPU emulation in tests.
+ * meta: 48 entries (layout: csrc/rldl_backend.c). */
 c_int rldl_plan_export(const csc *P, const csc *A, c_int polish, const c_int *perm_in, c_int *meta, int *blob, c_int blob_cap,
                        c_int *LtoS);
 /* closed-form stage-interleaved permutation, compute_permutations src/recursive_ldl.c:1350-1362 */

@@ -152,6 +152,12 @@ static int upload_symbolic(rldl_batch *h) {
   D->po_perm = s->po_perm; D->po_avmap = s->po_avmap; D->po_avcol = s->po_avcol; D->po_avrow = s->po_avrow; D->nOp = s->nOp;
   D->arrow_ok = s->plan_ok ? s->arrow_ok : 0; D->arrow_group = s->arrow_group; D->arrow_steps = s->arrow_steps;
   D->arrow_vsteps = s->arrow_vsteps; D->arrow_vrows = s->arrow_vrows;
+  D->tile_ok = D->arrow_ok ? s->tile_ok : 0; D->tile_ta = s->tile_ta; D->tile_tq = s->tile_tq; D->tile_lanes = s->tile_lanes;
+  D->nTi = s->nTi; D->ldTi = (s->nTi + 1) & ~1;
+  D->po_tlane = s->po_tlane; D->po_tmap = s->po_tmap; D->po_tislot = s->po_tislot;
+  D->tile_admm_ok = D->tile_ok ? s->tile_admm_ok : 0; D->tile_vslots = s->tile_vslots; D->tile_slots = s->tile_slots; D->po_tpos = s->po_tpos;
+  D->tile_ck[0] = s->tile_ck[0]; D->tile_ck[1] = s->tile_ck[1]; D->tile_ck[2] = s->tile_ck[2]; D->tile_tk = s->tile_tk;
+  D->po_cmap = s->po_cmap; D->po_crow = s->po_crow;
   if (D->arrow_ok) {
     int t, l;
     D->arrow_g0 = s->plan[s->po_gstart + s->arrow_group];
@@ -235,6 +241,7 @@ void rldl_batch_free(rldl_batch *h) {
   if (h->num.Kx) (void)hipFree(h->num.Kx);
   if (h->num.F) (void)hipFree(h->num.F);
   if (h->num.D) (void)hipFree(h->num.D);
+  if (h->num.Ti) (void)hipFree(h->num.Ti);
   if (h->num.rho_inv) (void)hipFree(h->num.rho_inv);
   if (h->num.status) (void)hipFree(h->num.status);
   if (h->ev0) (void)hipEventDestroy((hipEvent_t)h->ev0);
@@ -280,6 +287,10 @@ static c_int batch_create(rldl_batch **hp, c_int batch, const csc *P, const csc 
   h->num.Kx = (double *)dev_alloc(sizeof(double) * (size_t)batch * (size_t)h->sym->nnzK, &ok);
   h->num.F = (double *)dev_alloc(sizeof(double) * (size_t)batch * (size_t)h->dsym.ldF, &ok);
   h->num.D = (double *)dev_alloc(sizeof(double) * (size_t)batch * (size_t)h->sym->N, &ok);
+  if (h->dsym.tile_ok) {                                        /* inverse of the tail triangle in tile order (k_tile_* kernels) */
+    h->num.Ti = (double *)dev_alloc(sizeof(double) * (size_t)batch * (size_t)h->dsym.ldTi, &ok);
+    if (ok && !HIP_OK(hipMemset(h->num.Ti, 0, sizeof(double) * (size_t)batch * (size_t)h->dsym.ldTi))) ok = 0;
+  }
   /* padding slots of the plan's dense triangles are never written by the factor kernel: zero them once */
   if (ok && !HIP_OK(hipMemset(h->num.F, 0, sizeof(double) * (size_t)batch * (size_t)h->dsym.ldF))) ok = 0;
   h->num.rho_inv = (double *)dev_alloc(sizeof(double) * (size_t)batch * (size_t)h->sym->m, &ok);
@@ -383,21 +394,28 @@ c_int rldl_symbolic_analyze(const csc *P, const csc *A, c_int polish, const c_in
 }
 
 /* Host-only export of the solve plan (tests emulate the device schedule on the CPU with it).
- * meta[0..23] = {plan_ok, nS, nO, ngroups, plan_words, po_gstart, po_gflag, po_gToff, po_fsp, po_bsp, po_fsb, po_fsc,
- *                po_bsb, po_bsc, po_fsig, po_bsig, po_fcol, po_brs, po_perm, N, nnzL, 0...}; blob/LtoS may be NULL. */
+ * meta[0..47] = {plan_ok, nS, nO, ngroups, plan_words, po_gstart, po_gflag, po_gToff, po_fsp, po_bsp, po_fsb, po_fsc,
+ *                po_bsb, po_bsc, po_fsig, po_bsig, po_fcol, po_brs, po_perm, N, nnzL, arrow_ok, arrow_group, arrow_vsteps,
+ *                arrow_vrows, po_avmap, po_avcol, po_avrow, nOp, tile_ok, tile_ta, tile_tq, tile_lanes, nTi, po_tlane, po_tmap,
+ *                po_tislot, tile_admm_ok, tile_vslots, tile_slots, po_tpos, tile_ck[0..2], tile_tk, po_cmap, po_crow, 0};
+ *                blob/LtoS may be NULL. */
 c_int rldl_plan_export(const csc *P, const csc *A, c_int polish, const c_int *perm_in, c_int *meta, int *blob, c_int blob_cap,
                        c_int *LtoS) {
   rldl_symbolic *s = 0;
   c_int i;
   if (!P || !A || !meta) return 1;
   if (rldl_symbolic_create(&s, P->n, A->m, P->p, P->i, A->p, A->i, polish != 0, perm_in)) return RLDL_LINSYS_SOLVER_INIT_ERROR;
-  for (i = 0; i < 32; i++) meta[i] = 0;
+  for (i = 0; i < 48; i++) meta[i] = 0;
   meta[0] = s->plan_ok; meta[1] = s->nS; meta[2] = s->nO; meta[3] = s->ngroups; meta[4] = s->plan_ok ? s->plan_words : 0;
   meta[5] = s->po_gstart; meta[6] = s->po_gflag; meta[7] = s->po_gToff; meta[8] = s->po_fsp; meta[9] = s->po_bsp;
   meta[10] = s->po_fsb; meta[11] = s->po_fsc; meta[12] = s->po_bsb; meta[13] = s->po_bsc; meta[14] = s->po_fsig;
   meta[15] = s->po_bsig; meta[16] = s->po_fcol; meta[17] = s->po_brs; meta[18] = s->po_perm; meta[19] = s->N; meta[20] = s->nnzL;
   meta[21] = s->plan_ok ? s->arrow_ok : 0; meta[22] = s->arrow_group; meta[23] = s->arrow_vsteps; meta[24] = s->arrow_vrows;
   meta[25] = s->po_avmap; meta[26] = s->po_avcol; meta[27] = s->po_avrow; meta[28] = s->nOp;
+  meta[29] = s->plan_ok ? s->tile_ok : 0; meta[30] = s->tile_ta; meta[31] = s->tile_tq; meta[32] = s->tile_lanes; meta[33] = s->nTi;
+  meta[34] = s->po_tlane; meta[35] = s->po_tmap; meta[36] = s->po_tislot;
+  meta[37] = s->plan_ok && s->tile_ok ? s->tile_admm_ok : 0; meta[38] = s->tile_vslots; meta[39] = s->tile_slots; meta[40] = s->po_tpos;
+  meta[41] = s->tile_ck[0]; meta[42] = s->tile_ck[1]; meta[43] = s->tile_ck[2]; meta[44] = s->tile_tk; meta[45] = s->po_cmap; meta[46] = s->po_crow;
   if (blob && s->plan_ok && blob_cap >= s->plan_words) memcpy(blob, s->plan, sizeof(int) * (size_t)s->plan_words);
   if (LtoS) for (i = 0; i < s->nnzL; i++) LtoS[i] = s->LtoS[i];
   rldl_symbolic_free(s);

@@ -56,6 +56,10 @@ typedef struct {
   int nOp;                     /* nO rounded up to even: first triangle slot */
   int arrow_ok, arrow_group, arrow_steps; /* arrowhead specialisation (see rldl_plan.c) */
   int arrow_vsteps, arrow_vrows;          /* virtual rows: coupling rows cut into pieces of <= vsteps entries, one piece per lane */
+  int tile_ok, tile_ta, tile_tq, tile_lanes, nTi, ldTi;   /* tail inverse by register tiles (rldl_symbolic.h); ldTi = nTi rounded up to even */
+  int po_tlane, po_tmap, po_tislot;
+  int tile_admm_ok, tile_vslots, tile_slots, po_tpos;   /* ADMM slots of the tile kernels (rldl_symbolic.h) */
+  int tile_ck[3], tile_tk, po_cmap, po_crow;            /* backward coupling product gathered by the owner lane */
   int arrow_g0, arrow_g;       /* index range of the tail group */
   int arrow_tb;                /* its triangle base relative to slot nOp, or -1 */
   int arrow_dense;             /* 1: every head column has entries only in the tail group, which ends the matrix (k_arrow_factor) */
@@ -73,6 +77,7 @@ typedef struct {
   double sigma;
   double *Kx;       /* [batch][nnzK]   permuted KKT values                     */
   double *F;        /* [batch][ldF]    factor in plan slot order (nS), then Dinv (N): what `solve` streams */
+  double *Ti;       /* [batch][ldTi]   inverse of the tail's unit lower triangle in tile order (tile_ok), else NULL */
   double *D;        /* [batch][N]      pivots (inertia check, export)           */
   double *rho_inv;  /* [batch][m]      param2 of the KKT (delta when polishing) */
   int *status;      /* [batch]         #positive pivots, or -1 on a zero pivot */

@@ -2356,6 +2356,442 @@ __global__ __launch_bounds__(256, 4) void k_arrow_admm(rldl_dev_sym S, rldl_dev_
   if (tr && lane == 0 && W.trace_iter < 0) tr[6] = wall_clock64();
 }
 
+// ================================================================================================
+// Tile kernels (S.tile_ok): the arrowhead solve WITHOUT dependent sweeps.
+// The two sweeps over the tail's packed triangle are a chain of g - 1 dependent (v_readlane x2 -> v_fma_f64) steps each
+// (94 of them at the metric shape: 4.5 of the 7.4 us a lone wave needs per solve).  Here the unit lower triangle L22 of
+// the tail group is inverted once per factorisation (k_tile_invert) and x <- L22^-T D^-1 L22^-1 x becomes two
+// dependency-free products with Linv = L22^-1:
+//   * Linv's strictly lower part is cut into ta x ta tiles, ONE TILE PER LANE, ta^2 values in registers (25 at the metric
+//     shape: 55 of 64 lanes hold a tile, the 10 diagonal tiles are half empty);
+//   * forward  y = Linv c : the lane of tile (I, J) reads the ta entries of c in block column J, forms its ta partial row
+//     sums with ta^2 independent fmas and adds them to block row I of x with ta LDS atomics (ds_add_f64);
+//   * backward x = Linv' w: the same registers, read by columns: ta reads from block row I, ta^2 fmas, ta atomics into block column J;
+//   * rows are stored rotated by J and columns by I inside a tile, so lanes that share a block row (column) start their
+//     atomics at different words (at most ceil(tq / ta) lanes meet on one word).
+// The coupling part (tail rows x head columns) is the virtual-row gather / scatter of the arrow kernels, with its values
+// loaded straight from the factor row in HBM into registers (per-lane slot table), no LDS staging.  LDS per wave is x only.
+// Same result as QDLDL_solve up to rounding (the products sum in a different order and use the explicit inverse):
+// tests hold it to the same 1e-10 / 1e-8 tolerances as the sweep kernels.  RLDL_NO_TILE=1 selects the sweep kernels.
+// ================================================================================================
+template <int TA>
+struct TileRegs { double v[TA * TA]; };
+// tile values: global (Ti row of the instance, (k, lane) order) -> registers through the slot table
+template <int TA>
+__device__ __forceinline__ void tile_load(const rldl_dev_sym &S, const double *__restrict__ Tg, int lane, TileRegs<TA> &T) {
+  const unsigned *tm = reinterpret_cast<const unsigned *>(S.plan + S.po_tmap);
+  unsigned w[(TA * TA + 1) / 2];
+#pragma unroll
+  for (int k2 = 0; k2 < (TA * TA + 1) / 2; k2++) w[k2] = tm[k2 * 64 + lane];
+#pragma unroll
+  for (int k = 0; k < TA * TA; k++) {
+    const unsigned slot = (k & 1) ? w[k >> 1] >> 16 : w[k >> 1] & 0xffffu;
+    const double val = Tg[slot != 0xffffu ? slot : 0u];
+    T.v[k] = slot != 0xffffu ? val : 0.0;
+  }
+}
+// coupling values: factor row in global memory -> registers through the virtual-row slot table
+template <int TG>
+__device__ __forceinline__ void arrow_load_val_global(const rldl_dev_sym &S, const double *__restrict__ Fg, int lane, ArrowRegs<TG> &R) {
+  ArrowIdx<TG> M;
+  arrow_load_map<TG>(S, lane, M);
+#pragma unroll
+  for (int t = 0; t < TG; t++) {
+    const unsigned slot = (t & 1) ? M.ix[t >> 1] >> 16 : M.ix[t >> 1] & 0xffffu;
+    const double val = Fg[slot != 0xffffu ? slot : 0u];
+    R.v[t] = slot != 0xffffu ? val : 0.0;
+  }
+}
+// All LDS traffic of the tile kernels goes through absolute byte addresses that are built once per launch and kept PACKED,
+// two 16-bit addresses per register (a workgroup's dynamic LDS stays below 64 KiB): one v_and / v_lshrrev per access.
+__device__ __forceinline__ double lds_ld(const char *shb, unsigned a) { return *reinterpret_cast<const double *>(shb + a); }
+__device__ __forceinline__ void lds_st(char *shb, unsigned a, double v) { *reinterpret_cast<double *>(shb + a) = v; }
+__device__ __forceinline__ void lds_add(char *shb, unsigned a, double v) { unsafeAtomicAdd(reinterpret_cast<double *>(shb + a), v); }
+__device__ __forceinline__ unsigned pk_lo(unsigned w) { return w & 0xffffu; }
+__device__ __forceinline__ unsigned pk_hi(unsigned w) { return w >> 16; }
+
+template <int TG>
+struct TileCols { unsigned a[(TG + 1) / 2]; };                   // byte address of x[column] per virtual-row step, packed
+template <int TA>
+struct TileAddr { unsigned rc[TA]; bool act; };                 // low half: address of the tile's (rotated) row s, high half: of its column s
+
+// xb = byte address of the wave's x[0]; steps without an entry point at the lane's own dummy word (dmy), so neither the
+// gather nor the scatter needs a predicate and the padding lanes of a step never meet on one address
+template <int TG>
+__device__ __forceinline__ void tile_cols(const rldl_dev_sym &S, int lane, unsigned xb, unsigned dmy, TileCols<TG> &C) {
+  const unsigned *ap = reinterpret_cast<const unsigned *>(S.plan + S.po_avcol), *mp = reinterpret_cast<const unsigned *>(S.plan + S.po_avmap);
+#pragma unroll
+  for (int t2 = 0; t2 < (TG + 1) / 2; t2++) {
+    const unsigned cw = ap[t2 * 64 + lane], mw = mp[t2 * 64 + lane];
+    const unsigned lo = (mw & 0xffffu) != 0xffffu ? xb + 8u * (cw & 0xffffu) : dmy, hi = (mw >> 16) != 0xffffu ? xb + 8u * (cw >> 16) : dmy;
+    C.a[t2] = lo | (hi << 16);                                    // (both halves stay below 2^16)
+  }
+}
+template <int TA>
+__device__ __forceinline__ void tile_addr(const rldl_dev_sym &S, int lane, unsigned xtb, TileAddr<TA> &A) {
+  const unsigned w = reinterpret_cast<const unsigned *>(S.plan + S.po_tlane)[lane];
+  const int I = (int)(w & 0xffu), J = (int)((w >> 8) & 0xffu);
+  A.act = w != 0xffffffffu;
+#pragma unroll
+  for (int s = 0; s < TA; s++) {
+    const unsigned r = A.act ? (unsigned)(TA * I + (s + J) % TA) : 0u, c = A.act ? (unsigned)(TA * J + (s + I) % TA) : 0u;
+    A.rc[s] = (xtb + 8u * r) | ((xtb + 8u * c) << 16);
+  }
+}
+// y = Linv c in place (strictly lower part times c, added to c) on the tail's x in LDS
+template <int TA>
+__device__ __forceinline__ void tile_fwd(const TileRegs<TA> &T, char *shb, const TileAddr<TA> &A) {
+  double c[TA], p[TA];
+  if (A.act) {
+#pragma unroll
+    for (int u = 0; u < TA; u++) c[u] = lds_ld(shb, pk_hi(A.rc[u]));
+#pragma unroll
+    for (int s = 0; s < TA; s++) {
+      double acc = 0.0;
+#pragma unroll
+      for (int u = 0; u < TA; u++) acc = fma(T.v[s * TA + u], c[u], acc);
+      p[s] = acc;
+    }
+  }
+  wave_sync();                                                   // every read of c precedes the first add
+  if (A.act) {
+#pragma unroll
+    for (int s = 0; s < TA; s++) lds_add(shb, pk_lo(A.rc[s]), p[s]);
+  }
+  wave_sync();
+}
+// x = Linv' w in place
+template <int TA>
+__device__ __forceinline__ void tile_bwd(const TileRegs<TA> &T, char *shb, const TileAddr<TA> &A) {
+  double w[TA], p[TA];
+  if (A.act) {
+#pragma unroll
+    for (int s = 0; s < TA; s++) w[s] = lds_ld(shb, pk_lo(A.rc[s]));
+#pragma unroll
+    for (int u = 0; u < TA; u++) {
+      double acc = 0.0;
+#pragma unroll
+      for (int s = 0; s < TA; s++) acc = fma(T.v[s * TA + u], w[s], acc);
+      p[u] = acc;
+    }
+  }
+  wave_sync();
+  if (A.act) {
+#pragma unroll
+    for (int u = 0; u < TA; u++) lds_add(shb, pk_hi(A.rc[u]), p[u]);
+  }
+  wave_sync();
+}
+// The whole permuted solve on the wave's x (LDS): rhs in; on return the tail slots hold their solution and every head slot
+// holds -sum_r L(r, c) x_r (the caller adds y_c Dinv_c, which it still has in registers).  Straight-line code: no predicate
+// besides the tile lanes' (one per phase).
+//   jra: byte address of x[row of this lane's virtual row] (the dummy word for lanes without one); za[t]: byte address of the
+//   caller's t-th x entry if that is a head entry, else the dummy word; dta: address of tail entry `lane` (dummy for lane >= g)
+template <int TG, int TA, int TS, bool SCATTER>
+__device__ __forceinline__ void tile_tri_solve(const ArrowRegs<TG> &R, const TileCols<TG> &C, const TileRegs<TA> &T, const TileAddr<TA> &A,
+                                               double dtail, char *shb, unsigned jra, unsigned dta, const unsigned (&za)[TS], int lane,
+                                               long long *tr = nullptr) {
+  double ga[3] = {0.0, 0.0, 0.0};                                // three partial sums: the gather is not one dependent fma chain
+#pragma unroll
+  for (int t = 0; t < TG; t++)
+  {
+    ga[t % 3] = fma(-R.v[t], lds_ld(shb, (t & 1) ? pk_hi(C.a[t >> 1]) : pk_lo(C.a[t >> 1])), ga[t % 3]);
+    if (t % 9 == 8) __builtin_amdgcn_sched_barrier(0);           // at most 9 reads in flight: their values need registers
+  }
+  wave_sync();                                                   // all reads of the head values are done
+  lds_add(shb, jra, (ga[0] + ga[1]) + ga[2]);
+  if (SCATTER) {
+#pragma unroll
+    for (int t = 0; t < TS; t++) lds_st(shb, za[t], 0.0);         // head slots become scatter accumulators
+  }
+  wave_sync();
+  if (tr && lane == 0) tr[2] = wall_clock64();                   // gather done
+  tile_fwd<TA>(T, shb, A);
+  if (tr && lane == 0) tr[3] = wall_clock64();                   // forward product done
+  lds_st(shb, dta, lds_ld(shb, dta) * dtail);                    // D^-1
+  wave_sync();
+  tile_bwd<TA>(T, shb, A);
+  if (tr && lane == 0) tr[4] = wall_clock64();                   // backward product done
+  if (SCATTER) {                                                 // SCATTER = false: the caller gathers the head entries itself (col_gather)
+    const double xr = -lds_ld(shb, jra);
+#pragma unroll
+    for (int t = 0; t < TG; t++)                                 // transposed gather: -L(r, c) x_r into the head columns
+      lds_add(shb, (t & 1) ? pk_hi(C.a[t >> 1]) : pk_lo(C.a[t >> 1]), R.v[t] * xr);
+    wave_sync();
+  }
+}
+
+// Backward coupling product gathered by the owner: lane (slot t) holds the entries L(r, c) of the column c it owns in slot t
+// (second register copy of the coupling values, host tables po_cmap / po_crow) and the LDS addresses of their x_r, packed.
+template <int TK>
+struct ColRegs { double v[TK]; unsigned a[TK / 2]; };
+template <int TK>
+__device__ __forceinline__ void col_load(const rldl_dev_sym &S, const double *__restrict__ Fg, int lane, unsigned xtb, unsigned dmy, ColRegs<TK> &Q) {
+  const unsigned *cm = reinterpret_cast<const unsigned *>(S.plan + S.po_cmap), *cr = reinterpret_cast<const unsigned *>(S.plan + S.po_crow);
+#pragma unroll
+  for (int k2 = 0; k2 < TK / 2; k2++) {
+    const unsigned mw = cm[k2 * 64 + lane], rw = cr[k2 * 64 + lane];
+    const unsigned s0 = mw & 0xffffu, s1 = mw >> 16;
+    const double v0 = Fg[s0 != 0xffffu ? s0 : 0u], v1 = Fg[s1 != 0xffffu ? s1 : 0u];
+    Q.v[2 * k2] = s0 != 0xffffu ? v0 : 0.0;
+    Q.v[2 * k2 + 1] = s1 != 0xffffu ? v1 : 0.0;
+    Q.a[k2] = (s0 != 0xffffu ? xtb + 8u * (rw & 0xffffu) : dmy) | ((s1 != 0xffffu ? xtb + 8u * (rw >> 16) : dmy) << 16);
+  }
+}
+// steps [0, 3 TK / 4): the column this lane owns in the first constraint slot, [3 TK / 4, TK): in the second (compile-time split)
+template <int TK>
+__device__ __forceinline__ void col_gather(const ColRegs<TK> &Q, const char *shb, double &r1, double &r2) {
+  constexpr int SP = (3 * TK) / 4;
+  double a[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int k = 0; k < TK; k++) {
+    const double xv = lds_ld(shb, (k & 1) ? pk_hi(Q.a[k >> 1]) : pk_lo(Q.a[k >> 1]));
+    const int j = (k < SP ? 0 : 2) + (k & 1);
+    a[j] = fma(Q.v[k], xv, a[j]);
+    if (k % 8 == 7) __builtin_amdgcn_sched_barrier(0);           // at most 8 reads in flight: their values need registers
+  }
+  r1 = a[0] + a[1]; r2 = a[2] + a[3];
+}
+
+// Inverse of the tail's unit lower triangle, once per factorisation: lane c solves L22 X = e_c by forward substitution with
+// the rows of L22 as LDS broadcast reads (one address per wave), X in registers; the columns then go through LDS into
+// the (k, lane) tile order of Ti.  SM = compile-time bound on g.  One wave per instance.
+template <int SM>
+__global__ __launch_bounds__(WAVE) void k_tile_invert(rldl_dev_sym S, rldl_dev_num Nn, const int *__restrict__ mask) {
+  const int inst = blockIdx.x, lane = threadIdx.x;
+  if (mask && !mask[inst]) return;
+  extern __shared__ double sh[];                                 // g (g - 1) / 2 doubles: the triangle, then the staging buffer
+  const int g = S.arrow_g, tri = (g * (g - 1)) >> 1;
+  const double *Lg = Nn.F + (size_t)inst * S.ldF + S.nOp;        // row-major packed triangle of the tail group (plan slot order)
+  for (int i = lane; i < tri; i += WAVE) sh[i] = Lg[i];
+  unsigned short sl[SM];
+  {
+    const unsigned short *ts = reinterpret_cast<const unsigned short *>(S.plan + S.po_tislot);
+#pragma unroll
+    for (int i = 1; i < SM; i++) sl[i] = i < g ? ts[i * 64 + lane] : (unsigned short)0xffffu;
+  }
+  wave_sync();
+  double X[SM];
+#pragma unroll
+  for (int i = 0; i < SM; i++) X[i] = i == lane ? 1.0 : 0.0;
+#pragma unroll
+  for (int i = 1; i < SM; i++) {
+    if (i < g) {                                                 // uniform
+      const double *row = sh + ((i * (i - 1)) >> 1);
+      double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+      for (int j = 0; j + 1 < i; j += 2) { a0 = fma(row[j], X[j], a0); a1 = fma(row[j + 1], X[j + 1], a1); }
+      if (i & 1) a0 = fma(row[i - 1], X[i - 1], a0);
+      X[i] -= a0 + a1;                                           // lanes c >= i: all X[j < i] are 0, X[i] stays delta_ic
+    }
+  }
+  wave_sync();                                                   // the triangle is dead: same LDS becomes the tile-order buffer
+#pragma unroll
+  for (int i = 1; i < SM; i++)
+    if (sl[i] != 0xffffu) sh[sl[i]] = X[i];
+  wave_sync();
+  double *To = Nn.Ti + (size_t)inst * S.ldTi;
+  for (int p = lane; p < S.nTi; p += WAVE) To[p] = sh[p];
+}
+
+// LDS per wave of the tile kernels (pws doubles): x (xdw doubles, incl. the padding rows of the last block row), 64 dummy words
+// (one per lane, always 0: the target of every access that has no entry), then -- k_tile_admm only -- the per-slot constants of
+// the ADMM step, [5][3 * 64]: l, u, rho, rho_inv (constraint slots) and the head's Dinv (0 for tail entries).  The constants
+// are private to a lane: LDS is used as a second register file, reads are conflict-free.
+template <int TMAX, int TG, int TA>
+__global__ __launch_bounds__(256, 2) void k_tile_solve(rldl_dev_sym S, rldl_dev_num Nn, double *__restrict__ b_all, int xdw) {
+  extern __shared__ __attribute__((aligned(16))) double sh[];
+  const int lane = threadIdx.x & (WAVE - 1), wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wpb = blockDim.x >> 6;
+  const int inst = blockIdx.x * wpb + wv;
+  if (inst >= Nn.batch) return;
+  char *shb = reinterpret_cast<char *>(sh);
+  const unsigned xb = (unsigned)wv * (unsigned)(xdw + WAVE) * 8u, dmy = xb + 8u * (unsigned)(xdw + lane);
+  const double *Fg = Nn.F + (size_t)inst * S.ldF;
+  double *b = b_all + (size_t)inst * S.N;
+  const int *permg = S.plan + S.po_perm;
+  const int g0 = S.arrow_g0, g = S.arrow_g;
+  ArrowRegs<TG> R;
+  TileRegs<TA> T;
+  arrow_load_val_global<TG>(S, Fg, lane, R);
+  tile_load<TA>(S, Nn.Ti + (size_t)inst * S.ldTi, lane, T);
+  TileCols<TG> C;
+  TileAddr<TA> A;
+  tile_cols<TG>(S, lane, xb, dmy, C);
+  tile_addr<TA>(S, lane, xb + 8u * (unsigned)g0, A);
+  const unsigned jra = lane < S.arrow_vrows ? xb + 8u * (unsigned)(S.plan + S.po_avrow)[lane] : dmy;
+  const unsigned dta = lane < g ? xb + 8u * (unsigned)(g0 + lane) : dmy;
+  const double dtail = Fg[S.nS + g0 + (lane < g ? lane : 0)];
+  int oo[TMAX];
+  unsigned xa[TMAX], za[TMAX];
+  double vb[TMAX];
+#pragma unroll
+  for (int t = 0; t < TMAX; t++) {
+    const int j = t * WAVE + lane;
+    oo[t] = j < S.N ? permg[j] : -1;
+    xa[t] = j < S.N ? xb + 8u * (unsigned)j : dmy;
+    za[t] = j < S.N && (j < g0 || j >= g0 + g) ? xa[t] : dmy;
+  }
+#pragma unroll
+  for (int t = 0; t < TMAX; t++) vb[t] = oo[t] >= 0 ? b[oo[t]] : 0.0;   // permute_x  qdldl_interface.c:538-541
+  double dv[TMAX], rr_[TMAX];                                   // head Dinv (0 for tail entries) and rho_inv
+  const double *ri = Nn.rho_inv + (size_t)inst * S.m;
+#pragma unroll
+  for (int t = 0; t < TMAX; t++) {
+    const int j = t * WAVE + lane;
+    const double d = Fg[S.nS + (j < S.N ? j : 0)];
+    dv[t] = za[t] != dmy ? d : 0.0;
+    rr_[t] = S.polish ? 0.0 : ri[oo[t] >= S.n ? oo[t] - S.n : 0];
+  }
+  for (int j = S.N + lane; j < xdw + WAVE; j += WAVE) lds_st(shb, xb + 8u * (unsigned)j, 0.0);   // padding rows, dummy words
+  wave_sync();
+#pragma unroll
+  for (int t = 0; t < TMAX; t++) lds_st(shb, xa[t], vb[t]);
+  wave_sync();
+  tile_tri_solve<TG, TA, TMAX, true>(R, C, T, A, dtail, shb, jra, dta, za, lane);
+#pragma unroll
+  for (int t = 0; t < TMAX; t++) {
+    if (oo[t] < 0) continue;
+    const double xv = fma(vb[t], dv[t], lds_ld(shb, xa[t]));    // head: x_c = y_c Dinv_c - sum_r L(r,c) x_r
+    if (S.polish || oo[t] < S.n) b[oo[t]] = xv;
+    else b[oo[t]] = vb[t] + rr_[t] * xv;                        // qdldl_interface.c:568-579
+  }
+}
+
+// `iters` fused ADMM iterations per launch (as k_arrow_admm).  Everything the loop touches is on chip: both copies of the
+// coupling values, the tile of Linv, the packed LDS addresses, x / z / y / q and rho_inv in registers, x~ and the other
+// per-slot constants in LDS -- no global memory access inside the loop and no branch besides the tile lanes' predicate.
+// The permuted positions are dealt to (slot, lane) by the host (po_tpos): slot 0 holds the variables, slots 1 and 2 the
+// constraints, so the step code of a slot is uniform (S.tile_vslots == 1 is a condition of tile_admm_ok).
+#define TILE_SLOTS 3
+template <int TG, int TA, int TK, bool TRACE>
+__global__ __launch_bounds__(256, 2) void k_tile_admm(rldl_dev_sym S, rldl_dev_num Nn, rldl_dev_admm W, int xdw, int iters) {
+  extern __shared__ __attribute__((aligned(16))) double sh[];
+  const int lane = threadIdx.x & (WAVE - 1), wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wpb = blockDim.x >> 6;
+  const int inst = blockIdx.x * wpb + wv;
+  if (inst >= Nn.batch) return;
+  if (W.status[inst] != ST_UNSOLVED) return;
+  long long *tr = TRACE && W.trace ? W.trace + 8 * (size_t)inst : nullptr;
+  if (TRACE && tr && lane == 0) tr[7] = wall_clock64();
+  char *shb = reinterpret_cast<char *>(sh);
+  constexpr int TS = TILE_SLOTS, CW = TS * WAVE;                 // doubles per constant array
+  const unsigned xb = (unsigned)wv * (unsigned)(xdw + WAVE + 4 * CW) * 8u, dmy = xb + 8u * (unsigned)(xdw + lane);
+  const unsigned cb = xb + 8u * (unsigned)(xdw + WAVE + lane);   // this lane's column of the constant arrays: l, u, rho, Dinv
+  const int *permg = S.plan + S.po_perm, *tpos = S.plan + S.po_tpos;
+  const int n = S.n, m = S.m, g0 = S.arrow_g0, g = S.arrow_g;
+  const size_t io = (size_t)inst;
+  const double *Fg = Nn.F + io * S.ldF;
+  ArrowRegs<TG> R;
+  TileRegs<TA> T;
+  arrow_load_val_global<TG>(S, Fg, lane, R);
+  tile_load<TA>(S, Nn.Ti + io * S.ldTi, lane, T);
+  TileCols<TG> C;
+  TileAddr<TA> A;
+  tile_cols<TG>(S, lane, xb, dmy, C);
+  tile_addr<TA>(S, lane, xb + 8u * (unsigned)g0, A);
+  const unsigned jra = lane < S.arrow_vrows ? xb + 8u * (unsigned)(S.plan + S.po_avrow)[lane] : dmy;
+  const unsigned dta = lane < g ? xb + 8u * (unsigned)(g0 + lane) : dmy;
+  const double dtail = Fg[S.nS + g0 + (lane < g ? lane : 0)];
+  ColRegs<TK> Q;                                                 // the owner's copy of the coupling values (backward product as a gather)
+  col_load<TK>(S, Fg, lane, xb + 8u * (unsigned)g0, dmy, Q);
+  int oo[TS];                                                    // index of the slot's entry in its own arrays (variable 0..n-1, constraint 0..m-1), -1: none
+  unsigned xz[TS];                                               // address of x[position] | address where the solve leaves the entry's x (dummy: head entry) << 16
+  double va[TS], vb[TS], rinv[TS];                               // slot 0: x, q; slots 1, 2: z, y, rho_inv
+  for (int j = S.N + lane; j < xdw + WAVE; j += WAVE) lds_st(shb, xb + 8u * (unsigned)j, 0.0);   // padding rows, dummy words
+  {
+    const double *ri = Nn.rho_inv + io * m, *x = W.x + io * n, *z = W.z + io * m, *y = W.y + io * m;
+    const double *q = W.q + io * n, *l = W.l + io * m, *u = W.u + io * m, *rv = W.rho_vec + io * m;
+#pragma unroll
+    for (int t = 0; t < TS; t++) {
+      const int jp = tpos[t * WAVE + lane];
+      const bool on = jp >= 0, var = t == 0, head = on && (jp < g0 || jp >= g0 + g);
+      const int o = on ? permg[jp] : 0, i = var ? o : o - n;      // (host: slot 0 holds perm < n, the others perm >= n)
+      oo[t] = on ? i : -1;
+      const unsigned xa = on ? xb + 8u * (unsigned)jp : dmy;
+      xz[t] = xa | ((head ? dmy : xa) << 16);
+      va[t] = !on ? 0.0 : var ? x[i] : z[i];
+      vb[t] = !on ? 0.0 : var ? q[i] : y[i];
+      const bool con = on && !var;
+      rinv[t] = con ? ri[i] : 0.0;
+      const unsigned ca = cb + 8u * (unsigned)(t * WAVE);
+      lds_st(shb, ca, con ? l[i] : 0.0);
+      lds_st(shb, ca + 8u * CW, con ? u[i] : 0.0);
+      lds_st(shb, ca + 16u * CW, con ? rv[i] : 0.0);
+      lds_st(shb, ca + 24u * CW, head ? Fg[S.nS + jp] : 0.0);
+    }
+  }
+  const double alpha = W.alpha, sigma = W.sigma;
+#pragma clang loop unroll(disable)
+  for (int it = 0; it < iters; it++) {
+    const bool last = it + 1 == iters;
+    const bool trit = TRACE && tr && (W.trace_iter < 0 ? last : it == W.trace_iter);
+    if (trit && lane == 0) tr[0] = wall_clock64();
+    // the packed addresses stay packed: without this every unpacked LDS address becomes a loop-invariant register of its own
+#pragma unroll
+    for (int t2 = 0; t2 < (TG + 1) / 2; t2++) asm volatile("" : "+v"(C.a[t2]));
+#pragma unroll
+    for (int s2 = 0; s2 < TA; s2++) asm volatile("" : "+v"(A.rc[s2]));
+#pragma unroll
+    for (int t = 0; t < TS; t++) asm volatile("" : "+v"(xz[t]), "+v"(oo[t]));   // (oo: else the 15 store addresses of the last iteration are hoisted)
+#pragma unroll
+    for (int k2 = 0; k2 < TK / 2; k2++) asm volatile("" : "+v"(Q.a[k2]));
+    unsigned cbo = cb;
+    asm volatile("" : "+v"(cbo));
+    const unsigned za[TS] = {dmy, dmy, dmy};                     // (unused: no scatter)
+    double rhs[TS];                                              // compute_rhs (auxil.c:164-178) in permuted order
+    rhs[0] = sigma * va[0] - vb[0];
+#pragma unroll
+    for (int t = 1; t < TS; t++) rhs[t] = va[t] - rinv[t] * vb[t];
+#pragma unroll
+    for (int t = 0; t < TS; t++) lds_st(shb, pk_lo(xz[t]), rhs[t]);
+    wave_sync();
+    if (trit && lane == 0) tr[1] = wall_clock64();              // rhs in LDS
+    tile_tri_solve<TG, TA, TS, false>(R, C, T, A, dtail, shb, jra, dta, za, lane, trit ? tr : nullptr);
+    double hs[TS] = {0.0, 0.0, 0.0};                             // sum_r L(r, c) x_r of the head entry this lane owns in slot t (0: tail entry)
+    col_gather<TK>(Q, shb, hs[1], hs[2]);
+    if (trit && lane == 0) tr[5] = wall_clock64();              // backward coupling product done
+    double xs_[TS], dinv[TS], lo[TS], hi[TS], rho[TS], dl[TS];
+#pragma unroll
+    for (int t = 0; t < TS; t++) {                               // all reads first: one LDS round trip for the whole update
+      const unsigned ca = cbo + 8u * (unsigned)(t * WAVE);
+      xs_[t] = lds_ld(shb, pk_hi(xz[t]));                        // tail entry: its solution; head entry: 0
+      dinv[t] = lds_ld(shb, ca + 24u * CW);                      // head: x_c = y_c Dinv_c - sum_r L(r,c) x_r, y_c = rhs_c; tail: 0
+      if (t > 0) { lo[t] = lds_ld(shb, ca); hi[t] = lds_ld(shb, ca + 8u * CW); rho[t] = lds_ld(shb, ca + 16u * CW); }
+    }
+    {                                                            // slot 0: update_x (auxil.c:188-201)
+      const double xp = va[0];
+      const double sv = fma(rhs[0], dinv[0], xs_[0] - hs[0]);
+      const double xn = alpha * sv + (1.0 - alpha) * xp;
+      va[0] = xn; dl[0] = xn - xp;
+    }
+#pragma unroll
+    for (int t = 1; t < TS; t++) {                               // slots 1, 2: z_tilde, update_z, update_y
+      const double zp = va[t], yi = vb[t], r = rinv[t];
+      const double sv = fma(rhs[t], dinv[t], xs_[t] - hs[t]);
+      const double zt = rhs[t] + r * sv;                       // z_tilde = (z_prev - rho_inv y) + rho_inv nu, qdldl_interface.c:577-579
+      const double mix = alpha * zt + (1.0 - alpha) * zp;
+      double zn = mix + r * yi;                                // update_z :203-215
+      zn = fmin(fmax(zn, lo[t]), hi[t]);                       // project, proj.c:4-14
+      const double d = rho[t] * (mix - zn);                    // update_y :217-228
+      va[t] = zn; vb[t] = yi + d; dl[t] = d;
+    }
+    if (last) {                                                  // uniform: the only stores of the launch
+      if (oo[0] >= 0) {
+        (W.x + io * n)[oo[0]] = va[0];
+        if (W.write_delta) (W.delta_x + io * n)[oo[0]] = dl[0];
+      }
+#pragma unroll
+      for (int t = 1; t < TS; t++)
+        if (oo[t] >= 0) {
+          (W.z + io * m)[oo[t]] = va[t];
+          (W.y + io * m)[oo[t]] = vb[t];
+          if (W.write_delta) (W.delta_y + io * m)[oo[t]] = dl[t];
+        }
+    }
+    if (trit && lane == 0 && W.trace_iter >= 0) tr[6] = wall_clock64();
+  }
+  if (tr && lane == 0 && W.trace_iter < 0) tr[6] = wall_clock64();
+}
+
 // ------------------------------------------------------------------------------------------------
 // Horizon change (osqp_update_recursive, src/recursive_ldl.c:1973-2016; update_AP_matrices :1675-1778;
 // LDL_update_from_pivot :946-1110).  Every horizon N <= Nmax has its own resident workspace; moving from one to another
@@ -2599,10 +3035,8 @@ static int launch_arrow_solve_t(const rldl_dev_sym *S, const rldl_dev_num *Nn, d
 }
 template <int TMAX>
 static int launch_arrow_solve_g(const rldl_dev_sym *S, const rldl_dev_num *Nn, double *d_b, void *stream) {
-  if (S->arrow_vsteps <= 8) return launch_arrow_solve_t<TMAX, 8>(S, Nn, d_b, stream);
+  // (the step counts the host pads the virtual-row tables to: the edge colouring may use every padded step)
   if (S->arrow_vsteps <= 12) return launch_arrow_solve_t<TMAX, 12>(S, Nn, d_b, stream);
-  if (S->arrow_vsteps <= 14) return launch_arrow_solve_t<TMAX, 14>(S, Nn, d_b, stream);
-  if (S->arrow_vsteps <= 16) return launch_arrow_solve_t<TMAX, 16>(S, Nn, d_b, stream);
   if (S->arrow_vsteps <= 18) return launch_arrow_solve_t<TMAX, 18>(S, Nn, d_b, stream);
   return launch_arrow_solve_t<TMAX, 24>(S, Nn, d_b, stream);
 }
@@ -2612,6 +3046,8 @@ static int launch_arrow_solve(const rldl_dev_sym *S, const rldl_dev_num *Nn, dou
   if (S->N <= 4 * WAVE) return launch_arrow_solve_g<4>(S, Nn, d_b, stream);
   return launch_arrow_solve_g<8>(S, Nn, d_b, stream);
 }
+static bool tile_admm_usable(const rldl_dev_sym *S, const rldl_dev_num *Nn, const rldl_dev_admm *W);
+static int launch_tile_admm(const rldl_dev_sym *S, const rldl_dev_num *Nn, const rldl_dev_admm *W, int iters, void *stream);
 template <int TMAX, int TG>
 static int launch_arrow_admm_t(const rldl_dev_sym *S, const rldl_dev_num *Nn, const rldl_dev_admm *W, int iters, void *stream) {
   size_t lds = 0;
@@ -2627,18 +3063,105 @@ static int launch_arrow_admm_t(const rldl_dev_sym *S, const rldl_dev_num *Nn, co
 }
 template <int TMAX>
 static int launch_arrow_admm_g(const rldl_dev_sym *S, const rldl_dev_num *Nn, const rldl_dev_admm *W, int iters, void *stream) {
-  if (S->arrow_vsteps <= 8) return launch_arrow_admm_t<TMAX, 8>(S, Nn, W, iters, stream);
   if (S->arrow_vsteps <= 12) return launch_arrow_admm_t<TMAX, 12>(S, Nn, W, iters, stream);
-  if (S->arrow_vsteps <= 14) return launch_arrow_admm_t<TMAX, 14>(S, Nn, W, iters, stream);
-  if (S->arrow_vsteps <= 16) return launch_arrow_admm_t<TMAX, 16>(S, Nn, W, iters, stream);
   if (S->arrow_vsteps <= 18) return launch_arrow_admm_t<TMAX, 18>(S, Nn, W, iters, stream);
   return launch_arrow_admm_t<TMAX, 24>(S, Nn, W, iters, stream);
 }
 static int launch_arrow_admm(const rldl_dev_sym *S, const rldl_dev_num *Nn, const rldl_dev_admm *W, int iters, void *stream) {
+  if (tile_admm_usable(S, Nn, W)) return launch_tile_admm(S, Nn, W, iters, stream);
   if (S->N <= 2 * WAVE) return launch_arrow_admm_g<2>(S, Nn, W, iters, stream);
   if (S->N <= 3 * WAVE) return launch_arrow_admm_g<3>(S, Nn, W, iters, stream);
   if (S->N <= 4 * WAVE) return launch_arrow_admm_g<4>(S, Nn, W, iters, stream);
   return launch_arrow_admm_g<8>(S, Nn, W, iters, stream);
+}
+
+// ---- tile kernels: geometry and dispatch ----
+// LDS per wave: x, long enough for the padding rows of the last block row (g0 + ta * tq >= N when the tail ends the matrix)
+#define TILE_WPB 4
+static int tile_per_wave(const rldl_dev_sym *S) {
+  const int need = S->arrow_g0 + S->tile_ta * S->tile_tq;
+  return ((need > S->N ? need : S->N) + 1) & ~1;
+}
+static bool tile_usable(const rldl_dev_sym *S, const rldl_dev_num *Nn) {
+  static const int off = getenv("RLDL_NO_TILE") ? 1 : 0;
+  return !off && S->tile_ok && Nn->Ti && S->arrow_tb == 0 && S->arrow_vsteps <= 24 && S->N <= 3 * WAVE &&
+         sizeof(double) * (size_t)(tile_per_wave(S) + WAVE + 5 * 3 * WAVE) * TILE_WPB < 65536;
+}
+// fused ADMM iterations: also needs the slot table (at most 3 slots of variables-only / constraints-only positions); the wave
+// timeline (W->trace) exists for the metric shape's instantiation only
+static bool tile_admm_usable(const rldl_dev_sym *S, const rldl_dev_num *Nn, const rldl_dev_admm *W) {
+  // register need of the instantiation the launcher would pick (measured fit: 2 TG + 2 TA^2 + 2.6 TK + 89): beyond 256 the
+  // kernel would spill inside its loop -- those shapes stay on the sweep kernels
+  const int tg = S->arrow_vsteps <= 12 ? 12 : S->arrow_vsteps <= 18 ? 18 : 24;
+  if (2 * tg + 2 * S->tile_ta * S->tile_ta + (26 * S->tile_tk) / 10 + 89 > 256) return false;
+  return tile_usable(S, Nn) && S->tile_admm_ok && (!W->trace || (S->arrow_vsteps > 12 && S->arrow_vsteps <= 18 && S->tile_ta == 5 && S->tile_tk == 24));
+}
+#define TILE_TA_SWITCH(CALL)                  \
+  switch (S->tile_ta) {                       \
+    case 2: CALL(2); break;                   \
+    case 3: CALL(3); break;                   \
+    case 5: CALL(5); break;                   \
+    case 7: CALL(7); break;                   \
+    default: return -1;                       \
+  }
+static int launch_tile_solve(const rldl_dev_sym *S, const rldl_dev_num *Nn, double *d_b, void *stream) {
+  const int pw = tile_per_wave(S), grid = (Nn->batch + TILE_WPB - 1) / TILE_WPB;
+  const size_t lds = sizeof(double) * (size_t)(pw + WAVE) * TILE_WPB;
+#define TS(TMAX, TG, TA) hipLaunchKernelGGL((k_tile_solve<TMAX, TG, TA>), dim3(grid), dim3(TILE_WPB * WAVE), lds, (hipStream_t)stream, *S, *Nn, d_b, pw)
+  if (S->arrow_vsteps <= 12) {
+#define C(TA) TS(3, 12, TA)
+    TILE_TA_SWITCH(C)
+#undef C
+  } else if (S->arrow_vsteps <= 18) {
+#define C(TA) TS(3, 18, TA)
+    TILE_TA_SWITCH(C)
+#undef C
+  } else {
+#define C(TA) TS(3, 24, TA)
+    TILE_TA_SWITCH(C)
+#undef C
+  }
+#undef TS
+  return launch_status();
+}
+static int launch_tile_admm(const rldl_dev_sym *S, const rldl_dev_num *Nn, const rldl_dev_admm *W, int iters, void *stream) {
+  const int pw = tile_per_wave(S), grid = (Nn->batch + TILE_WPB - 1) / TILE_WPB;
+  const size_t lds = sizeof(double) * (size_t)(pw + WAVE + 4 * TILE_SLOTS * WAVE) * TILE_WPB;
+  if (W->trace) {                                                 // the wave timeline exists for the metric shape's instantiation only
+    hipLaunchKernelGGL((k_tile_admm<18, 5, 24, true>), dim3(grid), dim3(TILE_WPB * WAVE), lds, (hipStream_t)stream, *S, *Nn, *W, pw, iters);
+    return launch_status();
+  }
+#define TA_(TG, TA, TK) hipLaunchKernelGGL((k_tile_admm<TG, TA, TK, false>), dim3(grid), dim3(TILE_WPB * WAVE), lds, (hipStream_t)stream, *S, *Nn, *W, pw, iters)
+#define TK_(TG, TA) switch (S->tile_tk) { case 16: TA_(TG, TA, 16); break; case 24: TA_(TG, TA, 24); break; case 32: TA_(TG, TA, 32); break; default: return -1; }
+  if (S->arrow_vsteps <= 12) {
+#define C(TA) TK_(12, TA)
+    TILE_TA_SWITCH(C)
+#undef C
+  } else if (S->arrow_vsteps <= 18) {
+#define C(TA) TK_(18, TA)
+    TILE_TA_SWITCH(C)
+#undef C
+  } else {
+#define C(TA) TK_(24, TA)
+    TILE_TA_SWITCH(C)
+#undef C
+  }
+#undef TK_
+#undef TA_
+  return launch_status();
+}
+// inverse of the tail triangle behind every numeric factorisation of a tile handle (any factor kernel: it reads the factor row)
+static int launch_tile_invert(const rldl_dev_sym *S, const rldl_dev_num *Nn, const int *d_mask, void *stream) {
+  if (!S->tile_ok || !Nn->Ti || S->arrow_tb != 0) return 0;
+  const int g = S->arrow_g;
+  const size_t lds = sizeof(double) * (size_t)((g * (g - 1)) / 2 + 2);
+  const dim3 grid(Nn->batch), blk(WAVE);
+  if (g <= 16) hipLaunchKernelGGL(k_tile_invert<16>, grid, blk, lds, (hipStream_t)stream, *S, *Nn, d_mask);
+  else if (g <= 32) hipLaunchKernelGGL(k_tile_invert<32>, grid, blk, lds, (hipStream_t)stream, *S, *Nn, d_mask);
+  else if (g <= 48) hipLaunchKernelGGL(k_tile_invert<48>, grid, blk, lds, (hipStream_t)stream, *S, *Nn, d_mask);
+  else if (g <= 56) hipLaunchKernelGGL(k_tile_invert<56>, grid, blk, lds, (hipStream_t)stream, *S, *Nn, d_mask);
+  else hipLaunchKernelGGL(k_tile_invert<64>, grid, blk, lds, (hipStream_t)stream, *S, *Nn, d_mask);
+  return launch_status();
 }
 
 extern "C" int rldl_launch_kkt_assemble(const rldl_dev_sym *S, const rldl_dev_num *Nn, const double *d_Px,
@@ -2690,7 +3213,8 @@ static int launch_factor(const rldl_dev_sym *S, const rldl_dev_num *Nn, const in
       else if (g <= 48) hipLaunchKernelGGL(k_arrow_factor<48>, grid, blk, al, (hipStream_t)stream, *S, *Nn, d_mask);
       else if (g <= 56) hipLaunchKernelGGL(k_arrow_factor<56>, grid, blk, al, (hipStream_t)stream, *S, *Nn, d_mask);
       else hipLaunchKernelGGL(k_arrow_factor<64>, grid, blk, al, (hipStream_t)stream, *S, *Nn, d_mask);
-      return launch_status();
+      if (launch_status()) return -1;
+      return launch_tile_invert(S, Nn, d_mask, stream);
     }
   }
   const size_t lds = sizeof(double) * (size_t)(S->nnzL + S->N);
@@ -2698,7 +3222,8 @@ static int launch_factor(const rldl_dev_sym *S, const rldl_dev_num *Nn, const in
     hipLaunchKernelGGL(k_factor<true>, dim3(Nn->batch), dim3(WAVE), lds, (hipStream_t)stream, *S, *Nn, d_mask, c_start);
   else
     hipLaunchKernelGGL(k_factor<false>, dim3(Nn->batch), dim3(WAVE), 0, (hipStream_t)stream, *S, *Nn, d_mask, c_start);
-  return launch_status();
+  if (launch_status()) return -1;
+  return launch_tile_invert(S, Nn, d_mask, stream);
 }
 
 static int launch_stage_factor(const rldl_dev_sym *S, const rldl_dev_num *Nn, const int *d_mask, int first_block, const int *d_b0v,
@@ -2739,6 +3264,7 @@ extern "C" int rldl_launch_factor_from(const rldl_dev_sym *S, const rldl_dev_num
 
 extern "C" int rldl_launch_solve(const rldl_dev_sym *S, const rldl_dev_num *Nn, double *d_b, void *stream) {
   if (Nn->batch <= 0) return 0;
+  if (arrow_usable(S) && tile_usable(S, Nn)) return launch_tile_solve(S, Nn, d_b, stream);
   if (arrow_usable(S)) return launch_arrow_solve(S, Nn, d_b, stream);
   if (blk_usable(S)) return launch_blk_solve(S, Nn, d_b, stream);
   if (plan_usable(S)) return launch_plan_solve(S, Nn, d_b, stream);

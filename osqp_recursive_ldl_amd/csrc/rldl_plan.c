@@ -40,7 +40,7 @@ int rldl_plan_build(rldl_symbolic *s) {
   int ng = 0, i, k, c, p, q, nO = 0, nOp = 0, tri = 0, na = 0, nr = 0, words, nfs = 0, nbs = 0, rc = -2;
   int arrow_k = -1, arrow_steps = 0, ngather = 0, ntri = 0, vpad = 0;
 
-  s->plan_ok = 0;
+  s->plan_ok = 0; s->tile_ok = 0; s->tile_admm_ok = 0;
   s->LtoS = (int *)malloc(sizeof(int) * (size_t)(s->nnzL > 0 ? s->nnzL : 1));
   group_of = (int *)malloc(sizeof(int) * (size_t)(N + 1));
   gstart = (int *)malloc(sizeof(int) * (size_t)(N + 2));
@@ -175,15 +175,69 @@ int rldl_plan_build(rldl_symbolic *s) {
     if (T > 32) s->arrow_ok = 0;
     else { s->arrow_vsteps = T; s->arrow_vrows = nv; }
   }
-  /* The tables are padded to the register bound the kernels are compiled for (8, 12, 14, 16, 18, 24 steps, see
-   * launch_arrow_*), so the device reads them without range checks. */
+  /* The tables are padded to the register bound the kernels are compiled for, so the device reads them without range
+   * checks: 12, 18 or 24 steps for the tile kernels (launch_tile_*); the sweep kernels (launch_arrow_*: 8, 12, 14, 16, 18,
+   * 24) read a prefix of the same table. */
   {
     const int T = s->arrow_vsteps;
-    vpad = T <= 8 ? 8 : T <= 12 ? 12 : T <= 14 ? 14 : T <= 16 ? 16 : T <= 18 ? 18 : T <= 24 ? 24 : ((T + 1) & ~1);
+    vpad = T <= 12 ? 12 : T <= 18 ? 18 : T <= 24 ? 24 : ((T + 1) & ~1);
   }
   s->po_avmap = words; words += s->arrow_ok ? ((vpad + 1) / 2) * 64 : 0;   /* dword [ceil(Tpad/2)][64]: slot(t even) | slot(t odd) << 16, 0xffff = none */
   s->po_avcol = words; words += s->arrow_ok ? ((vpad + 1) / 2) * 64 : 0;   /* same packing, column index (0 where there is no entry) */
   s->po_avrow = words; words += s->arrow_ok ? 64 : 0;                                 /* row (permuted index) of the lane's piece */
+  /* tail inverse by register tiles (see rldl_symbolic.h): tile size from the set the kernels are compiled for */
+  s->tile_ok = 0; s->tile_ta = 0; s->tile_tq = 0; s->tile_lanes = 0; s->nTi = 0;
+  s->po_tlane = s->po_tmap = s->po_tislot = 0;
+  if (s->arrow_ok && coloff[gstart[arrow_k]] == nOp) {
+    static const int tas[4] = {2, 3, 5, 7};
+    const int g = gstart[arrow_k + 1] - gstart[arrow_k];
+    int a = 0, tq = 0;
+    for (i = 0; i < 4; i++) {
+      tq = (g + tas[i] - 1) / tas[i];
+      if (tq * (tq + 1) / 2 <= 64) { a = tas[i]; break; }
+    }
+    if (a > 0 && g >= 2 && g <= 64) {
+      s->tile_ok = 1; s->tile_ta = a; s->tile_tq = tq; s->tile_lanes = tq * (tq + 1) / 2; s->nTi = g * (g - 1) / 2;
+      s->po_tlane = words; words += 64;
+      s->po_tmap = words; words += ((a * a + 1) / 2) * 64;
+      s->po_tislot = words; words += g * 32;
+      s->tile_vslots = (s->n + 63) / 64; s->tile_slots = s->tile_vslots + (s->m + 63) / 64;
+      s->tile_admm_ok = s->tile_slots <= 3 && !s->polish;
+      s->po_tpos = words; words += 3 * 64;
+      /* owner gather of the backward coupling product: positions of a kind by decreasing column count, steps per slot */
+      s->tile_ck[0] = s->tile_ck[1] = s->tile_ck[2] = 0; s->tile_tk = 16;
+      if (s->tile_admm_ok) {
+        int kind, tot = 0;
+        for (kind = 0; kind < 2; kind++) {
+          int t0 = kind ? s->tile_vslots : 0, t1 = kind ? s->tile_slots : s->tile_vslots, t;
+          for (t = t0; t < t1; t++) {                         /* largest count among the positions ranked [64 (t - t0), ...) of this kind */
+            int rank = 64 * (t - t0), best = 0, nbig;
+            /* the (rank+1)-th largest count: count how many positions of the kind have a count > v */
+            for (best = N; best > 0; best--) {
+              nbig = 0;
+              for (i = 0; i < N; i++) if ((s->perm[i] < s->n) == (kind == 0) && colcnt[i] >= best) nbig++;
+              if (nbig > rank) break;
+            }
+            s->tile_ck[t] = best; tot += best;
+          }
+        }
+        /* compile-time split of the steps: the first constraint slot's columns in [0, 3 tk / 4), the second's in [3 tk / 4, tk);
+         * head entries must all be constraints (variable slots own tail entries only: ck = 0) */
+        (void)tot;
+        {
+          const int k1 = s->tile_slots > s->tile_vslots ? s->tile_ck[s->tile_vslots] : 0;
+          const int k2 = s->tile_slots > s->tile_vslots + 1 ? s->tile_ck[s->tile_vslots + 1] : 0;
+          int t, okv = 1;
+          for (t = 0; t < s->tile_vslots; t++) if (s->tile_ck[t] > 0) okv = 0;
+          s->tile_tk = 0;
+          for (t = 16; t <= 32; t += 8) if (k1 <= (3 * t) / 4 && k2 <= t / 4) { s->tile_tk = t; break; }
+          if (!okv || !s->tile_tk || s->tile_vslots != 1 || s->tile_slots - s->tile_vslots > 2) { s->tile_admm_ok = 0; s->tile_tk = 16; }
+        }
+      }
+      s->po_cmap = words; words += (s->tile_tk / 2) * 64;
+      s->po_crow = words; words += (s->tile_tk / 2) * 64;
+    }
+  }
   blob = (int *)calloc((size_t)words + 4, sizeof(int));
   if (!blob) goto out;
 
@@ -199,7 +253,6 @@ int rldl_plan_build(rldl_symbolic *s) {
     blob[s->po_gflag + k] = coloff[g0] >= 0 ? 1 : 0;         /* 1: the group has a packed triangle to sweep */
   }
   for (i = 0; i < N; i++) blob[s->po_perm + i] = s->perm[i];
-
   /* ---- forward jagged diagonals: rows of each group by out-of-group count (descending) ---- */
   {
     unsigned short *fsig = (unsigned short *)(blob + s->po_fsig), *fcol = (unsigned short *)(blob + s->po_fcol);
@@ -323,6 +376,67 @@ int rldl_plan_build(rldl_symbolic *s) {
       { const int il = i - gstart[group_of[i]], jl = cc - gstart[group_of[i]];
         s->LtoS[pcsc] = slot_of_csr[q] >= 0 ? slot_of_csr[q] : coloff[i] + il * (il - 1) / 2 + jl; }
     }
+  if (s->tile_ok) {                                           /* tile tables of the tail inverse */
+    const int a = s->tile_ta, tq = s->tile_tq, g = gstart[arrow_k + 1] - gstart[arrow_k];
+    unsigned *tl = (unsigned *)(blob + s->po_tlane), *tm = (unsigned *)(blob + s->po_tmap);
+    unsigned short *ts = (unsigned short *)(blob + s->po_tislot);
+    int tI[64], tJ[64], nl = 0, l, kk, slot = 0;
+    for (i = 1; i < tq; i++)                                  /* full tiles first (I > J), then the diagonal tiles */
+      for (k = 0; k < i; k++) { tI[nl] = i; tJ[nl] = k; nl++; }
+    for (i = 0; i < tq; i++) { tI[nl] = i; tJ[nl] = i; nl++; }
+    for (l = 0; l < 64; l++) tl[l] = l < nl ? (unsigned)tI[l] | ((unsigned)tJ[l] << 8) : 0xffffffffu;
+    for (l = 0; l < ((a * a + 1) / 2) * 64; l++) tm[l] = 0xffffffffu;
+    for (l = 0; l < g * 64; l++) ts[l] = 0xffffu;
+    for (kk = 0; kk < a * a; kk++) {
+      const int sr = kk / a, u = kk % a, sh = 16 * (kk & 1);
+      for (l = 0; l < nl; l++) {
+        const int row = a * tI[l] + (sr + tJ[l]) % a, col = a * tJ[l] + (u + tI[l]) % a;
+        if (row >= g || col >= row) continue;                 /* structural zero: not stored */
+        tm[(kk >> 1) * 64 + l] = (tm[(kk >> 1) * 64 + l] & ~(0xffffu << sh)) | ((unsigned)slot << sh);
+        ts[row * 64 + col] = (unsigned short)slot;
+        slot++;
+      }
+    }
+    if (slot != s->nTi) { rc = -2; goto out; }                /* cannot happen: every strictly lower entry lies in exactly one tile */
+    {                                                         /* ADMM slots: variables first, then constraints; inside a kind by decreasing
+                                                               * number of coupling entries in the position's column (ties: ascending position) */
+      int *tp = blob + s->po_tpos;
+      unsigned *cm = (unsigned *)(blob + s->po_cmap), *cr = (unsigned *)(blob + s->po_crow);
+      const int g0 = gstart[arrow_k];
+      for (l = 0; l < 3 * 64; l++) tp[l] = -1;
+      for (l = 0; l < (s->tile_tk / 2) * 64; l++) { cm[l] = 0xffffffffu; cr[l] = 0u; }
+      if (s->tile_admm_ok) {
+        kv *ord = (kv *)malloc(sizeof(kv) * (size_t)(N + 1));
+        int kind, e0 = 0, t;
+        if (!ord) goto out;
+        for (kind = 0; kind < 2; kind++) {
+          int cntk = 0, base = kind ? 64 * s->tile_vslots : 0;
+          for (i = 0; i < N; i++)
+            if ((s->perm[i] < s->n) == (kind == 0)) { ord[cntk].key = colcnt[i]; ord[cntk].idx = i; cntk++; }
+          qsort(ord, (size_t)cntk, sizeof(kv), cmp_kv_desc);
+          for (i = 0; i < cntk; i++) tp[base + i] = ord[i].idx;
+        }
+        free(ord);
+        for (t = 0; t < s->tile_slots; t++) {                 /* entries of the owner's column, ascending row, steps [e0, e0 + ck[t]) */
+          e0 = t <= s->tile_vslots ? 0 : (3 * s->tile_tk) / 4;
+          for (l = 0; l < 64; l++) {
+            const int cpos = tp[t * 64 + l];
+            int kk2 = 0;
+            if (cpos < 0) continue;
+            for (p = s->Lp[cpos]; p < s->Lp[cpos + 1]; p++) {
+              const int r = s->Li[p], kstep = e0 + kk2, sh = 16 * (kstep & 1);
+              if (group_of[r] == group_of[cpos]) continue;    /* (in-group entry of a tail column) */
+              if (kk2 >= s->tile_ck[t] || r < g0 || r >= gstart[arrow_k + 1]) { rc = -2; goto out; }   /* cannot happen on an arrowhead plan */
+              cm[(kstep >> 1) * 64 + l] = (cm[(kstep >> 1) * 64 + l] & ~(0xffffu << sh)) | ((unsigned)s->LtoS[p] << sh);
+              cr[(kstep >> 1) * 64 + l] |= (unsigned)(r - g0) << sh;
+              kk2++;
+            }
+          }
+        }
+      }
+    }
+  }
+
   /* ---- backward jagged diagonals: columns of each group by out-of-group count (descending) ---- */
   {
     unsigned short *bsig = (unsigned short *)(blob + s->po_bsig);
@@ -369,7 +483,7 @@ int rldl_plan_build(rldl_symbolic *s) {
 out:
   if (rc == 0 && !s->plan_ok) {                               /* identity layout for the generic kernels */
     for (p = 0; p < s->nnzL; p++) s->LtoS[p] = p;
-    s->nS = s->nnzL; s->nO = s->nnzL; s->nOp = s->nnzL; s->ngroups = 0; s->arrow_ok = 0;
+    s->nS = s->nnzL; s->nO = s->nnzL; s->nOp = s->nnzL; s->ngroups = 0; s->arrow_ok = 0; s->tile_ok = 0;
   }
   free(group_of); free(gstart); free(col_active); free(row_active); free(coloff); free(rowcnt); free(colcnt);
   free(fpos_of_row); free(bpos_of_col); free(order); free(slot_of_csr);

@@ -57,7 +57,31 @@ typedef struct {
       po_fsc, po_bsb, po_bsc, po_fsig, po_bsig, po_fcol, po_brs, po_perm, po_avmap, po_avcol, po_avrow;
   int nOp;                     /* nO rounded up to even: first triangle slot */
   int arrow_ok, arrow_group, arrow_steps; /* arrowhead specialisation (see rldl_plan.c) */
-  int arrow_vsteps, arrow_vrows;          /* virtual rows: coupling rows cut into pieces of <= vsteps entries, one piece per lane */        /* word offsets of the sub-arrays inside `plan` */
+  int arrow_vsteps, arrow_vrows;          /* virtual rows: coupling rows cut into pieces of <= vsteps entries, one piece per lane */
+  /* tail inverse by register tiles (k_tile_* kernels): the g x g unit lower triangle of the tail group is inverted at
+   * factor time and its strictly lower part is cut into ta x ta tiles, one tile per lane (tq tiles per side, full tiles
+   * first, then the diagonal tiles).  Register k = s * ta + u of the lane that owns tile (I, J) holds
+   * Linv(ta I + (s + J) % ta, ta J + (u + I) % ta): rows rotated by J, columns by I, so the LDS atomics of lanes that share a
+   * block row / block column start at different addresses.  Values live in their own array Ti[batch][ldTi] in (k, lane)
+   * order, structural zeros (diagonal tiles, rows >= g) are not stored.
+   *   po_tlane  [64]                 I | J << 8, 0xffffffff for lanes without a tile
+   *   po_tmap   [ceil(ta^2 / 2)][64] slot(k even) | slot(k odd) << 16, 0xffff = structural zero
+   *   po_tislot [g][32]              u16 [g][64]: slot of Linv(i, c) for lane c, 0xffff where c >= i (inverse kernel) */
+  int tile_ok, tile_ta, tile_tq, tile_lanes, nTi;
+  int po_tlane, po_tmap, po_tislot;
+  /* ADMM slots of the tile kernels: the permuted positions are dealt to (slot, lane) so that a slot holds variables only or
+   * constraints only (uniform code per slot, no per-lane role test): po_tpos [3][64] = permuted position or -1;
+   * tile_vslots = number of leading variable slots, tile_slots = slots in use (<= 3; more -> tile_admm_ok = 0) */
+  int tile_admm_ok, tile_vslots, tile_slots, po_tpos;
+  /* Backward coupling product as a GATHER by the owner of each head entry (scattered ds_add_f64 costs ~14 LDS cycles per
+   * instruction, a read 2-5): the lane that owns position c in slot t also holds the entries L(r, c) of column c (a second
+   * register copy of the coupling values) and sums L(r, c) x_r itself.  Positions are dealt to the slots of their kind by
+   * decreasing column count, so slot t needs tile_ck[t] = (count of its first column) steps.  Head entries must all be
+   * constraints (ck = 0 for the variable slots) in at most two constraint slots: the first one's columns take steps
+   * [0, 3 tk / 4), the second one's [3 tk / 4, tk) -- a compile-time split; tile_tk = 16 / 24 / 32, the smallest that fits.
+   *   po_cmap [tile_tk / 2][64]  factor slot(k even) | slot(k odd) << 16, 0xffff = none
+   *   po_crow [tile_tk / 2][64]  same packing: row of the entry, local to the tail group */
+  int tile_ck[3], tile_tk, po_cmap, po_crow;
   /* problem matrices for the residual kernels: CSC as given plus row-order (CSR) access maps */
   int *Pp, *Pi, *Prp, *Prj, *Prpos;   /* P upper triangular n x n */
   int *Ap, *Ai, *Arp, *Arj, *Arpos;   /* A m x n */

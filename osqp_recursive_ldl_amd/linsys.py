@@ -266,7 +266,7 @@ def plan_export(P, A, polish=0, perm=None):
     Pc = P if isinstance(P, CscPattern) else CscPattern(P)
     Ac = A if isinstance(A, CscPattern) else CscPattern(A)
     pm = None if perm is None else np.ascontiguousarray(perm, dtype=np.int64)
-    meta = np.zeros(32, np.int64)
+    meta = np.zeros(48, np.int64)
     if L.rldl_plan_export(Pc.ref, Ac.ref, int(polish), None if pm is None else _ip(pm), _ip(meta), None, 0, None):
         raise ValueError("rldl_plan_export failed")
     words, nnzL = int(meta[4]), int(meta[20])
@@ -276,7 +276,9 @@ def plan_export(P, A, polish=0, perm=None):
                        blob.ctypes.data_as(C.POINTER(C.c_int)), words, _ip(LtoS))
     names = ["plan_ok", "nS", "nO", "ngroups", "plan_words", "po_gstart", "po_gflag", "po_gToff", "po_fsp", "po_bsp", "po_fsb",
              "po_fsc", "po_bsb", "po_bsc", "po_fsig", "po_bsig", "po_fcol", "po_brs", "po_perm", "N", "nnzL", "arrow_ok", "arrow_group",
-             "arrow_vsteps", "arrow_vrows", "po_avmap", "po_avcol", "po_avrow", "nOp"]
+             "arrow_vsteps", "arrow_vrows", "po_avmap", "po_avcol", "po_avrow", "nOp", "tile_ok", "tile_ta", "tile_tq", "tile_lanes", "nTi",
+             "po_tlane", "po_tmap", "po_tislot", "tile_admm_ok", "tile_vslots", "tile_slots", "po_tpos", "tile_ck0", "tile_ck1",
+             "tile_ck2", "tile_tk", "po_cmap", "po_crow"]
     out = {k: int(meta[i]) for i, k in enumerate(names)}
     out["blob"] = blob[:words]
     out["LtoS"] = LtoS[:nnzL]

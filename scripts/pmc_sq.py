@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Reduce a rocprofv3 --pmc pass of SQ counters to per-wave-iteration figures for k_arrow_admm (scripts/pmc_run.py)."""
 import csv, glob, json, os, sys
-d = sys.argv[1]; kern = "k_arrow_admm"
+d = sys.argv[1]; kern = sys.argv[2] if len(sys.argv) > 2 else "k_arrow_admm"
 acc = {}
 for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
     for row in csv.DictReader(open(f)):

@@ -230,7 +230,7 @@ def test_virtual_row_tables_cover_every_coupling_entry_once(case):
     if not pl["arrow_ok"]:
         pytest.skip("not an arrowhead plan")
     T, nv = pl["arrow_vsteps"], pl["arrow_vrows"]
-    Tp = next(v for v in (8, 12, 14, 16, 18, 24, (T + 1) & ~1) if T <= v)      # register bound the tables are padded to
+    Tp = next(v for v in (12, 18, 24, (T + 1) & ~1) if T <= v)      # register bound the tables are padded to
     blob = pl["blob"].view(np.uint32)
     half = (Tp + 1) // 2
     vmap = blob[pl["po_avmap"]:pl["po_avmap"] + half * 64].reshape(half, 64)
@@ -272,3 +272,64 @@ def test_virtual_row_tables_cover_every_coupling_entry_once(case):
     rows = np.bincount([r - g0 for r, _ in want.values()], minlength=g1 - g0)
     pieces = lambda tt: int(sum((int(v) + tt - 1) // tt for v in rows))
     assert pieces(T) == nv <= 64 and (T == 1 or pieces(T - 1) > 64)
+
+
+@pytest.mark.parametrize("case", ["arrowhead", "small", "g30"])
+def test_tile_tables_reproduce_the_products_with_the_tail_inverse(case):
+    """Tile plan of the arrowhead tail (csrc/rldl_plan.c, "tail inverse by register tiles"): the strictly lower part of
+    Linv = L22^-1 is cut into ta x ta tiles, one per lane, rows rotated by the tile's block column and columns by its block
+    row.  Emulates what a lane of k_tile_* does with the tables (po_tlane, po_tmap, po_tislot) on a random unit lower
+    triangle: every strictly lower entry is stored exactly once, in (register, lane) order, and the forward / backward
+    lane products followed by the atomic adds give Linv c and Linv' w."""
+    from osqp_recursive_ldl_amd.linsys import plan_export
+    wl = {"arrowhead": lambda: R.workloads.SharedPatternQPs(),
+          "small": lambda: R.workloads.SharedPatternQPs(n=20, m=35, density=0.2, pattern_seed=5),
+          "g30": lambda: R.workloads.SharedPatternQPs(n=30, m=60, density=0.2, pattern_seed=3)}[case]()
+    pl = plan_export(wl.P_pattern, wl.A_pattern)
+    if not pl["tile_ok"]:
+        pytest.skip("no tile plan")
+    gs = pl["blob"][pl["po_gstart"]:pl["po_gstart"] + pl["ngroups"] + 1]
+    g = int(gs[pl["arrow_group"] + 1] - gs[pl["arrow_group"]])
+    a, tq, nl, nTi = pl["tile_ta"], pl["tile_tq"], pl["tile_lanes"], pl["nTi"]
+    assert a in (2, 3, 5, 7) and tq == -(-g // a) and nl == tq * (tq + 1) // 2 <= 64 and nTi == g * (g - 1) // 2
+    blob = pl["blob"].view(np.uint32)
+    tl = blob[pl["po_tlane"]:pl["po_tlane"] + 64]
+    half = (a * a + 1) // 2
+    tm = blob[pl["po_tmap"]:pl["po_tmap"] + half * 64].reshape(half, 64)
+    ts = pl["blob"][pl["po_tislot"]:pl["po_tislot"] + g * 32].view(np.uint16).reshape(g, 64)
+    rng = np.random.default_rng(11)
+    L = np.tril(rng.standard_normal((g, g)), -1) * 0.3 + np.eye(g)
+    Linv = np.linalg.inv(L)
+    Ti = np.full(nTi, np.nan)
+    for i in range(g):                                    # what k_tile_invert stores: lane c of row i -> slot
+        for c in range(64):
+            if ts[i, c] != 0xffff:
+                assert c < i and np.isnan(Ti[ts[i, c]])
+                Ti[ts[i, c]] = Linv[i, c]
+    assert not np.isnan(Ti).any()
+    slot = lambda k, lane: int((tm[k >> 1, lane] >> (16 * (k & 1))) & 0xffff)
+    # slots are handed out in (register, lane) order: the loads of one register are one contiguous run
+    seq = [slot(k, lane) for k in range(a * a) for lane in range(64) if slot(k, lane) != 0xffff]
+    assert seq == list(range(nTi))
+    cvec, wvec = rng.standard_normal(a * tq), rng.standard_normal(a * tq)
+    cvec[g:] = 0.0; wvec[g:] = 0.0                        # padding rows of the last block row
+    y, x = cvec.copy(), wvec.copy()
+    for lane in range(64):
+        if tl[lane] == 0xffffffff:
+            assert lane >= nl and all(slot(k, lane) == 0xffff for k in range(a * a))
+            continue
+        I, J = int(tl[lane] & 0xff), int((tl[lane] >> 8) & 0xff)
+        assert J <= I < tq
+        T = np.array([[Ti[slot(s * a + u, lane)] if slot(s * a + u, lane) != 0xffff else 0.0 for u in range(a)] for s in range(a)])
+        rows = [a * I + (s + J) % a for s in range(a)]
+        cols = [a * J + (u + I) % a for u in range(a)]
+        for s in range(a):
+            for u in range(a):
+                if rows[s] < g and cols[u] < rows[s]:
+                    assert T[s, u] == Linv[rows[s], cols[u]]
+                else:
+                    assert T[s, u] == 0.0
+        y[rows] += T @ cvec[cols]                         # tile_fwd: reads of c precede the adds
+        x[cols] += T.T @ wvec[rows]                       # tile_bwd
+    assert np.allclose(y[:g], Linv @ cvec[:g], rtol=1e-13, atol=1e-13)
+    assert np.allclose(x[:g], Linv.T @ wvec[:g], rtol=1e-13, atol=1e-13)
