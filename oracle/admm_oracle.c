@@ -23,6 +23,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <pthread.h>
 #include <time.h>
 #include "osqp_oracle.h"
 
@@ -702,4 +703,63 @@ double orc_bench_shared_pattern(orc_int count, orc_int n, orc_int m, const orc_i
   if (t_factor) *t_factor = tf;
   if (t_solve) *t_solve = ts;
   return tf + ts;
+}
+
+/* The same per-instance work on `nthreads` host threads (bench.py, "all cores" leg of cpu_baseline): the reference is
+ * single-threaded per instance (lin_sys/direct/qdldl/qdldl_interface.c:208-209), so the all-core figure is one instance
+ * per task.  Thread t runs instances t, t + nthreads, ... (cyclically over the `ndata` instances given), count_per_thread of
+ * them.  Returns the wall-clock seconds from before the first thread starts to after the last one has finished
+ * (clock_gettime(CLOCK_MONOTONIC), as osqp_tic / osqp_toc, src/util.c:317-337), or -1. */
+typedef struct {
+  orc_int t, nthreads, count, ndata, n, m;
+  const orc_int *Pp, *Pi, *Ap, *Ai, *perm;
+  const orc_float *Px, *Ax, *q, *l, *u;
+  const orc_settings *settings;
+  int failed;
+} orc_mt_job;
+
+static void *orc_mt_worker(void *arg) {
+  orc_mt_job *j = (orc_mt_job *)arg;
+  orc_int k, nnzP = j->Pp[j->n], nnzA = j->Ap[j->n];
+  orc_csc P, A;
+  P.m = j->n; P.n = j->n; P.nzmax = nnzP; P.nz = -1; P.p = (orc_int *)j->Pp; P.i = (orc_int *)j->Pi;
+  A.m = j->m; A.n = j->n; A.nzmax = nnzA; A.nz = -1; A.p = (orc_int *)j->Ap; A.i = (orc_int *)j->Ai;
+  for (k = 0; k < j->count; k++) {
+    const orc_int b = (j->t + k * j->nthreads) % j->ndata;
+    orc_workspace *w;
+    P.x = (orc_float *)(j->Px + b * nnzP);
+    A.x = (orc_float *)(j->Ax + b * nnzA);
+    if (orc_setup(&w, &P, j->q + b * j->n, &A, j->l + b * j->m, j->u + b * j->m, j->settings, j->perm)) { j->failed = 1; return 0; }
+    orc_solve(w);
+    orc_cleanup(w);
+  }
+  return 0;
+}
+
+double orc_bench_shared_pattern_mt(orc_int nthreads, orc_int count_per_thread, orc_int ndata, orc_int n, orc_int m,
+                                   const orc_int *Pp, const orc_int *Pi, const orc_float *Px_all, const orc_int *Ap,
+                                   const orc_int *Ai, const orc_float *Ax_all, const orc_float *q_all, const orc_float *l_all,
+                                   const orc_float *u_all, const orc_settings *settings, const orc_int *perm_in) {
+  pthread_t *th;
+  orc_mt_job *jobs;
+  orc_int t, started = 0;
+  double t0, t1;
+  int bad = 0;
+  if (nthreads <= 0 || ndata <= 0 || count_per_thread <= 0) return -1.;
+  th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)nthreads);
+  jobs = (orc_mt_job *)calloc((size_t)nthreads, sizeof(orc_mt_job));
+  if (!th || !jobs) { free(th); free(jobs); return -1.; }
+  t0 = now_s();
+  for (t = 0; t < nthreads; t++) {
+    orc_mt_job *j = jobs + t;
+    j->t = t; j->nthreads = nthreads; j->count = count_per_thread; j->ndata = ndata; j->n = n; j->m = m;
+    j->Pp = Pp; j->Pi = Pi; j->Ap = Ap; j->Ai = Ai; j->perm = perm_in;
+    j->Px = Px_all; j->Ax = Ax_all; j->q = q_all; j->l = l_all; j->u = u_all; j->settings = settings;
+    if (pthread_create(th + t, 0, orc_mt_worker, j)) { bad = 1; break; }
+    started++;
+  }
+  for (t = 0; t < started; t++) { pthread_join(th[t], 0); if (jobs[t].failed) bad = 1; }
+  t1 = now_s();
+  free(th); free(jobs);
+  return bad ? -1. : t1 - t0;
 }

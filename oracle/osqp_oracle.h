@@ -185,6 +185,11 @@ double orc_bench_shared_pattern(orc_int count, orc_int n, orc_int m, const orc_i
                                 const orc_float *u_all, const orc_settings *settings,
                                 const orc_int *perm_in, orc_float *x_out, orc_float *y_out,
                                 double *t_factor, double *t_solve);
+/* the same work on nthreads host threads, one instance per task; returns wall seconds (admm_oracle.c) */
+double orc_bench_shared_pattern_mt(orc_int nthreads, orc_int count_per_thread, orc_int ndata, orc_int n, orc_int m,
+                                   const orc_int *Pp, const orc_int *Pi, const orc_float *Px_all, const orc_int *Ap,
+                                   const orc_int *Ai, const orc_float *Ax_all, const orc_float *q_all, const orc_float *l_all,
+                                   const orc_float *u_all, const orc_settings *settings, const orc_int *perm_in);
 
 #ifdef __cplusplus
 }

@@ -12,6 +12,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 LIB_PATH = os.path.join(ORACLE_DIR, "liboracle.so")
+LIB_PATH_OFAST = os.path.join(ORACLE_DIR, "liboracle_ofast.so")   # same sources, the reference's shipped flags (bench.py only)
 
 c_int = C.c_longlong
 c_float = C.c_double
@@ -38,7 +39,7 @@ class Info(C.Structure):
 
 
 def build(force=False):
-    if force or not os.path.exists(LIB_PATH) or any(
+    if force or not os.path.exists(LIB_PATH) or not os.path.exists(LIB_PATH_OFAST) or any(
             os.path.getmtime(os.path.join(ORACLE_DIR, f)) > os.path.getmtime(LIB_PATH)
             for f in os.listdir(ORACLE_DIR) if f.endswith((".c", ".h"))):
         subprocess.check_call(["make", "-s", "-C", ORACLE_DIR])
@@ -103,10 +104,35 @@ def lib():
                                                C.POINTER(Settings), IP, FP, FP, C.POINTER(C.c_double),
                                                C.POINTER(C.c_double)]
         L.orc_bench_shared_pattern.restype = C.c_double
+        _bind_bench_mt(L)
         for nm in ("orc_rldl_factor", ):
             pass
         _lib = L
     return _lib
+
+
+def _bind_bench_mt(L):
+    L.orc_bench_shared_pattern_mt.argtypes = [c_int, c_int, c_int, c_int, c_int, IP, IP, FP, IP, IP, FP, FP, FP, FP,
+                                              C.POINTER(Settings), IP]
+    L.orc_bench_shared_pattern_mt.restype = C.c_double
+
+
+_lib_ofast = None
+
+
+def lib_ofast():
+    """The -Ofast build (bench.py's cpu_baseline): only the two bench entry points are bound."""
+    global _lib_ofast
+    if _lib_ofast is None:
+        build()
+        L = C.CDLL(LIB_PATH_OFAST)
+        L.orc_bench_shared_pattern.argtypes = [c_int, c_int, c_int, IP, IP, FP, IP, IP, FP, FP, FP, FP,
+                                               C.POINTER(Settings), IP, FP, FP, C.POINTER(C.c_double),
+                                               C.POINTER(C.c_double)]
+        L.orc_bench_shared_pattern.restype = C.c_double
+        _bind_bench_mt(L)
+        _lib_ofast = L
+    return _lib_ofast
 
 
 def ip(a):
