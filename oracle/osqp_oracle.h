@@ -194,4 +194,11 @@ double orc_bench_shared_pattern_mt(orc_int nthreads, orc_int count_per_thread, o
 #ifdef __cplusplus
 }
 #endif
+/* ---- stage recursion (src/recursive_ldl.c:554-1318, src/cs_addon.c), rldl_oracle.c ---- */
+typedef struct { orc_int N, nx, nu, ny, nt; } orc_stage_dims;
+orc_int orc_rldl_xeven_stride(const orc_stage_dims *d);
+orc_int orc_rldl_factor(const orc_stage_dims *d, const orc_csc *P, const orc_csc *A, orc_float sigma, const orc_float *rho_inv,
+                        orc_int Nmax, orc_int mirror_drops, orc_int terminal_rho_own, orc_int iter_start, orc_float *xeven,
+                        orc_int *Lp, orc_int *Li, orc_float *Lx, orc_int Lcap, orc_float *Dinv, orc_int *perm);
+
 #endif

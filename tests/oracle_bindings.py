@@ -33,6 +33,10 @@ class Settings(C.Structure):
                 ("polish", c_int), ("polish_refine_iter", c_int), ("delta", c_float)]
 
 
+class StageDims(C.Structure):
+    _fields_ = [("N", c_int), ("nx", c_int), ("nu", c_int), ("ny", c_int), ("nt", c_int)]
+
+
 class Info(C.Structure):
     _fields_ = [("iter", c_int), ("status_val", c_int), ("rho_updates", c_int), ("obj_val", c_float),
                 ("pri_res", c_float), ("dua_res", c_float), ("rho_estimate", c_float), ("status_polish", c_int)]
@@ -105,8 +109,11 @@ def lib():
                                                C.POINTER(C.c_double)]
         L.orc_bench_shared_pattern.restype = C.c_double
         _bind_bench_mt(L)
-        for nm in ("orc_rldl_factor", ):
-            pass
+        L.orc_rldl_xeven_stride.argtypes = [C.POINTER(StageDims)]
+        L.orc_rldl_xeven_stride.restype = c_int
+        L.orc_rldl_factor.argtypes = [C.POINTER(StageDims), C.POINTER(Csc), C.POINTER(Csc), c_float, FP, c_int, c_int, c_int, c_int, FP,
+                                      IP, IP, FP, c_int, FP, IP]
+        L.orc_rldl_factor.restype = c_int
         _lib = L
     return _lib
 
@@ -225,6 +232,37 @@ class OracleLinsys:
             self.free()
         except Exception:
             pass
+
+
+class OracleRLDL:
+    """The stage recursion of src/recursive_ldl.c (oracle/rldl_oracle.c): LDL_factorize_recursive on the assembled P, A of an
+    MPC problem, LDL_update_from_pivot restarts from the cached constraint block of a stage."""
+
+    def __init__(self, dims, mirror_drops=0, terminal_rho_own=1, Nmax=None):
+        self.d = StageDims(*[int(v) for v in dims])
+        N, nx, nu, ny, nt = [int(v) for v in dims]
+        self.n, self.m = N * (nx + nu), N * (nx + ny) + nt
+        self.mirror, self.own, self.Nmax = int(mirror_drops), int(terminal_rho_own), int(N if Nmax is None else Nmax)
+        Nk = self.n + self.m
+        smax = max(nx + ny, nx + nu, nt)
+        self.cap = (2 * N + 2) * 2 * smax * smax
+        self.xeven = np.zeros((N + 1) * int(lib().orc_rldl_xeven_stride(C.byref(self.d))))
+        self.Lp = np.zeros(Nk + 1, np.int64); self.Li = np.zeros(self.cap, np.int64); self.Lx = np.zeros(self.cap)
+        self.Dinv = np.zeros(Nk); self.perm = np.zeros(Nk, np.int64)
+        self.nnz = -100
+
+    def factor(self, P, A, sigma, rho_inv, iter_start=-1):
+        Pc, Ac = CscHolder.from_scipy(P), CscHolder.from_scipy(A)
+        ri = np.ascontiguousarray(rho_inv, dtype=np.float64)
+        self.nnz = int(lib().orc_rldl_factor(C.byref(self.d), Pc.ref, Ac.ref, sigma, fp(ri), self.Nmax, self.mirror, self.own,
+                                             int(iter_start), fp(self.xeven), ip(self.Lp), ip(self.Li), fp(self.Lx), self.cap,
+                                             fp(self.Dinv), ip(self.perm)))
+        return self.nnz
+
+    def L(self):
+        from scipy import sparse
+        Nk = self.n + self.m
+        return sparse.csc_matrix((self.Lx[:self.nnz].copy(), self.Li[:self.nnz].copy(), self.Lp.copy()), shape=(Nk, Nk))
 
 
 class OracleOSQP:
