@@ -187,6 +187,12 @@ static void set_rho_vec(orc_workspace *w) { /* auxil.c:79-101 */
   }
 }
 
+/* update_rho_vec of whichever backend is in use (work->linsys_solver->update_rho_vec, osqp.c:1310-1318) */
+static orc_int ws_update_rho_vec(orc_workspace *w) {
+  if (w->ext_update_rho_vec) return w->ext_update_rho_vec(w->ext_self, w->rho_vec);
+  return orc_linsys_update_rho_vec(w->linsys, w->rho_vec);
+}
+
 static orc_int update_rho_vec(orc_workspace *w) { /* auxil.c:103-145 */
   orc_int i, changed = 0;
   for (i = 0; i < w->m; i++) {
@@ -204,7 +210,7 @@ static orc_int update_rho_vec(orc_workspace *w) { /* auxil.c:103-145 */
       w->rho_inv_vec[i] = 1. / w->settings.rho; changed = 1;
     }
   }
-  if (changed) return orc_linsys_update_rho_vec(w->linsys, w->rho_vec);
+  if (changed) return ws_update_rho_vec(w);
   return 0;
 }
 
@@ -218,7 +224,7 @@ orc_int orc_update_rho(orc_workspace *w, orc_float rho_new) { /* osqp.c:1268-131
       w->rho_vec[i] = RHO_EQ_OVER_RHO_INEQ * w->settings.rho; w->rho_inv_vec[i] = 1. / w->rho_vec[i];
     }
   }
-  return orc_linsys_update_rho_vec(w->linsys, w->rho_vec);
+  return ws_update_rho_vec(w);
 }
 
 static orc_float compute_rho_estimate(orc_workspace *w) { /* auxil.c:13-55 */
@@ -300,7 +306,8 @@ static void update_xz_tilde(orc_workspace *w) { /* auxil.c:164-186 */
   orc_int i, n = w->n, m = w->m;
   for (i = 0; i < n; i++) w->xz_tilde[i] = w->settings.sigma * w->x_prev[i] - w->q[i];
   for (i = 0; i < m; i++) w->xz_tilde[i + n] = w->z_prev[i] - w->rho_inv_vec[i] * w->y[i];
-  orc_linsys_solve(w->linsys, w->xz_tilde);
+  if (w->ext_solve) w->ext_solve(w->ext_self, w->xz_tilde);      /* work->linsys_solver->solve(...), auxil.c:185 */
+  else orc_linsys_solve(w->linsys, w->xz_tilde);
 }
 static void update_x(orc_workspace *w) { /* auxil.c:188-201 */
   orc_int i;
@@ -662,6 +669,13 @@ orc_float *orc_ws_sol_x(orc_workspace *w) { return w->sol_x; }
 orc_float *orc_ws_sol_y(orc_workspace *w) { return w->sol_y; }
 orc_info  *orc_ws_info(orc_workspace *w) { return &w->info; }
 orc_linsys *orc_ws_linsys(orc_workspace *w) { return w->linsys; }
+void orc_use_external_linsys(orc_workspace *w, void *self, orc_int (*solve)(void *, orc_float *),
+                             orc_int (*update_rho_vec)(void *, const orc_float *)) {
+  w->ext_self = self; w->ext_solve = solve; w->ext_update_rho_vec = update_rho_vec;
+}
+const orc_csc *orc_ws_P(const orc_workspace *w) { return w->P; }
+const orc_csc *orc_ws_A(const orc_workspace *w) { return w->A; }
+const orc_float *orc_ws_rho_vec(const orc_workspace *w) { return w->rho_vec; }
 orc_float *orc_ws_delta_x(orc_workspace *w) { return w->delta_x; }
 orc_float *orc_ws_delta_y(orc_workspace *w) { return w->delta_y; }
 orc_float *orc_ws_D(orc_workspace *w) { return w->D; }

@@ -144,7 +144,18 @@ typedef struct {
   orc_info     info;
   orc_linsys  *linsys;
   orc_int     *perm;               /* optional fixed permutation handed to the backend */
+  /* optional EXTERNAL linear-system plugin with the reference's vtable shape (include/types.h:298-319): when set, the ADMM
+   * loop calls it where osqp.c / auxil.c call work->linsys_solver->solve / ->update_rho_vec (auxil.c:185, osqp.c:1310-1318).
+   * Tests hand the HIP plugin object in here to drive it through the reference's own call sites (config 1). */
+  void        *ext_self;
+  orc_int    (*ext_solve)(void *self, orc_float *b);
+  orc_int    (*ext_update_rho_vec)(void *self, const orc_float *rho_vec);
 } orc_workspace;
+void orc_use_external_linsys(orc_workspace *w, void *self, orc_int (*solve)(void *, orc_float *),
+                             orc_int (*update_rho_vec)(void *, const orc_float *));
+const orc_csc *orc_ws_P(const orc_workspace *w);         /* the (scaled) data the backend must be initialised with */
+const orc_csc *orc_ws_A(const orc_workspace *w);
+const orc_float *orc_ws_rho_vec(const orc_workspace *w);
 
 void    orc_set_default_settings(orc_settings *s);
 orc_int orc_setup(orc_workspace **wp, const orc_csc *P, const orc_float *q, const orc_csc *A,

@@ -21,9 +21,11 @@ Suites (reference file -> fixture):
     tests/unconstrained/generate_problem.py             -> unconstrained.json
     tests/primal_dual_infeasibility/generate_problem.py -> primal_dual_infeasibility.json
     tests/lin_alg/generate_problem.py                   -> lin_alg.json
-    tests/primal_infeasibility/generate_problem.py      -> NOT generated: the script calls
-        `scipy.randn`, which current scipy no longer has (ordinary AttributeError).  The
-        counterpart fixture is produced by tests/golden/make_synthetic.py with numpy's generator.
+    tests/primal_infeasibility/generate_problem.py      -> primal_infeasibility.json, RE-SEEDED: the script draws q, l, u
+        with `scipy.randn` (:17, :19-20), which current scipy no longer has (ordinary AttributeError) and which drew from
+        numpy's unseeded global state anyway (the reference's own data.h is not reproducible).  The generator is imported
+        unchanged with `scipy.randn` bound to numpy's Generator(PCG64(20261004)).standard_normal, so P, A and the
+        infeasible row pair come from the script's own PCG64(2) stream and q, l, u from that recorded seed.
 """
 import importlib
 import json
@@ -90,6 +92,11 @@ def main():
     sys.dont_write_bytecode = True
     suites = ["solve_linsys", "update_matrices", "basic_qp", "basic_qp2", "non_cvx",
               "unconstrained", "primal_dual_infeasibility", "lin_alg"]
+    import scipy
+    if not hasattr(scipy, "randn"):                          # removed from the scipy namespace; see the module docstring
+        _rs = np.random.Generator(np.random.PCG64(20261004))
+        scipy.randn = lambda *shape: _rs.standard_normal(shape if len(shape) != 1 else shape[0])
+    suites.append("primal_infeasibility")
     for s in suites:
         importlib.import_module(s + ".generate_problem")
         if s not in _captured:

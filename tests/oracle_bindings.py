@@ -104,6 +104,11 @@ def lib():
         L.orc_ws_info.restype = C.POINTER(Info)
         L.orc_ws_linsys.argtypes = [VP]
         L.orc_ws_linsys.restype = VP
+        L.orc_use_external_linsys.argtypes = [VP, VP, VP, VP]
+        L.orc_use_external_linsys.restype = None
+        L.orc_ws_P.argtypes = [VP]; L.orc_ws_P.restype = C.POINTER(Csc)
+        L.orc_ws_A.argtypes = [VP]; L.orc_ws_A.restype = C.POINTER(Csc)
+        L.orc_ws_rho_vec.argtypes = [VP]; L.orc_ws_rho_vec.restype = FP
         L.orc_bench_shared_pattern.argtypes = [c_int, c_int, c_int, IP, IP, FP, IP, IP, FP, FP, FP, FP,
                                                C.POINTER(Settings), IP, FP, FP, C.POINTER(C.c_double),
                                                C.POINTER(C.c_double)]
@@ -292,6 +297,24 @@ class OracleOSQP:
                     x_iter=self._vec(lib().orc_ws_x, self.n), y_iter=self._vec(lib().orc_ws_y, self.m),
                     z_iter=self._vec(lib().orc_ws_z, self.m), delta_x=self._vec(lib().orc_ws_delta_x, self.n),
                     delta_y=self._vec(lib().orc_ws_delta_y, self.m))
+
+    def backend_data(self):
+        """What the workspace hands to init_linsys_solver (osqp.c:157-160): the (scaled) P, A, sigma and rho_vec."""
+        from scipy import sparse
+
+        def mat(cp):
+            c = cp.contents
+            nz = int(c.p[c.n])
+            return sparse.csc_matrix((np.array(c.x[:nz], float), np.array(c.i[:nz], np.int64), np.array(c.p[:c.n + 1], np.int64)),
+                                     shape=(int(c.m), int(c.n)))
+        rv = np.array(lib().orc_ws_rho_vec(self.h)[:self.m], float)
+        return mat(lib().orc_ws_P(self.h)), mat(lib().orc_ws_A(self.h)), float(self.st.sigma), rv
+
+    def use_external_linsys(self, self_ptr, solve_fn, update_rho_vec_fn):
+        """Route the ADMM loop's linear solves through an external plugin object with the reference's vtable shape
+        (work->linsys_solver->solve / ->update_rho_vec, auxil.c:185, osqp.c:1310-1318)."""
+        cast = lambda f: C.cast(f, C.c_void_p)
+        lib().orc_use_external_linsys(self.h, C.cast(self_ptr, C.c_void_p), cast(solve_fn), cast(update_rho_vec_fn))
 
     def scaling_vectors(self):
         lib().orc_ws_c.restype = C.c_double

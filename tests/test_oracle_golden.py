@@ -220,6 +220,18 @@ def test_primal_dual_infeasibility_golden():
             assert abs(r["obj"] - obj) < TESTS_TOL
 
 
+def test_primal_infeasibility_golden():
+    """tests/primal_infeasibility/test_primal_infeasibility.h:27-52 (n = 50, m = 150, two parallel rows with disjoint bounds):
+    OSQP_PRIMAL_INFEASIBLE with the reference's settings.  Fixture re-seeded, see tests/golden/make_golden.py."""
+    d = load_golden("primal_infeasibility")
+    assert d["sols"]["status_test"] == "primal_infeasible"
+    w = ob.OracleOSQP(d["P"], d["q"], d["A"], osqp_inf(d["l"]), osqp_inf(d["u"]), max_iter=10000, alpha=1.6, polish=1, scaling=0,
+                      warm_start=0)
+    r = w.solve()
+    assert r["status"] == ob_status("primal_infeasible")
+    assert r["obj"] == 1e30 or r["obj"] > 1e29                 # OSQP_INFTY (osqp.c:565-569)
+
+
 def test_lin_alg_golden_spmv():
     """tests/lin_alg/test_lin_alg.h mat_vec / mat_tpose_vec: the oracle's residual SpMVs are pinned
     indirectly through the ADMM tests; here we pin the fixture algebra itself so the GPU tests can
