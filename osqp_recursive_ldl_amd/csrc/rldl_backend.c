@@ -244,6 +244,7 @@ void rldl_batch_free(rldl_batch *h) {
   if (h->num.Ti) (void)hipFree(h->num.Ti);
   if (h->num.rho_inv) (void)hipFree(h->num.rho_inv);
   if (h->num.status) (void)hipFree(h->num.status);
+  if (h->num.fail) (void)hipFree(h->num.fail);
   if (h->ev0) (void)hipEventDestroy((hipEvent_t)h->ev0);
   if (h->ev1) (void)hipEventDestroy((hipEvent_t)h->ev1);
   rldl_symbolic_free(h->sym);
@@ -254,13 +255,17 @@ void rldl_batch_free(rldl_batch *h) {
 /* numeric factor of every (masked) instance + host-side verdict, qdldl_interface.c:80-92 */
 static c_int collect_status(rldl_batch *h) {
   c_int b, bad = 0;
+  int sticky = 0;
   if (!HIP_OK(hipMemcpyAsync(h->status_host, h->num.status, sizeof(int) * (size_t)h->batch, hipMemcpyDeviceToHost,
                              (hipStream_t)h->stream)))
     return RLDL_LINSYS_SOLVER_INIT_ERROR;
+  /* the sticky flag covers every factorisation enqueued since the last verdict, not only the last one per instance */
+  if (!HIP_OK(hipMemcpyAsync(&sticky, h->num.fail, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)h->stream))) return RLDL_LINSYS_SOLVER_INIT_ERROR;
+  if (!HIP_OK(hipMemsetAsync(h->num.fail, 0, sizeof(int), (hipStream_t)h->stream))) return RLDL_LINSYS_SOLVER_INIT_ERROR;
   if (!HIP_OK(hipStreamSynchronize((hipStream_t)h->stream))) return RLDL_LINSYS_SOLVER_INIT_ERROR;
   for (b = 0; b < h->batch; b++)
     if (h->status_host[b] < 0 || h->status_host[b] < h->sym->n) bad = 1;
-  return bad ? RLDL_NONCVX_ERROR : 0;
+  return (bad || sticky) ? RLDL_NONCVX_ERROR : 0;
 }
 
 static c_int factor_and_check(rldl_batch *h, const int *d_mask) {
@@ -295,6 +300,8 @@ static c_int batch_create(rldl_batch **hp, c_int batch, const csc *P, const csc 
   if (ok && !HIP_OK(hipMemset(h->num.F, 0, sizeof(double) * (size_t)batch * (size_t)h->dsym.ldF))) ok = 0;
   h->num.rho_inv = (double *)dev_alloc(sizeof(double) * (size_t)batch * (size_t)h->sym->m, &ok);
   h->num.status = (int *)dev_alloc(sizeof(int) * (size_t)batch, &ok);
+  h->num.fail = (int *)dev_alloc(sizeof(int), &ok);
+  if (ok && !HIP_OK(hipMemset(h->num.fail, 0, sizeof(int)))) ok = 0;
   if (ok && !HIP_OK(hipHostMalloc((void **)&h->status_host, sizeof(int) * (size_t)batch, hipHostMallocDefault))) { h->status_host = 0; ok = 0; }
   if (!ok || !h->status_host) { rldl_batch_free(h); return RLDL_MEM_ALLOC_ERROR; }   /* pinned: the status read-back can be asynchronous */
   if (!HIP_OK(hipEventCreate((hipEvent_t *)&h->ev0)) || !HIP_OK(hipEventCreate((hipEvent_t *)&h->ev1))) {

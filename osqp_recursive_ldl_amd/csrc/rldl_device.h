@@ -80,7 +80,10 @@ typedef struct {
   double *Ti;       /* [batch][ldTi]   inverse of the tail's unit lower triangle in tile order (tile_ok), else NULL */
   double *D;        /* [batch][N]      pivots (inertia check, export)           */
   double *rho_inv;  /* [batch][m]      param2 of the KKT (delta when polishing) */
-  int *status;      /* [batch]         #positive pivots, or -1 on a zero pivot */
+  int *status;      /* [batch]         #positive pivots, or -1 on a zero pivot (verdict of the LAST factorisation of the instance) */
+  int *fail;        /* [1]             sticky: set by any factorisation whose verdict is bad (zero pivot or fewer than n positive
+                     *                  pivots, qdldl_interface.c:80-92); only the host clears it when it reads the verdict, so a
+                     *                  failure in a stream of asynchronous refactorisations is not overwritten by a later success */
 } rldl_dev_num;
 
 /* ADMM iterate state (DEVICE pointers, instance-major) + scalar settings */
@@ -149,6 +152,8 @@ int rldl_launch_unscale_data(const rldl_dev_sym *S, const rldl_dev_admm *W, doub
 /* dst[b][i] = src[b][i] * s[b][i] * (c ? c[b] : 1) */
 int rldl_launch_ew_scale(int batch, int len, double *dst, const double *src, const double *s, const double *c, void *stream);
 int rldl_launch_matvec_A(const rldl_dev_sym *S, const rldl_dev_admm *W, const double *d_x, double *d_out, void *stream);
+/* *flag |= 1 when l[i] > u[i] for some i < count (osqp.c:805-813) */
+int rldl_launch_check_bounds(long long count, const double *l, const double *u, int *flag, void *stream);
 const char *rldl_kernel_arch(void);
 
 #ifdef __cplusplus

@@ -202,7 +202,7 @@ __global__ __launch_bounds__(WAVE) void k_factor(rldl_dev_sym S, rldl_dev_num Nn
     for (int j = lane; j < S.N; j += WAVE) Dg[j] = sh[S.nnzL + j];
   }
   for (int j = lane; j < S.N; j += WAVE) F[S.nS + j] = 1.0 / W(S.nnzL + j);   // Dinv rides behind the factor
-  if (lane == 0) Nn.status[inst] = bad ? -1 : npos;
+  if (lane == 0) { Nn.status[inst] = bad ? -1 : npos; if (Nn.fail && (bad || npos < S.n)) atomicOr(Nn.fail, 1); }   // sticky verdict, see rldl_dev_num.fail
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1781,7 +1781,7 @@ __global__ __launch_bounds__(WAVE) void k_stage_factor(rldl_dev_sym S, rldl_dev_
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) npos += __shfl_xor(npos, o);
-  if (lane == 0) Nn.status[inst] = zero ? -1 : npos;
+  if (lane == 0) { Nn.status[inst] = zero ? -1 : npos; if (Nn.fail && (zero || npos < S.n)) atomicOr(Nn.fail, 1); }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1800,30 +1800,38 @@ __device__ __forceinline__ double recip_nr(double d) {
   return x;
 }
 
-template <int SM>
+// MFMA: the Schur complement S_b -= L(b, b-1) D_{b-1} L(b, b-1)' on the matrix cores.  S_b is cut into NT x NT tiles of 16 x 16
+// (NT = ceil(SM / 16)), K = SM in steps of 4: NT^2 SM / 4 v_mfma_f64_16x16x4_f64 per block with both operands read from the
+// LDS copy of L(b, b-1) (one double per lane: A(i, k) = L(i, k) d_k, B(k, j) = L(j, k)); the result tiles go through LDS (the
+// staging tile T is free at that point) and every lane subtracts its row.  On the MPC shape (22-wide blocks) this step is
+// 3.8 x faster than the row-per-lane fma form with LDS broadcast reads, hand-over included (scripts/ubench_mfma_f64.hip:
+// 6.45 -> 1.72 us per block update per wave at 8 waves per CU); the f64 MFMA rate equals the f64 vector rate on gfx950, what
+// is saved are the SM^2 broadcast reads and the issue slots of SM^2 scalar fmas.  The elimination itself stays on the VALUs.
+typedef double v4d __attribute__((ext_vector_type(4)));
+template <int SM, bool MFMA>
 __global__ __launch_bounds__(WAVE) void k_stage_factor_r(rldl_dev_sym S, rldl_dev_num Nn, const int *__restrict__ mask, int b0,
-                                                         const int *__restrict__ b0v) {
+                                                         const int *__restrict__ b0v, int lt_rows) {
   const int inst = blockIdx.x, lane = threadIdx.x;
   if (mask && !mask[inst]) return;
   if (b0v) b0 = __builtin_amdgcn_readfirstlane(b0v[inst]);      // per-instance restart block (horizon change)
   const rldl_dev_stage &G = S.stage;
   const int ld = G.ld, nb = G.nb;
+  constexpr int NT = (SM + 15) / 16, SO_LD = 16 * NT + 1;
   extern __shared__ double sh[];
-  // T: staging tile of the panel (2 smax rows); Lt: L(b, b-1) as broadcast source (smax rows)
-  double *T = sh, *Lt = T + 2 * G.smax * ld, *dprev = Lt + G.smax * ld, *dcur = dprev + ld;
+  // T: staging tile of the panel (2 smax rows; MFMA: also the 16 NT x SO_LD result tiles); Lt: L(b, b-1) as broadcast source /
+  // MFMA operand (lt_rows = smax, or 16 NT zero-padded rows)
+  double *T = sh, *Lt = T + 2 * G.smax * ld, *dprev = Lt + lt_rows * ld, *dcur = dprev + ld;
   const double *Kx = Nn.Kx + (size_t)inst * S.nnzK;
   double *F = Nn.F + (size_t)inst * S.ldF, *Dv = Nn.D + (size_t)inst * S.N;
-  double w[SM], lcd[SM];
+  double w[SM];
   int npos = 0, zero = 0;
   // every inner loop below runs to SM without range checks (checks would fence the LDS reads one by one): the tiles are
   // SM + 1 wide (host: ld), zero outside the live block, so the surplus terms are exact zeros
-  for (int p = lane; p < 3 * G.smax * ld + 2 * ld + 128; p += WAVE) sh[p] = 0.0;
+  for (int p = lane; p < (2 * G.smax + lt_rows) * ld + 2 * ld + 128; p += WAVE) sh[p] = 0.0;
   wave_sync();
   for (int j = lane; j < G.bs[b0]; j += WAVE) npos += Dv[j] > 0.0 ? 1 : 0;        // pivots kept from the blocks before b0
   if (b0 > 0) {                                                  // L(b0, b0-1) and D_{b0-1} back from the stored factor
-    const int sprev = G.bs[b0] - G.bs[b0 - 1], scur = G.bs[b0 + 1] - G.bs[b0];
-    for (int p = lane; p < scur * ld; p += WAVE) Lt[p] = 0.0;
-    wave_sync();
+    const int sprev = G.bs[b0] - G.bs[b0 - 1];
     for (int e = G.lc_ptr[b0 - 1] + lane; e < G.lc_ptr[b0]; e += WAVE) Lt[G.lc_pos[e]] = F[G.lc_slot[e]];
     for (int c = lane; c < sprev; c += WAVE) dprev[c] = Dv[G.bs[b0 - 1] + c];
     wave_sync();
@@ -1840,21 +1848,52 @@ __global__ __launch_bounds__(WAVE) void k_stage_factor_r(rldl_dev_sym S, rldl_de
     wave_sync();
     const double *myT = T + (lane < R ? lane : 0) * ld, *myL = Lt + (lane < s ? lane : 0) * ld;
 #pragma unroll
-    for (int c = 0; c < SM; c++) {
-      w[c] = myT[c];
-      lcd[c] = myL[c] * dprev[c];                                // own row of L(b, b-1) times D_{b-1} (rows of S_b only)
-    }
-    // 2. Schur complement of the previous block (rows of C_b: lcd is garbage-free zero? no -- they must stay untouched)
+    for (int c = 0; c < SM; c++) w[c] = myT[c];
+    // 2. Schur complement of the previous block (rows of S_b only; the rows of the coupling block C_b stay as they are)
     if (b > 0) {
       const bool srow = lane < s;
+      if (MFMA) {
+        wave_sync();                                             // own rows are in registers: T becomes the result buffer
+        v4d acc[NT * NT];
 #pragma unroll
-      for (int k = 0; k < SM; k++) {
-        if (k < s) {                                             // uniform
-          const double *lk = Lt + k * ld;
-          double acc = 0.0;
+        for (int t = 0; t < NT * NT; t++) acc[t] = v4d{0.0, 0.0, 0.0, 0.0};
+        double av[NT][SM / 4], bv[NT][SM / 4];
 #pragma unroll
-          for (int c = 0; c < SM; c++) acc = fma(lcd[c], lk[c], acc);   // lk[c]: one address for the whole wave
-          if (srow) w[k] -= acc;
+        for (int g = 0; g < NT; g++)
+#pragma unroll
+          for (int kk = 0; kk < SM / 4; kk++) {
+            const int k = 4 * kk + (lane >> 4);
+            const double v = Lt[(16 * g + (lane & 15)) * ld + k];
+            bv[g][kk] = v; av[g][kk] = v * dprev[k];
+          }
+#pragma unroll
+        for (int r = 0; r < NT; r++)
+#pragma unroll
+          for (int cc = 0; cc < NT; cc++)
+#pragma unroll
+            for (int kk = 0; kk < SM / 4; kk++)
+              acc[r * NT + cc] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[r][kk], bv[cc][kk], acc[r * NT + cc], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT * NT; t++)                        // register q of lane l holds tile element (l / 16 + 4 q, l % 16) (measured on gfx950)
+#pragma unroll
+          for (int q = 0; q < 4; q++) T[(16 * (t / NT) + (lane >> 4) + 4 * q) * SO_LD + 16 * (t % NT) + (lane & 15)] = acc[t][q];
+        wave_sync();
+        const double *mine = T + (srow ? lane : 0) * SO_LD;
+#pragma unroll
+        for (int k = 0; k < SM; k++) { const double a = mine[k]; if (srow) w[k] -= a; }
+      } else {
+        double lcd[SM];
+#pragma unroll
+        for (int c = 0; c < SM; c++) lcd[c] = myL[c] * dprev[c];  // own row of L(b, b-1) times D_{b-1}
+#pragma unroll
+        for (int k = 0; k < SM; k++) {
+          if (k < s) {                                           // uniform
+            const double *lk = Lt + k * ld;
+            double acc = 0.0;
+#pragma unroll
+            for (int c = 0; c < SM; c++) acc = fma(lcd[c], lk[c], acc);   // lk[c]: one address for the whole wave
+            if (srow) w[k] -= acc;
+          }
         }
       }
     }
@@ -1876,6 +1915,10 @@ __global__ __launch_bounds__(WAVE) void k_stage_factor_r(rldl_dev_sym S, rldl_de
     }
     // 4. outputs: rows back to the tile, then D, Dinv, L_bb and L(b+1, b) into the factor's slots
     wave_sync();
+    if (MFMA) {                                                  // the result tiles of step 2 used another row length: clear what they left
+      for (int p = lane; p < 2 * G.smax * ld; p += WAVE) T[p] = 0.0;
+      wave_sync();
+    }
     if (lane < R) {
       double *o = T + lane * ld;
 #pragma unroll
@@ -1886,14 +1929,14 @@ __global__ __launch_bounds__(WAVE) void k_stage_factor_r(rldl_dev_sym S, rldl_de
     for (int e = G.ld_ptr[b] + lane; e < G.ld_ptr[b + 1]; e += WAVE) F[G.ld_slot[e]] = T[G.ld_pos[e]];
     if (sn) {
       for (int e = G.lc_ptr[b] + lane; e < G.lc_ptr[b + 1]; e += WAVE) F[G.lc_slot[e]] = T[s * ld + G.lc_pos[e]];
-      for (int p = lane; p < sn * ld; p += WAVE) Lt[p] = T[s * ld + p];              // L(b+1, b): broadcast source of the next block
+      for (int p = lane; p < lt_rows * ld; p += WAVE) Lt[p] = p < sn * ld ? T[s * ld + p] : 0.0;   // L(b+1, b): source of the next block's Schur complement (zero padded)
       double *tp = dprev; dprev = dcur; dcur = tp;
     }
     wave_sync();
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) npos += __shfl_xor(npos, o);
-  if (lane == 0) Nn.status[inst] = zero ? -1 : npos;
+  if (lane == 0) { Nn.status[inst] = zero ? -1 : npos; if (Nn.fail && (zero || npos < S.n)) atomicOr(Nn.fail, 1); }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2002,7 +2045,7 @@ __global__ __launch_bounds__(WAVE) void k_arrow_factor(rldl_dev_sym S, rldl_dev_
   for (int j = lane; j < S.N; j += WAVE) { const double d = Wd[j]; Dg[j] = d; F[S.nS + j] = 1.0 / d; }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { npos += __shfl_xor(npos, o); zero |= __shfl_xor(zero, o); }
-  if (lane == 0) Nn.status[inst] = zero ? -1 : npos;
+  if (lane == 0) { Nn.status[inst] = zero ? -1 : npos; if (Nn.fail && (zero || npos < S.n)) atomicOr(Nn.fail, 1); }
 }
 
 // ================================================================================================
@@ -2881,8 +2924,8 @@ static int plan_pick_wpb_for(const rldl_dev_sym *S, const void *kernel, bool sta
 // staged (factor row in LDS) when that still leaves >= 4 waves per CU, streamed from global memory otherwise
 struct PlanGeom { int wpb; bool stage; size_t lds; };
 static PlanGeom plan_geometry(const rldl_dev_sym *S, const void *k_staged, const void *k_stream) {
-  static const void *ck = 0; static int cw = -1, cl = -1; static PlanGeom cg = {0, false, 0};
-  if (ck == k_staged && cw == S->plan_words && cl == S->ldF) return cg;
+  static thread_local const void *ck = 0; static thread_local int cw = -1, cl = -1, cn = -1; static thread_local PlanGeom cg = {0, false, 0};
+  if (ck == k_staged && cw == S->plan_words && cl == S->ldF && cn == S->N) return cg;
   int ws = 0, wg = 0;
   const int wpb_s = plan_pick_wpb_for(S, k_staged, true, &ws), wpb_g = plan_pick_wpb_for(S, k_stream, false, &wg);
   PlanGeom g;
@@ -2892,7 +2935,7 @@ static PlanGeom plan_geometry(const rldl_dev_sym *S, const void *k_staged, const
   if (getenv("RLDL_VERBOSE"))
     fprintf(stderr, "[rldl] plan kernel: %s, wpb=%d, %d waves/CU, %zu B LDS per workgroup\n", g.stage ? "factor staged in LDS" : "factor read from global",
             g.wpb, g.stage ? ws : wg, g.lds);
-  ck = k_staged; cw = S->plan_words; cl = S->ldF; cg = g;
+  ck = k_staged; cw = S->plan_words; cl = S->ldF; cn = S->N; cg = g;
   return g;
 }
 static int plan_pick_wpb(const rldl_dev_sym *S) {   // feasibility only: the global-memory variant needs plan + x in LDS
@@ -2998,7 +3041,7 @@ static ArrowGeom arrow_geometry(const rldl_dev_sym *S) {
   return arrow_geometry_rr(S, 0);
 }
 static int arrow_pick_wpb(const rldl_dev_sym *S, const void *kernel, const ArrowGeom &G, size_t *lds_out) {
-  static const void *ck = 0; static int cpw = -1, cbest = 0; static size_t clds = 0;
+  static thread_local const void *ck = 0; static thread_local int cpw = -1, cbest = 0; static thread_local size_t clds = 0;
   if (ck == kernel && cpw == G.per_wave) { *lds_out = clds; return cbest; }
   int best = 0, best_waves = 0; size_t best_lds = 0;
   const char *force = getenv("RLDL_WPB");
@@ -3054,7 +3097,8 @@ static int launch_arrow_admm_t(const rldl_dev_sym *S, const rldl_dev_num *Nn, co
   const ArrowGeom G = arrow_geometry(S);
   const int wpb = arrow_pick_wpb(S, (const void *)k_arrow_admm<TMAX, TG, false>, G, &lds);
   if (wpb <= 0) return -1;
-  if (lds > 64 * 1024 && hipFuncSetAttribute((const void *)k_arrow_admm<TMAX, TG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+  if (lds > 64 * 1024 && hipFuncSetAttribute(W->trace ? (const void *)k_arrow_admm<TMAX, TG, true> : (const void *)k_arrow_admm<TMAX, TG, false>,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
   if (W->trace)
     hipLaunchKernelGGL((k_arrow_admm<TMAX, TG, true>), dim3((Nn->batch + wpb - 1) / wpb), dim3(wpb * WAVE), lds, (hipStream_t)stream, *S, *Nn, *W, G, iters);
   else
@@ -3236,12 +3280,20 @@ static int launch_stage_factor(const rldl_dev_sym *S, const rldl_dev_num *Nn, co
     hipLaunchKernelGGL(k_stage_factor, dim3(Nn->batch), dim3(WAVE), lds, (hipStream_t)stream, *S, *Nn, d_mask, first_block, d_b0v);
     return launch_status();
   }
-  const size_t lds = sizeof(double) * (size_t)(3 * G->smax * G->ld + 2 * G->ld + 128);
+  // matrix-core Schur complement (see k_stage_factor_r) when the result tiles fit the staging tile; RLDL_NO_MFMA=1: fma form
+  static const int no_mfma = getenv("RLDL_NO_MFMA") ? 1 : 0;
+  const int sm = G->smax <= 8 ? 8 : G->smax <= 16 ? 16 : G->smax <= 24 ? 24 : 32, nt16 = 16 * ((sm + 15) / 16);
+  const bool mfma = !no_mfma && nt16 * (nt16 + 1) <= 2 * G->smax * G->ld && G->ld >= sm + 1;
+  const int lt_rows = mfma ? (nt16 > G->smax ? nt16 : G->smax) : G->smax;
+  const size_t lds = sizeof(double) * (size_t)((2 * G->smax + lt_rows) * G->ld + 2 * G->ld + 128);
   const dim3 grid(Nn->batch), blk(WAVE);
-  if (G->smax <= 8) hipLaunchKernelGGL(k_stage_factor_r<8>, grid, blk, lds, (hipStream_t)stream, *S, *Nn, d_mask, first_block, d_b0v);
-  else if (G->smax <= 16) hipLaunchKernelGGL(k_stage_factor_r<16>, grid, blk, lds, (hipStream_t)stream, *S, *Nn, d_mask, first_block, d_b0v);
-  else if (G->smax <= 24) hipLaunchKernelGGL(k_stage_factor_r<24>, grid, blk, lds, (hipStream_t)stream, *S, *Nn, d_mask, first_block, d_b0v);
-  else hipLaunchKernelGGL(k_stage_factor_r<32>, grid, blk, lds, (hipStream_t)stream, *S, *Nn, d_mask, first_block, d_b0v);
+#define SF(SMV) do { if (mfma) hipLaunchKernelGGL((k_stage_factor_r<SMV, true>), grid, blk, lds, (hipStream_t)stream, *S, *Nn, d_mask, first_block, d_b0v, lt_rows); \
+                     else hipLaunchKernelGGL((k_stage_factor_r<SMV, false>), grid, blk, lds, (hipStream_t)stream, *S, *Nn, d_mask, first_block, d_b0v, lt_rows); } while (0)
+  if (sm == 8) SF(8);
+  else if (sm == 16) SF(16);
+  else if (sm == 24) SF(24);
+  else SF(32);
+#undef SF
   return launch_status();
 }
 extern "C" int rldl_launch_stage_factor(const rldl_dev_sym *S, const rldl_dev_num *Nn, const int *d_mask, int first_block, void *stream) {
@@ -3411,6 +3463,20 @@ extern "C" int rldl_launch_matvec_A(const rldl_dev_sym *S, const rldl_dev_admm *
   rldl_dev_sym Sk = *S;
   if (lds > 64 * 1024) Sk.flat_ok = 0;                           // vectors too long for LDS: row loops
   hipLaunchKernelGGL(k_matvec_A, dim3(W->batch), dim3(WAVE), Sk.flat_ok ? lds : 0, (hipStream_t)stream, Sk, *W, d_x, d_out);
+  return launch_status();
+}
+
+// l <= u for every entry (osqp_update_bounds, src/osqp.c:805-813; osqp_partial_update_bounds, src/recursive_ldl.c:137-145):
+// *flag becomes 1 when a lower bound exceeds its upper bound anywhere in the batch
+__global__ __launch_bounds__(256) void k_check_bounds(long long count, const double *__restrict__ l, const double *__restrict__ u, int *flag) {
+  int bad = 0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long long)gridDim.x * blockDim.x) bad |= l[i] > u[i];
+  if (__any(bad) && (threadIdx.x & (WAVE - 1)) == 0) atomicOr(flag, 1);
+}
+extern "C" int rldl_launch_check_bounds(long long count, const double *l, const double *u, int *flag, void *stream) {
+  if (count <= 0) return 0;
+  const long long blocks = (count + 255) / 256;
+  hipLaunchKernelGGL(k_check_bounds, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, (hipStream_t)stream, count, l, u, flag);
   return launch_status();
 }
 

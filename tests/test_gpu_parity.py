@@ -563,3 +563,27 @@ def test_enqueued_update_and_solve_equal_the_blocking_calls_and_report_a_failed_
     rc = w.wait()
     assert torch.equal(ra["x"], rc["x"])
     w.cleanup()
+
+
+def test_update_bounds_refuses_crossed_bounds_and_refactor_failure_is_sticky(R):
+    """osqp_update_bounds (src/osqp.c:805-813): l > u anywhere -> exitflag 1 and nothing changes.  And the verdict of an
+    asynchronous refactorisation is sticky: a failing update_P_A enqueued BEFORE a good one is still reported by wait()."""
+    wl = R.workloads.SharedPatternQPs(n=20, m=30, density=0.2, pattern_seed=7)
+    B = 4
+    Px, Ax, q, l, u = wl.values(B)
+    kw = dict(rho=0.1, sigma=1e-6, alpha=1.6, max_iter=30, check_termination=0, adaptive_rho=0, warm_start=0, scaling=0)
+    w = R.OSQPBatch(wl.P_pattern, wl.A_pattern, dev(Px), dev(Ax), dev(q), dev(l), dev(u), **kw)
+    r0 = w.solve()["x"].cpu().numpy().copy()
+    bad_l = l.copy(); bad_l[2, 5] = u[2, 5] + 1.0
+    assert w.update_bounds(dev(bad_l), dev(u)) == 1
+    assert np.array_equal(w.solve()["x"].cpu().numpy(), r0)     # bounds untouched
+    assert w.update_bounds(dev(l), dev(u)) == 0
+    Pbad = Px.copy()
+    Pbad[1] = -Px[1]                                             # instance 1 becomes non-convex: fewer than n positive pivots
+    assert w.update_P_A(dev(Pbad), dev(Ax), wait=False) == 0
+    assert w.update_P_A(dev(Px), dev(Ax), wait=False) == 0       # a later, good refactorisation must not hide the failure
+    with pytest.raises(RuntimeError):
+        w.wait()
+    assert w.update_P_A(dev(Px), dev(Ax), wait=False) == 0
+    w.wait()                                                     # the verdict was cleared when it was read
+    w.cleanup()
