@@ -156,7 +156,7 @@ static int upload_symbolic(rldl_batch *h) {
   D->nTi = s->nTi; D->ldTi = (s->nTi + 1) & ~1;
   D->po_tlane = s->po_tlane; D->po_tmap = s->po_tmap; D->po_tislot = s->po_tislot;
   D->tile_admm_ok = D->tile_ok ? s->tile_admm_ok : 0; D->tile_vslots = s->tile_vslots; D->tile_slots = s->tile_slots; D->po_tpos = s->po_tpos;
-  D->tile_ck[0] = s->tile_ck[0]; D->tile_ck[1] = s->tile_ck[1]; D->tile_ck[2] = s->tile_ck[2]; D->tile_tk = s->tile_tk;
+  D->tile_ck[0] = s->tile_ck[0]; D->tile_ck[1] = s->tile_ck[1]; D->tile_ck[2] = s->tile_ck[2]; D->tile_tk = s->tile_tk; D->tile_sp = s->tile_sp;
   D->po_cmap = s->po_cmap; D->po_crow = s->po_crow;
   if (D->arrow_ok) {
     int t, l;
@@ -404,7 +404,7 @@ c_int rldl_symbolic_analyze(const csc *P, const csc *A, c_int polish, const c_in
  * meta[0..47] = {plan_ok, nS, nO, ngroups, plan_words, po_gstart, po_gflag, po_gToff, po_fsp, po_bsp, po_fsb, po_fsc,
  *                po_bsb, po_bsc, po_fsig, po_bsig, po_fcol, po_brs, po_perm, N, nnzL, arrow_ok, arrow_group, arrow_vsteps,
  *                arrow_vrows, po_avmap, po_avcol, po_avrow, nOp, tile_ok, tile_ta, tile_tq, tile_lanes, nTi, po_tlane, po_tmap,
- *                po_tislot, tile_admm_ok, tile_vslots, tile_slots, po_tpos, tile_ck[0..2], tile_tk, po_cmap, po_crow, 0};
+ *                po_tislot, tile_admm_ok, tile_vslots, tile_slots, po_tpos, tile_ck[0..2], tile_tk, po_cmap, po_crow, tile_sp};
  *                blob/LtoS may be NULL. */
 c_int rldl_plan_export(const csc *P, const csc *A, c_int polish, const c_int *perm_in, c_int *meta, int *blob, c_int blob_cap,
                        c_int *LtoS) {
@@ -422,7 +422,7 @@ c_int rldl_plan_export(const csc *P, const csc *A, c_int polish, const c_int *pe
   meta[29] = s->plan_ok ? s->tile_ok : 0; meta[30] = s->tile_ta; meta[31] = s->tile_tq; meta[32] = s->tile_lanes; meta[33] = s->nTi;
   meta[34] = s->po_tlane; meta[35] = s->po_tmap; meta[36] = s->po_tislot;
   meta[37] = s->plan_ok && s->tile_ok ? s->tile_admm_ok : 0; meta[38] = s->tile_vslots; meta[39] = s->tile_slots; meta[40] = s->po_tpos;
-  meta[41] = s->tile_ck[0]; meta[42] = s->tile_ck[1]; meta[43] = s->tile_ck[2]; meta[44] = s->tile_tk; meta[45] = s->po_cmap; meta[46] = s->po_crow;
+  meta[41] = s->tile_ck[0]; meta[42] = s->tile_ck[1]; meta[43] = s->tile_ck[2]; meta[44] = s->tile_tk; meta[45] = s->po_cmap; meta[46] = s->po_crow; meta[47] = s->tile_sp;
   if (blob && s->plan_ok && blob_cap >= s->plan_words) memcpy(blob, s->plan, sizeof(int) * (size_t)s->plan_words);
   if (LtoS) for (i = 0; i < s->nnzL; i++) LtoS[i] = s->LtoS[i];
   rldl_symbolic_free(s);

@@ -59,7 +59,7 @@ typedef struct {
   int tile_ok, tile_ta, tile_tq, tile_lanes, nTi, ldTi;   /* tail inverse by register tiles (rldl_symbolic.h); ldTi = nTi rounded up to even */
   int po_tlane, po_tmap, po_tislot;
   int tile_admm_ok, tile_vslots, tile_slots, po_tpos;   /* ADMM slots of the tile kernels (rldl_symbolic.h) */
-  int tile_ck[3], tile_tk, po_cmap, po_crow;            /* backward coupling product gathered by the owner lane */
+  int tile_ck[3], tile_tk, tile_sp, po_cmap, po_crow;            /* backward coupling product gathered by the owner lane */
   int arrow_g0, arrow_g;       /* index range of the tail group */
   int arrow_tb;                /* its triangle base relative to slot nOp, or -1 */
   int arrow_dense;             /* 1: every head column has entries only in the tail group, which ends the matrix (k_arrow_factor) */

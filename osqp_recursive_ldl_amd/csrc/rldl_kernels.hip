@@ -2581,10 +2581,9 @@ __device__ __forceinline__ void col_load(const rldl_dev_sym &S, const double *__
     Q.a[k2] = (s0 != 0xffffu ? xtb + 8u * (rw & 0xffffu) : dmy) | ((s1 != 0xffffu ? xtb + 8u * (rw >> 16) : dmy) << 16);
   }
 }
-// steps [0, 3 TK / 4): the column this lane owns in the first constraint slot, [3 TK / 4, TK): in the second (compile-time split)
-template <int TK>
+// steps [0, SP): the column this lane owns in the first constraint slot, [SP, TK): in the second (compile-time split)
+template <int TK, int SP>
 __device__ __forceinline__ void col_gather(const ColRegs<TK> &Q, const char *shb, double &r1, double &r2) {
-  constexpr int SP = (3 * TK) / 4;
   double a[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
   for (int k = 0; k < TK; k++) {
@@ -2706,7 +2705,7 @@ __global__ __launch_bounds__(256, 2) void k_tile_solve(rldl_dev_sym S, rldl_dev_
 // The permuted positions are dealt to (slot, lane) by the host (po_tpos): slot 0 holds the variables, slots 1 and 2 the
 // constraints, so the step code of a slot is uniform (S.tile_vslots == 1 is a condition of tile_admm_ok).
 #define TILE_SLOTS 3
-template <int TG, int TA, int TK, bool TRACE>
+template <int TG, int TA, int TK, int SP, bool TRACE>
 __global__ __launch_bounds__(256, 2) void k_tile_admm(rldl_dev_sym S, rldl_dev_num Nn, rldl_dev_admm W, int xdw, int iters) {
   extern __shared__ __attribute__((aligned(16))) double sh[];
   const int lane = threadIdx.x & (WAVE - 1), wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wpb = blockDim.x >> 6;
@@ -2790,7 +2789,7 @@ __global__ __launch_bounds__(256, 2) void k_tile_admm(rldl_dev_sym S, rldl_dev_n
     if (trit && lane == 0) tr[1] = wall_clock64();              // rhs in LDS
     tile_tri_solve<TG, TA, TS, false>(R, C, T, A, dtail, shb, jra, dta, za, lane, trit ? tr : nullptr);
     double hs[TS] = {0.0, 0.0, 0.0};                             // sum_r L(r, c) x_r of the head entry this lane owns in slot t (0: tail entry)
-    col_gather<TK>(Q, shb, hs[1], hs[2]);
+    col_gather<TK, SP>(Q, shb, hs[1], hs[2]);
     if (trit && lane == 0) tr[5] = wall_clock64();              // backward coupling product done
     double xs_[TS], dinv[TS], lo[TS], hi[TS], rho[TS], dl[TS];
 #pragma unroll
@@ -3138,7 +3137,7 @@ static bool tile_admm_usable(const rldl_dev_sym *S, const rldl_dev_num *Nn, cons
   // kernel would spill inside its loop -- those shapes stay on the sweep kernels
   const int tg = S->arrow_vsteps <= 12 ? 12 : S->arrow_vsteps <= 18 ? 18 : 24;
   if (2 * tg + 2 * S->tile_ta * S->tile_ta + (26 * S->tile_tk) / 10 + 89 > 256) return false;
-  return tile_usable(S, Nn) && S->tile_admm_ok && (!W->trace || (S->arrow_vsteps > 12 && S->arrow_vsteps <= 18 && S->tile_ta == 5 && S->tile_tk == 24));
+  return tile_usable(S, Nn) && S->tile_admm_ok && (!W->trace || (S->arrow_vsteps > 12 && S->arrow_vsteps <= 18 && S->tile_ta == 5 && S->tile_tk == 24 && S->tile_sp == 18));
 }
 #define TILE_TA_SWITCH(CALL)                  \
   switch (S->tile_ta) {                       \
@@ -3172,11 +3171,16 @@ static int launch_tile_admm(const rldl_dev_sym *S, const rldl_dev_num *Nn, const
   const int pw = tile_per_wave(S), grid = (Nn->batch + TILE_WPB - 1) / TILE_WPB;
   const size_t lds = sizeof(double) * (size_t)(pw + WAVE + 4 * TILE_SLOTS * WAVE) * TILE_WPB;
   if (W->trace) {                                                 // the wave timeline exists for the metric shape's instantiation only
-    hipLaunchKernelGGL((k_tile_admm<18, 5, 24, true>), dim3(grid), dim3(TILE_WPB * WAVE), lds, (hipStream_t)stream, *S, *Nn, *W, pw, iters);
+    hipLaunchKernelGGL((k_tile_admm<18, 5, 24, 18, true>), dim3(grid), dim3(TILE_WPB * WAVE), lds, (hipStream_t)stream, *S, *Nn, *W, pw, iters);
     return launch_status();
   }
-#define TA_(TG, TA, TK) hipLaunchKernelGGL((k_tile_admm<TG, TA, TK, false>), dim3(grid), dim3(TILE_WPB * WAVE), lds, (hipStream_t)stream, *S, *Nn, *W, pw, iters)
-#define TK_(TG, TA) switch (S->tile_tk) { case 16: TA_(TG, TA, 16); break; case 24: TA_(TG, TA, 24); break; case 32: TA_(TG, TA, 32); break; default: return -1; }
+  int launched = 0;
+  // one instantiation per (virtual-row steps, tile size, owner-gather steps, split); combinations whose register need exceeds
+  // 256 (tile_admm_usable rules them out) are not compiled
+#define TA_(TG, TA, TK, SP) do { if constexpr (2 * TG + 2 * TA * TA + (26 * TK) / 10 + 89 <= 256) { \
+    hipLaunchKernelGGL((k_tile_admm<TG, TA, TK, SP, false>), dim3(grid), dim3(TILE_WPB * WAVE), lds, (hipStream_t)stream, *S, *Nn, *W, pw, iters); launched = 1; } } while (0)
+#define TK_(TG, TA) switch (S->tile_tk * 100 + S->tile_sp) { case 1612: TA_(TG, TA, 16, 12); break; case 1610: TA_(TG, TA, 16, 10); break; \
+    case 2418: TA_(TG, TA, 24, 18); break; case 2416: TA_(TG, TA, 24, 16); break; case 3224: TA_(TG, TA, 32, 24); break; case 3220: TA_(TG, TA, 32, 20); break; default: return -1; }
   if (S->arrow_vsteps <= 12) {
 #define C(TA) TK_(12, TA)
     TILE_TA_SWITCH(C)
@@ -3192,7 +3196,7 @@ static int launch_tile_admm(const rldl_dev_sym *S, const rldl_dev_num *Nn, const
   }
 #undef TK_
 #undef TA_
-  return launch_status();
+  return launched ? launch_status() : -1;
 }
 // inverse of the tail triangle behind every numeric factorisation of a tile handle (any factor kernel: it reads the factor row)
 static int launch_tile_invert(const rldl_dev_sym *S, const rldl_dev_num *Nn, const int *d_mask, void *stream) {

@@ -205,7 +205,7 @@ int rldl_plan_build(rldl_symbolic *s) {
       s->tile_admm_ok = s->tile_slots <= 3 && !s->polish;
       s->po_tpos = words; words += 3 * 64;
       /* owner gather of the backward coupling product: positions of a kind by decreasing column count, steps per slot */
-      s->tile_ck[0] = s->tile_ck[1] = s->tile_ck[2] = 0; s->tile_tk = 16;
+      s->tile_ck[0] = s->tile_ck[1] = s->tile_ck[2] = 0; s->tile_tk = 16; s->tile_sp = 12;
       if (s->tile_admm_ok) {
         int kind, tot = 0;
         for (kind = 0; kind < 2; kind++) {
@@ -221,7 +221,7 @@ int rldl_plan_build(rldl_symbolic *s) {
             s->tile_ck[t] = best; tot += best;
           }
         }
-        /* compile-time split of the steps: the first constraint slot's columns in [0, 3 tk / 4), the second's in [3 tk / 4, tk);
+        /* compile-time split of the steps: the first constraint slot's columns in [0, sp), the second's in [sp, tk), sp = 3 tk / 4 or 2 tk / 3;
          * head entries must all be constraints (variable slots own tail entries only: ck = 0) */
         (void)tot;
         {
@@ -230,8 +230,13 @@ int rldl_plan_build(rldl_symbolic *s) {
           int t, okv = 1;
           for (t = 0; t < s->tile_vslots; t++) if (s->tile_ck[t] > 0) okv = 0;
           s->tile_tk = 0;
-          for (t = 16; t <= 32; t += 8) if (k1 <= (3 * t) / 4 && k2 <= t / 4) { s->tile_tk = t; break; }
-          if (!okv || !s->tile_tk || s->tile_vslots != 1 || s->tile_slots - s->tile_vslots > 2) { s->tile_admm_ok = 0; s->tile_tk = 16; }
+          s->tile_sp = 0;
+          for (t = 16; t <= 32 && !s->tile_tk; t += 8) {       /* split after 3/4 or after 2/3 of the steps (what the kernels are compiled for) */
+            const int spa = (3 * t) / 4, spb = ((2 * t) / 3) & ~1;
+            if (k1 <= spa && k2 <= t - spa) { s->tile_tk = t; s->tile_sp = spa; }
+            else if (k1 <= spb && k2 <= t - spb) { s->tile_tk = t; s->tile_sp = spb; }
+          }
+          if (!okv || !s->tile_tk || s->tile_vslots != 1 || s->tile_slots - s->tile_vslots > 2) { s->tile_admm_ok = 0; s->tile_tk = 16; s->tile_sp = 12; }
         }
       }
       s->po_cmap = words; words += (s->tile_tk / 2) * 64;
@@ -407,7 +412,7 @@ int rldl_plan_build(rldl_symbolic *s) {
       for (l = 0; l < (s->tile_tk / 2) * 64; l++) { cm[l] = 0xffffffffu; cr[l] = 0u; }
       if (s->tile_admm_ok) {
         kv *ord = (kv *)malloc(sizeof(kv) * (size_t)(N + 1));
-        int kind, e0 = 0, t;
+        int kind, t;
         if (!ord) goto out;
         for (kind = 0; kind < 2; kind++) {
           int cntk = 0, base = kind ? 64 * s->tile_vslots : 0;
@@ -417,21 +422,49 @@ int rldl_plan_build(rldl_symbolic *s) {
           for (i = 0; i < cntk; i++) tp[base + i] = ord[i].idx;
         }
         free(ord);
-        for (t = 0; t < s->tile_slots; t++) {                 /* entries of the owner's column, ascending row, steps [e0, e0 + ck[t]) */
-          e0 = t <= s->tile_vslots ? 0 : (3 * s->tile_tk) / 4;
-          for (l = 0; l < 64; l++) {
-            const int cpos = tp[t * 64 + l];
-            int kk2 = 0;
-            if (cpos < 0) continue;
-            for (p = s->Lp[cpos]; p < s->Lp[cpos + 1]; p++) {
-              const int r = s->Li[p], kstep = e0 + kk2, sh = 16 * (kstep & 1);
-              if (group_of[r] == group_of[cpos]) continue;    /* (in-group entry of a tail column) */
-              if (kk2 >= s->tile_ck[t] || r < g0 || r >= gstart[arrow_k + 1]) { rc = -2; goto out; }   /* cannot happen on an arrowhead plan */
-              cm[(kstep >> 1) * 64 + l] = (cm[(kstep >> 1) * 64 + l] & ~(0xffffu << sh)) | ((unsigned)s->LtoS[p] << sh);
-              cr[(kstep >> 1) * 64 + l] |= (unsigned)(r - g0) << sh;
-              kk2++;
+        /* Entries of the owner's column on the steps [e0, e0 + ck[t]) of its slot.  WHICH step an entry takes is free, and it
+         * decides the LDS bank conflicts of the gather: a ds_read_b64 serves 32 lanes per pass and two lanes of a pass collide
+         * when they read different words of one bank pair ((word index) mod 32).  Greedy placement, lane by lane: an entry goes
+         * to a free step of the lane where its bank pair is still unused in the lane's half-wave (or holds the same word); the
+         * steps a lane leaves empty read the lane's own dummy word, which occupies its bank pair too. */
+        {
+          const int tk = s->tile_tk, need = g0 + s->tile_ta * s->tile_tq, xdw = ((need > N ? need : N) + 1) & ~1;
+          int *used = (int *)malloc(sizeof(int) * (size_t)tk * 2 * 32);             /* [step][half][bank pair] -> word index or -1 */
+          int *lane_step = (int *)malloc(sizeof(int) * (size_t)tk);
+          if (!used || !lane_step) { free(used); free(lane_step); goto out; }
+          for (l = 0; l < tk * 64; l++) used[l] = -1;
+          for (t = 0; t < s->tile_slots; t++) {
+            const int e0 = t <= s->tile_vslots ? 0 : s->tile_sp, K = s->tile_ck[t];
+            for (l = 0; l < 64; l++) {
+              const int cpos = tp[t * 64 + l], half = l >> 5, dmy = xdw + l;
+              int kk2;
+              if (cpos < 0) continue;
+              for (kk2 = 0; kk2 < K; kk2++) lane_step[kk2] = -1;
+              for (p = s->Lp[cpos]; p < s->Lp[cpos + 1]; p++) {
+                const int r = s->Li[p], word = r, bank = r & 31;
+                int best = -1, bestc = 3;
+                if (group_of[r] == group_of[cpos]) continue;  /* (in-group entry of a tail column) */
+                if (r < g0 || r >= gstart[arrow_k + 1]) { free(used); free(lane_step); rc = -2; goto out; }   /* cannot happen on an arrowhead plan */
+                for (kk2 = 0; kk2 < K; kk2++) {
+                  int u, c;
+                  if (lane_step[kk2] >= 0) continue;
+                  u = used[((e0 + kk2) * 2 + half) * 32 + bank];
+                  c = (u < 0) ? 0 : (u == word ? 0 : 1);
+                  if (c < bestc) { bestc = c; best = kk2; }
+                }
+                if (best < 0) { free(used); free(lane_step); rc = -2; goto out; }   /* more entries than steps: cannot happen (ck = max count) */
+                lane_step[best] = p;
+                if (used[((e0 + best) * 2 + half) * 32 + bank] < 0) used[((e0 + best) * 2 + half) * 32 + bank] = word;
+              }
+              for (kk2 = 0; kk2 < K; kk2++) {
+                const int kstep = e0 + kk2, sh = 16 * (kstep & 1), pp = lane_step[kk2];
+                if (pp < 0) { if (used[(kstep * 2 + half) * 32 + (dmy & 31)] < 0) used[(kstep * 2 + half) * 32 + (dmy & 31)] = dmy; continue; }
+                cm[(kstep >> 1) * 64 + l] = (cm[(kstep >> 1) * 64 + l] & ~(0xffffu << sh)) | ((unsigned)s->LtoS[pp] << sh);
+                cr[(kstep >> 1) * 64 + l] |= (unsigned)(s->Li[pp] - g0) << sh;
+              }
             }
           }
+          free(used); free(lane_step);
         }
       }
     }

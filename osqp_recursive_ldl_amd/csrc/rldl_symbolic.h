@@ -78,10 +78,11 @@ typedef struct {
    * register copy of the coupling values) and sums L(r, c) x_r itself.  Positions are dealt to the slots of their kind by
    * decreasing column count, so slot t needs tile_ck[t] = (count of its first column) steps.  Head entries must all be
    * constraints (ck = 0 for the variable slots) in at most two constraint slots: the first one's columns take steps
-   * [0, 3 tk / 4), the second one's [3 tk / 4, tk) -- a compile-time split; tile_tk = 16 / 24 / 32, the smallest that fits.
+   * [0, tile_sp), the second one's [tile_sp, tile_tk) -- a compile-time split (tile_sp = 3 tk / 4 or 2 tk / 3, even);
+   * tile_tk = 16 / 24 / 32, the smallest that fits.
    *   po_cmap [tile_tk / 2][64]  factor slot(k even) | slot(k odd) << 16, 0xffff = none
    *   po_crow [tile_tk / 2][64]  same packing: row of the entry, local to the tail group */
-  int tile_ck[3], tile_tk, po_cmap, po_crow;
+  int tile_ck[3], tile_tk, tile_sp, po_cmap, po_crow;
   /* problem matrices for the residual kernels: CSC as given plus row-order (CSR) access maps */
   int *Pp, *Pi, *Prp, *Prj, *Prpos;   /* P upper triangular n x n */
   int *Ap, *Ai, *Arp, *Arj, *Arpos;   /* A m x n */

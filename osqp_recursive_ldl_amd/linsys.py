@@ -278,7 +278,7 @@ def plan_export(P, A, polish=0, perm=None):
              "po_fsc", "po_bsb", "po_bsc", "po_fsig", "po_bsig", "po_fcol", "po_brs", "po_perm", "N", "nnzL", "arrow_ok", "arrow_group",
              "arrow_vsteps", "arrow_vrows", "po_avmap", "po_avcol", "po_avrow", "nOp", "tile_ok", "tile_ta", "tile_tq", "tile_lanes", "nTi",
              "po_tlane", "po_tmap", "po_tislot", "tile_admm_ok", "tile_vslots", "tile_slots", "po_tpos", "tile_ck0", "tile_ck1",
-             "tile_ck2", "tile_tk", "po_cmap", "po_crow"]
+             "tile_ck2", "tile_tk", "po_cmap", "po_crow", "tile_sp"]
     out = {k: int(meta[i]) for i, k in enumerate(names)}
     out["blob"] = blob[:words]
     out["LtoS"] = LtoS[:nnzL]

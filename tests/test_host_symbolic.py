@@ -333,3 +333,58 @@ def test_tile_tables_reproduce_the_products_with_the_tail_inverse(case):
         x[cols] += T.T @ wvec[rows]                       # tile_bwd
     assert np.allclose(y[:g], Linv @ cvec[:g], rtol=1e-13, atol=1e-13)
     assert np.allclose(x[:g], Linv.T @ wvec[:g], rtol=1e-13, atol=1e-13)
+
+
+@pytest.mark.parametrize("case", ["arrowhead", "small", "g30"])
+def test_owner_gather_tables_hold_every_coupling_entry_under_its_column_owner(case):
+    """ADMM slots and the owner gather of the tile kernels (csrc/rldl_plan.c): slot 0 holds the variables, slots 1-2 the
+    constraints by decreasing column count; the lane that owns position c holds the entries L(r, c) of its column on the
+    steps of its slot ([0, sp) for the first constraint slot, [sp, tk) for the second; sp = 3 tk / 4 or 2 tk / 3), each exactly once with its
+    factor slot and its row (local to the tail group)."""
+    from osqp_recursive_ldl_amd.linsys import plan_export
+    wl = {"arrowhead": lambda: R.workloads.SharedPatternQPs(),
+          "small": lambda: R.workloads.SharedPatternQPs(n=20, m=35, density=0.2, pattern_seed=5),
+          "g30": lambda: R.workloads.SharedPatternQPs(n=30, m=60, density=0.2, pattern_seed=3)}[case]()
+    pl = plan_export(wl.P_pattern, wl.A_pattern)
+    sym = R.symbolic_analyze(wl.P_pattern, wl.A_pattern)
+    if not pl["tile_admm_ok"]:
+        pytest.skip("no ADMM slot plan")
+    N, tk = wl.n + wl.m, pl["tile_tk"]
+    assert pl["tile_vslots"] == 1 and pl["tile_slots"] <= 3 and tk in (16, 24, 32)
+    ck = [pl["tile_ck0"], pl["tile_ck1"], pl["tile_ck2"]]
+    sp = pl["tile_sp"]
+    assert ck[0] == 0 and sp in (3 * tk // 4, (2 * tk // 3) & ~1) and ck[1] <= sp and ck[2] <= tk - sp
+    tpos = pl["blob"][pl["po_tpos"]:pl["po_tpos"] + 192].reshape(3, 64)
+    perm = sym["perm"]
+    owned = tpos[tpos >= 0]
+    assert sorted(owned.tolist()) == list(range(N))                                  # every permuted position has one owner
+    assert all(perm[j] < wl.n for j in tpos[0][tpos[0] >= 0]) and all(perm[j] >= wl.n for j in tpos[1:][tpos[1:] >= 0])
+    gs = pl["blob"][pl["po_gstart"]:pl["po_gstart"] + pl["ngroups"] + 1]
+    g0, g1 = int(gs[pl["arrow_group"]]), int(gs[pl["arrow_group"] + 1])
+    blob = pl["blob"].view(np.uint32)
+    cm = blob[pl["po_cmap"]:pl["po_cmap"] + (tk // 2) * 64].reshape(tk // 2, 64)
+    cr = blob[pl["po_crow"]:pl["po_crow"] + (tk // 2) * 64].reshape(tk // 2, 64)
+    Lp, Li = sym["Lp"], sym["Li"]
+    want = {}
+    for c in range(N):
+        for p in range(Lp[c], Lp[c + 1]):
+            r = int(Li[p])
+            if g0 <= r < g1 and not (g0 <= c < g1):
+                want[int(pl["LtoS"][p])] = (r - g0, c)
+    got = {}
+    for t in (1, 2):
+        lo, hi = (0, sp) if t == 1 else (sp, tk)
+        for lane in range(64):
+            for k in range(lo, hi):
+                slot = int((cm[k >> 1, lane] >> (16 * (k & 1))) & 0xffff)
+                row = int((cr[k >> 1, lane] >> (16 * (k & 1))) & 0xffff)
+                if slot == 0xffff:
+                    assert row == 0
+                    continue
+                assert tpos[t, lane] >= 0 and slot not in got and k - lo < ck[t]
+                got[slot] = (row, int(tpos[t, lane]))
+    assert got == want and len(want) == pl["nO"]
+    cnt = np.bincount([c for _, c in want.values()], minlength=N)
+    for t in (1, 2):                                                                   # decreasing column count inside a kind
+        cols = tpos[1:].ravel()[tpos[1:].ravel() >= 0]
+        assert all(cnt[cols[i]] >= cnt[cols[i + 1]] for i in range(len(cols) - 1))
