@@ -3149,8 +3149,10 @@ static bool tile_admm_usable(const rldl_dev_sym *S, const rldl_dev_num *Nn, cons
   }
 static int launch_tile_solve(const rldl_dev_sym *S, const rldl_dev_num *Nn, double *d_b, void *stream) {
   const int pw = tile_per_wave(S), grid = (Nn->batch + TILE_WPB - 1) / TILE_WPB;
-  const size_t lds = sizeof(double) * (size_t)(pw + WAVE) * TILE_WPB;
-#define TS(TMAX, TG, TA) hipLaunchKernelGGL((k_tile_solve<TMAX, TG, TA>), dim3(grid), dim3(TILE_WPB * WAVE), lds, (hipStream_t)stream, *S, *Nn, d_b, pw)
+  static const size_t pad = getenv("RLDL_SOLVE_LDS_PAD") ? (size_t)atol(getenv("RLDL_SOLVE_LDS_PAD")) : 0;   // occupancy experiments: LDS bytes per workgroup
+  const size_t lds0 = sizeof(double) * (size_t)(pw + WAVE) * TILE_WPB, lds = pad > lds0 ? pad : lds0;
+#define TS(TMAX, TG, TA) do { if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_tile_solve<TMAX, TG, TA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL((k_tile_solve<TMAX, TG, TA>), dim3(grid), dim3(TILE_WPB * WAVE), lds, (hipStream_t)stream, *S, *Nn, d_b, pw); } while (0)
   if (S->arrow_vsteps <= 12) {
 #define C(TA) TS(3, 12, TA)
     TILE_TA_SWITCH(C)
