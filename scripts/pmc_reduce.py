@@ -2,6 +2,7 @@
 """Reduce rocprofv3 --pmc passes to the JSON summaries bench.py reads from profiles/.
   pmc_reduce.py fused  <out.json> <dir> [<dir> ...]   SQ counters of the fused iteration kernel (scripts/pmc_run.py), per wave-iteration
   pmc_reduce.py traffic <out.json> <fetch_dir> <write_dir> <kernel substring> <algorithmic bytes per launch> <batch>
+  pmc_reduce.py mpc   <out.json> <dir> [<dir> ...]   SQ counters of the MPC kernels (scripts/pmc_run_mpc.py), per wave and launch
 """
 import csv, glob, json, os, sys
 
@@ -26,6 +27,13 @@ if mode == "fused":
            "launches": {k: v[1] for k, v in c.items()}, "per_launch": {k: v[0] for k, v in c.items()},
            "per_wave_iteration": {k: v[0] / (B * iters) for k, v in c.items()},
            "units": "SQ_WAVE_CYCLES, SQ_WAIT_*, SQ_ACTIVE_INST_* count quad-cycles; SQ_LDS_IDX_ACTIVE and SQ_LDS_BANK_CONFLICT count LDS-array cycles; SQ_INSTS_* count wave instructions"}
+elif mode == "mpc":
+    B = 4096
+    res = {"workload": "scripts/pmc_run_mpc.py (MPC shape N=20 nx=12 nu=4 ny=10 nt=12, batch 4096)", "batch": B,
+           "units": "per wave (= per instance) and launch; SQ_WAVE_CYCLES, SQ_WAIT_*, SQ_ACTIVE_INST_* count quad-cycles; SQ_LDS_* count LDS-array cycles"}
+    for kern in ("k_stage_factor_r", "k_plan_solve", "k_plan_admm_loop"):
+        c = collect(sys.argv[3:], kern)
+        res[kern] = {"launches": {k: v[1] for k, v in c.items()}, "per_wave_and_launch": {k: v[0] / B for k, v in c.items()}}
 else:
     fd, wd, kern, alg, B = sys.argv[3], sys.argv[4], sys.argv[5], int(sys.argv[6]), int(sys.argv[7])
     fe, wr = collect([fd], kern).get("FETCH_SIZE", (0.0, 0)), collect([wd], kern).get("WRITE_SIZE", (0.0, 0))
