@@ -18,8 +18,9 @@ for _ in range(3):
 b = torch.randn((B, wl.n + wl.m), dtype=torch.float64, device="cuda")
 print("solve ms per launch:", ls.time_solve(b, reps=20))
 ls.free()
-w = R.OSQPBatch(wl.P_pattern, wl.A_pattern, dPx, dAx, t(q), t(l), t(u), perm=R.workloads.stage_permutation(*wl.dims), rho=0.1, sigma=1e-6,
-                alpha=1.6, max_iter=20, check_termination=0, adaptive_rho=0, warm_start=0, scaling=0)
+kw = dict(rho=0.1, sigma=1e-6, alpha=1.6, max_iter=20, check_termination=0, adaptive_rho=0, warm_start=0, scaling=0)
+w = R.OSQPBatch.recursive(wl.dims, wl.Q0, wl.Qi, wl.QN, wl.A0, wl.Ai, wl.Aij, wl.AN, t(q), t(l), t(u), **kw)   # osqp_setup_recursive: stage kernels
+w.update_recursive(0, dPx, dAx)
 w.solve()
 torch.cuda.synchronize()
 print("loop:", w.last_loop())
