@@ -458,6 +458,25 @@ c_int rldl_batch_export_factor(const rldl_batch *h, c_int inst, c_float *Lx, c_f
   return 0;
 }
 
+c_int rldl_batch_export_prod(const rldl_batch *h, c_int inst, c_int *meta, int *prog, int *tinfo, unsigned *tab, unsigned short *src,
+                             int *blk, c_float *Ti) {
+  const rldl_dev_stage *G;
+  if (!h || !meta || inst < 0 || inst >= h->batch) return 1;
+  G = &h->dsym.stage;
+  memset(meta, 0, sizeof(c_int) * 8);
+  if (!G->pv_ok || !h->num.Ti) return 1;
+  if (!HIP_OK(hipStreamSynchronize((hipStream_t)h->stream))) return 1;
+  meta[0] = 1; meta[1] = G->pv_ntiles; meta[2] = G->pv_ntab; meta[3] = G->pv_nTi; meta[4] = G->nb; meta[5] = G->ld; meta[6] = G->pv_kmax;
+  meta[7] = G->pv_nsteps;
+  if (prog && !HIP_OK(hipMemcpy(prog, G->pv_prog, sizeof(int) * 12 * (size_t)G->pv_nsteps, hipMemcpyDeviceToHost))) return 1;
+  if (tinfo && !HIP_OK(hipMemcpy(tinfo, G->pv_tinfo, sizeof(int) * 4 * (size_t)(G->pv_ntiles + 1), hipMemcpyDeviceToHost))) return 1;
+  if (tab && !HIP_OK(hipMemcpy(tab, G->pv_tab, sizeof(unsigned) * (size_t)G->pv_ntab, hipMemcpyDeviceToHost))) return 1;
+  if (src && G->pv_nTi && !HIP_OK(hipMemcpy(src, G->pv_src, sizeof(unsigned short) * (size_t)G->pv_nTi, hipMemcpyDeviceToHost))) return 1;
+  if (blk && !HIP_OK(hipMemcpy(blk, G->pv_blk, sizeof(int) * 2 * (size_t)G->nb, hipMemcpyDeviceToHost))) return 1;
+  if (Ti && G->pv_nTi && !HIP_OK(hipMemcpy(Ti, h->num.Ti + (size_t)inst * (size_t)G->pv_ldTi, sizeof(double) * (size_t)G->pv_nTi, hipMemcpyDeviceToHost))) return 1;
+  return 0;
+}
+
 c_int rldl_batch_factor_status(const rldl_batch *h, c_int *status) {
   c_int b;
   if (!h || !status) return 1;

@@ -15,6 +15,7 @@ extern "C" {
 /* Dense stage-block view of a block-tridiagonal (MPC) pattern for k_stage_factor: per diagonal block b the
  * entries of the permuted KKT matrix and of L that fall into block (b, b) and into the coupling block (b+1, b), each
  * with its position in a dense ld x ld LDS tile (row * ld + col, rows/cols local to their blocks). */
+#define RLDL_PV_RING 4   /* groups of the product tri-solve whose loads are in flight + 1 (stage_prod_solve); pv_prog is padded to multiples of it */
 typedef struct {
   int nb, ld, smax;
   const int *bs;                          /* [nb+1] first permuted index of each block */
@@ -28,6 +29,23 @@ typedef struct {
   const unsigned *sv_pk;
   const int *sv_prog;
   int sv_ok, sv_ld, sv_coff, sv_ntiles;
+  /* product tri-solve (stage_prod_solve, k_stage_invert): the diagonal blocks are inverted behind every factorisation, so both
+   * passes are chains of sparse tile products without a dependent sweep.  Tiles in forward order D_0, C_0, D_1, ..., D_{nb-1}
+   * (D_b = -(strictly lower part of L_bb^-1), C_b = L(b+1, b); empty tiles are left out); rldl_dev_num.Ti holds their entries,
+   * tile after tile, step after step, lane after lane (layout: rldl_recursive.c, build_prod_tiles).  Every row of a tile has its
+   * own lanes, every lane takes <= 1 entry per step, steps come in groups of four:
+   *   pv_prog[12 s] = the group of step s of the kernel's sequence (forward groups, padding, backward groups, padding):
+   *                   { first Ti entry of the group, first table word, byte address in x of the tile's first column | first row << 16,
+   *                     1 (first group of its tile) | 2 (last), then the 64-bit lane mask of each of the four steps }
+   *   pv_tab        : one word per (group, lane) = columns of the lane's four entries (5 bits each, relative to the tile's first
+   *                   column) | one bit per step << 20 (lane has an entry) | the lane's row (relative) << 24 | 1 << 29 (lane has entries)
+   *   pv_tinfo[4 t] = { first Ti entry, entries, kind (0 = D, 1 = C), first group }
+   *   pv_src[i]     = where Ti entry i comes from: position row * ld + col in the inverted diagonal tile (D) / factor slot (C)
+   *   pv_blk[2 b], pv_blk[2 b + 1] = tile id of D_b, C_b or -1 */
+  const unsigned *pv_tab;
+  const int *pv_prog, *pv_tinfo, *pv_blk;
+  const unsigned short *pv_src;
+  int pv_ok, pv_ntiles, pv_ngroups, pv_nsteps, pv_kmax, pv_nTi, pv_ldTi, pv_ntab;
 } rldl_dev_stage;
 
 typedef struct {
@@ -120,6 +138,7 @@ int rldl_launch_kkt_assemble_keep(const rldl_dev_sym *S, const rldl_dev_num *Nn,
                                   double *keepA, void *stream);
 int rldl_launch_factor(const rldl_dev_sym *S, const rldl_dev_num *Nn, const int *d_mask, void *stream);
 int rldl_launch_stage_factor(const rldl_dev_sym *S, const rldl_dev_num *Nn, const int *d_mask, int first_block, void *stream);
+int rldl_launch_stage_invert(const rldl_dev_sym *S, const rldl_dev_num *Nn, void *stream);
 /* stage recursion where instance b restarts at block d_b0v[b] (0 = from the first block) */
 int rldl_launch_stage_factor_each(const rldl_dev_sym *S, const rldl_dev_num *Nn, const int *d_b0v, void *stream);
 /* horizon change (src/recursive_ldl.c:1973-2016): old horizon's workspace (So, Wo / No) -> new horizon's (Sn, Nn) */

@@ -1086,6 +1086,10 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+// LDS accesses by byte address (shb = base of the wave's LDS region)
+__device__ __forceinline__ double lds_ld(const char *shb, unsigned a) { return *reinterpret_cast<const double *>(shb + a); }
+__device__ __forceinline__ void lds_st(char *shb, unsigned a, double v) { *reinterpret_cast<double *>(shb + a) = v; }
+__device__ __forceinline__ void lds_add(char *shb, unsigned a, double v) { unsafeAtomicAdd(reinterpret_cast<double *>(shb + a), v); }
 __device__ __forceinline__ double readlane_f64(double v, int src) {   // src must be wave-uniform
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
@@ -1421,6 +1425,194 @@ __device__ __forceinline__ void stage_tri_solve(const rldl_dev_sym &S, const dou
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// stage_prod_solve -- the block tri-solve without dependent sweeps: k_stage_invert has replaced every diagonal block by the
+// inverse of its unit triangle, so  y_b = L_bb^-1 (b_b - L(b, b-1) y_{b-1})  and its transpose are chains of sparse tile
+// PRODUCTS (tiles D_0, C_0, D_1, ... of rldl_dev_stage.pv_*; forward pass = tiles in order, backward pass = the same tiles in
+// reverse order, transposed).  Every row of a tile has its own lanes; a lane takes one entry of its row per step, streamed from
+// Ti by plain coalesced loads whose addresses come from uniform data only (the step's lane mask, v_mbcnt):
+//   forward   every lane gathers x[col] of its entries from LDS and sums in a register; at the tile's last step the lanes of a
+//             row add their sums into x[row] (LDS atomic, as many lanes on a word as the row has lanes);
+//   backward  every lane reads x[row] once and ADDS  -v x[row]  into x[col] with an LDS atomic (the host orders a lane's
+//             entries so that the lanes of a step meet few equal columns).
+// LDS operations of a wave execute in order, so consecutive tiles need no wait between them.  Per wave x is the only LDS
+// array (stage_tri_solve above needs x + one dense tile and three passes over every tile's data in LDS).
+// Load pipeline: steps come in groups of four; the loads of a group (4 values and 1 table word per lane) are issued
+// RLDL_PV_RING - 1 groups ahead of their use into a register ring -- every group issues the same number of loads, in
+// straight-line code, so the waits are exact counts.  The host lays the groups out as the sequence the kernel walks
+// (forward, backward), so a step's descriptors are two scalar loads at consecutive addresses, fetched one step ahead.
+// ------------------------------------------------------------------------------------------------
+struct PvGrp { double v[4]; unsigned w; };                       // one ring slot: four values + the lane's word of the group
+struct PvGI { int ti0, wo; unsigned long long m[4]; };           // what issuing a group's loads needs, uniform (SGPRs); m = lane mask per step
+struct PvGC { int base, fl; unsigned long long m[4]; };          // what its products need
+typedef unsigned pv_v2u __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned long long pv_u64(int lo, int hi) { return (unsigned long long)(unsigned)lo | ((unsigned long long)(unsigned)hi << 32); }
+__device__ __forceinline__ PvGI pv_gdesc_i(sv_cptr_t q) {
+  PvGI d;
+  d.ti0 = q[0]; d.wo = q[1];
+#pragma unroll
+  for (int j = 0; j < 4; j++) d.m[j] = pv_u64(q[4 + 2 * j], q[5 + 2 * j]);
+  return d;
+}
+__device__ __forceinline__ PvGC pv_gdesc_c(sv_cptr_t q, bool fwd) {
+  PvGC d;
+  d.base = q[2]; d.fl = q[3];
+#pragma unroll
+  for (int j = 0; j < 4; j++) d.m[j] = fwd ? 0ull : pv_u64(q[4 + 2 * j], q[5 + 2 * j]);   // (only the backward products use the masks)
+  return d;
+}
+// set lanes of the uniform mask get a, the others b: one v_cndmask with the mask as its SGPR-pair condition
+__device__ __forceinline__ unsigned pv_select(unsigned long long mask, unsigned a, unsigned b) {
+  unsigned r;
+  asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(mask));
+  return r;
+}
+// LDS double atomic add by the lanes of a uniform mask (lds32 = LDS byte address)
+__device__ __forceinline__ void pv_masked_add(unsigned long long mask, unsigned lds32, double v) {
+  unsigned long long keep;
+  asm volatile("s_and_saveexec_b64 %0, %3\n\tds_add_f64 %1, %2\n\ts_mov_b64 exec, %0" : "=&s"(keep) : "v"(lds32), "v"(v), "s"(mask) : "memory", "scc");
+}
+// The loads of a group.  A lane's entry of a step sits at (entries of the earlier steps) + (set mask bits below the lane);
+// lanes outside the mask get an out-of-range offset: the buffer load returns 0.0 for them without touching memory.
+__device__ __forceinline__ void pv_issue(__amdgpu_buffer_rsrc_t rTi, __amdgpu_buffer_rsrc_t rTab, const PvGI &d, unsigned lane4, PvGrp &P) {
+  unsigned sb = 8u * (unsigned)d.ti0;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const unsigned mb = __builtin_amdgcn_mbcnt_hi((unsigned)(d.m[j] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)d.m[j], 0u));
+    const pv_v2u r = __builtin_amdgcn_raw_buffer_load_b64(rTi, pv_select(d.m[j], (mb << 3) + sb, 0xffffffffu), 0, 0);
+    P.v[j] = __hiloint2double((int)r.y, (int)r.x);
+    sb += 8u * (unsigned)__builtin_popcountll(d.m[j]);
+  }
+  P.w = __builtin_amdgcn_raw_buffer_load_b32(rTab, lane4 + 4u * (unsigned)d.wo, 0, 0);
+}
+template <bool FWD>
+__device__ __forceinline__ void pv_group(char *xb, unsigned xb32, const PvGC &d, const PvGrp &P, double &acc, double &own) {
+  const unsigned cb = (unsigned)d.base & 0xffffu, ra = ((unsigned)d.base >> 16) + (__builtin_amdgcn_ubfe(P.w, 24, 5) << 3);
+  if (FWD) {
+    if (d.fl & 1) acc = 0.0;
+    double g[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) g[j] = lds_ld(xb, (__builtin_amdgcn_ubfe(P.w, 5 * j, 5) << 3) + cb);
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc = fma(P.v[j], g[j], acc);    // (0.0 for lanes without an entry)
+    if (d.fl & 2)                                                // last group of the tile: the lanes of a row add their sums into x[row]
+      pv_masked_add(__builtin_amdgcn_ballot_w64((P.w >> 29) & 1u), xb32 + ra, -acc);
+  } else {
+    if (d.fl & 2) own = lds_ld(xb, ra);                          // (the backward pass meets a tile's last group first)
+#pragma unroll
+    for (int j = 0; j < 4; j++) pv_masked_add(d.m[j], (__builtin_amdgcn_ubfe(P.w, 5 * j, 5) << 3) + (xb32 + cb), -(P.v[j] * own));
+  }
+}
+__device__ __forceinline__ void stage_prod_solve(const rldl_dev_sym &S, const double *F, const double *Ti, double *xs, int lane) {
+  const rldl_dev_stage &G = S.stage;
+  const int NS = G.pv_nsteps;                                     // forward steps [0, NS / 2), backward steps [NS / 2, NS), both multiples of the ring
+  sv_cptr_t prog = (sv_cptr_t)(unsigned long long)G.pv_prog;
+  const double *Dinv = F + S.nS;
+  char *xb = reinterpret_cast<char *>(xs);
+  const unsigned xb32 = (unsigned)(unsigned long long)xb;         // low half of a generic LDS address = LDS byte address
+  const unsigned lane4 = 4u * (unsigned)lane;
+  const __amdgpu_buffer_rsrc_t rTi = __builtin_amdgcn_make_buffer_rsrc((void *)Ti, 0, 8 * G.pv_nTi, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rTab = __builtin_amdgcn_make_buffer_rsrc((void *)G.pv_tab, 0, 4 * G.pv_ntab, 0x00020000);
+  PvGrp P0, P1, P2, P3;
+  double acc = 0.0, own = 0.0;
+  {
+    const PvGI e0 = pv_gdesc_i(prog), e1 = pv_gdesc_i(prog + 12), e2 = pv_gdesc_i(prog + 24);
+    pv_issue(rTi, rTab, e0, lane4, P0); pv_issue(rTi, rTab, e1, lane4, P1); pv_issue(rTi, rTab, e2, lane4, P2);
+  }
+  sv_cptr_t qI = prog + 12 * (RLDL_PV_RING - 1), qC = prog;      // descriptors of the group to issue / to multiply
+  PvGI dI = pv_gdesc_i(qI);
+  // one step: issue the loads of step s + RING - 1 into the slot that came free, then the products of step s
+#define PV_STEP(FWD, PC, PN)                                                                                                    \
+  {                                                                                                                            \
+    const PvGC dC = pv_gdesc_c(qC, FWD);                                                                                       \
+    qI += 12; qC += 12;                                                                                                        \
+    const PvGI nI = pv_gdesc_i(qI);                                                                                            \
+    pv_issue(rTi, rTab, dI, lane4, PN);                                                                                        \
+    pv_group<FWD>(xb, xb32, dC, PC, acc, own);                                                                                 \
+    dI = nI;                                                                                                                   \
+  }
+#define PV_ROUND(FWD) PV_STEP(FWD, P0, P3) PV_STEP(FWD, P1, P0) PV_STEP(FWD, P2, P1) PV_STEP(FWD, P3, P2)
+  for (int s = 0; s < NS / 2; s += RLDL_PV_RING) { PV_ROUND(true) }
+  for (int j0 = 0; j0 < S.N; j0 += 4 * WAVE) {                   // D^-1 between the passes
+    double dd[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) { const int j = j0 + u * WAVE + lane; dd[u] = Dinv[min(j, S.N - 1)]; }
+#pragma unroll
+    for (int u = 0; u < 4; u++) { const int j = j0 + u * WAVE + lane; if (j < S.N) xs[j] *= dd[u]; }
+  }
+  for (int s = NS / 2; s < NS; s += RLDL_PV_RING) { PV_ROUND(false) }
+#undef PV_ROUND
+#undef PV_STEP
+  wave_sync();
+}
+
+// k_stage_invert -- behind every stage factorisation of a handle with pv_ok: per diagonal block, L_bb goes from the factor's
+// slots into a dense LDS tile, lane c solves  L_bb X = e_c  by forward substitution with the rows of L_bb as LDS broadcast
+// reads (one address for all lanes, two entries per read), X goes back to LDS and its entries -X(r, c), r > c, to their places
+// in Ti (pv_src names the tile position behind every Ti entry); the coupling tiles are copied from their factor slots.
+// Blocks before the restart block keep their tiles.  SM = compile-time bound on the block width (blocks of <= 16 take the
+// 16-wide instance of the substitution).  One wave per instance.
+template <int SB>
+__device__ __forceinline__ void invert_block(const double *T, double *X, int ldT, int lane, int s) {
+  // column `lane` of X = L_bb^-1: x[r] = [r == lane] - sum_{k < r} L(r, k) x[k]   (x[k] = 0 for k < lane falls out by itself)
+  double x[SB];
+#pragma unroll
+  for (int r = 0; r < SB; r++) {
+    double acc = r == lane ? 1.0 : 0.0;
+    const double *row = T + r * ldT;                               // ldT even, T 16-byte aligned: pairs at even k are aligned
+#pragma unroll
+    for (int k = 0; k + 1 < r; k += 2) {
+      const double2 l2 = *reinterpret_cast<const double2 *>(row + k);
+      acc = fma(-l2.x, x[k], acc);
+      acc = fma(-l2.y, x[k + 1], acc);
+    }
+    if (r & 1) acc = fma(-row[r - 1], x[r - 1], acc);
+    x[r] = acc;
+  }
+  if (lane < s) {
+#pragma unroll
+    for (int r = 0; r < SB; r++) X[r * ldT + lane] = x[r];
+  }
+}
+template <int SM>
+__global__ __launch_bounds__(WAVE) void k_stage_invert(rldl_dev_sym S, rldl_dev_num Nn, const int *__restrict__ mask, int b0,
+                                                       const int *__restrict__ b0v) {
+  const int inst = blockIdx.x, lane = threadIdx.x;
+  if (mask && !mask[inst]) return;
+  if (b0v) b0 = __builtin_amdgcn_readfirstlane(b0v[inst]);
+  const rldl_dev_stage &G = S.stage;
+  const int ld = G.ld, nb = G.nb;
+  constexpr int ldT = SM + 2;                                     // even
+  extern __shared__ __attribute__((aligned(16))) double sh[];
+  double *T = sh, *X = sh + SM * ldT;                             // [SM][ldT] each
+  const double *F = Nn.F + (size_t)inst * S.ldF;
+  double *To = Nn.Ti + (size_t)inst * G.pv_ldTi;
+  sv_cptr_t tinfo = (sv_cptr_t)(unsigned long long)G.pv_tinfo;
+  sv_cptr_t blk = (sv_cptr_t)(unsigned long long)G.pv_blk;
+  for (int b = b0; b < nb; b++) {
+    const int td = blk[2 * b], tc = blk[2 * b + 1];
+    if (tc >= 0) {                                               // coupling tile L(b + 1, b): slot -> Ti
+      const int t0 = tinfo[4 * tc], E = tinfo[4 * tc + 1];
+      for (int e = lane; e < E; e += WAVE) To[t0 + e] = F[G.pv_src[t0 + e]];
+    }
+    if (td < 0) continue;
+    const int s = G.bs[b + 1] - G.bs[b];
+    for (int p = lane; p < SM * ldT; p += WAVE) T[p] = 0.0;
+    wave_sync();
+    for (int e = G.ld_ptr[b] + lane; e < G.ld_ptr[b + 1]; e += WAVE) {
+      const int pos = G.ld_pos[e];
+      T[(pos / ld) * ldT + pos % ld] = F[G.ld_slot[e]];
+    }
+    wave_sync();
+    if (SM > 16 && s <= 16) invert_block<16>(T, X, ldT, lane, s);
+    else invert_block<SM>(T, X, ldT, lane, s);
+    wave_sync();
+    const int t0 = tinfo[4 * td], E = tinfo[4 * td + 1];
+    for (int e = lane; e < E; e += WAVE) { const int pos = G.pv_src[t0 + e]; To[t0 + e] = -X[(pos / ld) * ldT + pos % ld]; }
+    wave_sync();
+  }
+}
+
 // cooperative staging: plan blob -> LDS by LDS-DMA, 16-byte pieces spread over the workgroup's waves
 // (the device copy of the blob is padded to a multiple of 4 words)
 __device__ __forceinline__ void stage_plan(const rldl_dev_sym &S, int *wl) {
@@ -1451,8 +1643,8 @@ __device__ __forceinline__ void wait_dma() { asm volatile("s_waitcnt vmcnt(0)" :
 // global memory / L2 (their addresses do not depend on x, so the batched reads still pipeline) and only the
 // plan and x live in LDS -- the variant for patterns whose row would leave one wave per CU.
 // BLK > 0: block-tridiagonal pattern solved by stage_tri_solve<BLK> (no plan blob; LDS per wave = x + one tile)
-template <bool STAGE, int BLK = 0>
-__global__ __launch_bounds__(1024) void k_plan_solve(rldl_dev_sym S, rldl_dev_num Nn, double *__restrict__ b_all, int per_wave) {
+template <bool STAGE, int BLK = 0, bool PROD = false>
+__global__ __launch_bounds__(PROD ? 256 : 1024, PROD ? 4 : 1) void k_plan_solve(rldl_dev_sym S, rldl_dev_num Nn, double *__restrict__ b_all, int per_wave) {
   extern __shared__ __attribute__((aligned(16))) double sh[];
   const int lane = threadIdx.x & (WAVE - 1), wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wpb = blockDim.x >> 6;
   const int inst = blockIdx.x * wpb + wv;
@@ -1482,7 +1674,8 @@ __global__ __launch_bounds__(1024) void k_plan_solve(rldl_dev_sym S, rldl_dev_nu
   __syncthreads();
   if (!live) return;
   const int *perm = BLK ? S.plan + S.po_perm : wl + S.po_perm;
-  if constexpr (BLK > 0) stage_tri_solve<BLK>(S, Sv, xs, xs + ((S.N + 1) & ~1), lane);
+  if constexpr (PROD) stage_prod_solve(S, Sv, Nn.Ti + (size_t)inst * S.stage.pv_ldTi, xs, lane);
+  else if constexpr (BLK > 0) stage_tri_solve<BLK>(S, Sv, xs, xs + ((S.N + 1) & ~1), lane);
   else plan_tri_solve(S, wl, Sv, xs, lane);
   if (S.polish) {
     for (int j = lane; j < S.N; j += WAVE) b[perm[j]] = xs[j];  // permutet_x :544-547, raw solution :563-565
@@ -1597,8 +1790,8 @@ __global__ __launch_bounds__(1024) void k_plan_admm(rldl_dev_sym S, rldl_dev_num
 
 // Large-N variant of the fused iteration: the per-position vectors do not fit in registers, so the right-hand side is
 // built and the x/z/y update applied in batches of four positions per lane (two extra memory latencies per batch).
-template <bool STAGE, int BLK = 0>
-__global__ __launch_bounds__(1024) void k_plan_admm_loop(rldl_dev_sym S, rldl_dev_num Nn, rldl_dev_admm W, int per_wave) {
+template <bool STAGE, int BLK = 0, bool PROD = false>
+__global__ __launch_bounds__(PROD ? 256 : 1024, PROD ? 4 : 1) void k_plan_admm_loop(rldl_dev_sym S, rldl_dev_num Nn, rldl_dev_admm W, int per_wave) {
   extern __shared__ __attribute__((aligned(16))) double sh[];
   const int lane = threadIdx.x & (WAVE - 1), wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wpb = blockDim.x >> 6;
   const int inst = blockIdx.x * wpb + wv;
@@ -1641,7 +1834,8 @@ __global__ __launch_bounds__(1024) void k_plan_admm_loop(rldl_dev_sym S, rldl_de
   wait_dma();
   __syncthreads();
   if (!live) return;
-  if constexpr (BLK > 0) stage_tri_solve<BLK>(S, Sv, xs, xs + ((S.N + 1) & ~1), lane);
+  if constexpr (PROD) stage_prod_solve(S, Sv, Nn.Ti + io * S.stage.pv_ldTi, xs, lane);
+  else if constexpr (BLK > 0) stage_tri_solve<BLK>(S, Sv, xs, xs + ((S.N + 1) & ~1), lane);
   else plan_tri_solve(S, wl, Sv, xs, lane);
   const double alpha = W.alpha;
   double *dx = W.delta_x + io * n, *dy = W.delta_y + io * m;
@@ -2447,9 +2641,6 @@ __device__ __forceinline__ void arrow_load_val_global(const rldl_dev_sym &S, con
 }
 // All LDS traffic of the tile kernels goes through absolute byte addresses that are built once per launch and kept PACKED,
 // two 16-bit addresses per register (a workgroup's dynamic LDS stays below 64 KiB): one v_and / v_lshrrev per access.
-__device__ __forceinline__ double lds_ld(const char *shb, unsigned a) { return *reinterpret_cast<const double *>(shb + a); }
-__device__ __forceinline__ void lds_st(char *shb, unsigned a, double v) { *reinterpret_cast<double *>(shb + a) = v; }
-__device__ __forceinline__ void lds_add(char *shb, unsigned a, double v) { unsafeAtomicAdd(reinterpret_cast<double *>(shb + a), v); }
 __device__ __forceinline__ unsigned pk_lo(unsigned w) { return w & 0xffffu; }
 __device__ __forceinline__ unsigned pk_hi(unsigned w) { return w >> 16; }
 
@@ -2965,13 +3156,32 @@ static bool blk_usable(const rldl_dev_sym *S) {
     case 32: hipLaunchKernelGGL((KERNEL<false, 32>), dim3(grid), dim3(wpb * WAVE), lds, (hipStream_t)stream, __VA_ARGS__); break; \
     default: return -1;                                                                                                        \
   }
+// product form (stage_prod_solve): Ti holds the tiles, x is the only LDS array
+static bool prod_usable(const rldl_dev_sym *S, const rldl_dev_num *Nn) {
+  static const int off = getenv("RLDL_NO_STAGE_PROD") ? 1 : 0;
+  return !off && S->stage.pv_ok && Nn->Ti;
+}
+#define PROD_WPB 4
+static int prod_per_wave_doubles(const rldl_dev_sym *S) { return ((S->N + 1) & ~1) + 2; }
 static int launch_blk_solve(const rldl_dev_sym *S, const rldl_dev_num *Nn, double *d_b, void *stream) {
+  if (prod_usable(S, Nn)) {
+    const int pw = prod_per_wave_doubles(S), grid = (Nn->batch + PROD_WPB - 1) / PROD_WPB;
+    hipLaunchKernelGGL((k_plan_solve<false, 1, true>), dim3(grid), dim3(PROD_WPB * WAVE), sizeof(double) * (size_t)pw * PROD_WPB, (hipStream_t)stream,
+                       *S, *Nn, d_b, pw);
+    return launch_status();
+  }
   const int wpb = blk_pick_wpb(S), pw = blk_per_wave_doubles(S), grid = (Nn->batch + wpb - 1) / wpb;
   const size_t lds = sizeof(double) * (size_t)pw * wpb;
   BLK_DISPATCH(k_plan_solve, *S, *Nn, d_b, pw)
   return launch_status();
 }
 static int launch_blk_admm(const rldl_dev_sym *S, const rldl_dev_num *Nn, const rldl_dev_admm *W, void *stream) {
+  if (prod_usable(S, Nn)) {
+    const int pw = prod_per_wave_doubles(S), grid = (Nn->batch + PROD_WPB - 1) / PROD_WPB;
+    hipLaunchKernelGGL((k_plan_admm_loop<false, 1, true>), dim3(grid), dim3(PROD_WPB * WAVE), sizeof(double) * (size_t)pw * PROD_WPB,
+                       (hipStream_t)stream, *S, *Nn, *W, pw);
+    return launch_status();
+  }
   const int wpb = blk_pick_wpb(S), pw = blk_per_wave_doubles(S), grid = (Nn->batch + wpb - 1) / wpb;
   const size_t lds = sizeof(double) * (size_t)pw * wpb;
   BLK_DISPATCH(k_plan_admm_loop, *S, *Nn, *W, pw)
@@ -3276,6 +3486,23 @@ static int launch_factor(const rldl_dev_sym *S, const rldl_dev_num *Nn, const in
   return launch_tile_invert(S, Nn, d_mask, stream);
 }
 
+// tiles of the product tri-solve (k_stage_invert) behind a stage factorisation.  Per-instance restart blocks come from a horizon
+// change, whose adopted columns arrive without their tiles: every block is redone then.
+static int launch_stage_invert(const rldl_dev_sym *S, const rldl_dev_num *Nn, const int *d_mask, int first_block, const int *d_b0v,
+                               void *stream) {
+  const rldl_dev_stage *G = &S->stage;
+  if (!G->pv_ok || !Nn->Ti || G->smax > 32) return 0;
+  const int sm = G->smax <= 8 ? 8 : G->smax <= 16 ? 16 : G->smax <= 24 ? 24 : 32;
+  if (G->ld < sm + 1) return -1;
+  const size_t lds = sizeof(double) * (size_t)(2 * sm * (sm + 2));
+  const dim3 grid(Nn->batch), blk(WAVE);
+  const int b0 = d_b0v ? 0 : first_block;
+  if (sm == 8) hipLaunchKernelGGL(k_stage_invert<8>, grid, blk, lds, (hipStream_t)stream, *S, *Nn, d_mask, b0, (const int *)0);
+  else if (sm == 16) hipLaunchKernelGGL(k_stage_invert<16>, grid, blk, lds, (hipStream_t)stream, *S, *Nn, d_mask, b0, (const int *)0);
+  else if (sm == 24) hipLaunchKernelGGL(k_stage_invert<24>, grid, blk, lds, (hipStream_t)stream, *S, *Nn, d_mask, b0, (const int *)0);
+  else hipLaunchKernelGGL(k_stage_invert<32>, grid, blk, lds, (hipStream_t)stream, *S, *Nn, d_mask, b0, (const int *)0);
+  return launch_status();
+}
 static int launch_stage_factor(const rldl_dev_sym *S, const rldl_dev_num *Nn, const int *d_mask, int first_block, const int *d_b0v,
                                void *stream) {
   if (Nn->batch <= 0) return 0;
@@ -3284,7 +3511,8 @@ static int launch_stage_factor(const rldl_dev_sym *S, const rldl_dev_num *Nn, co
   if (getenv("RLDL_STAGE_LDS") || G->smax > 32) {                // LDS-resident panel (reference version of the same recursion)
     const size_t lds = sizeof(double) * (size_t)(3 * G->smax * G->ld + 2 * G->ld);
     hipLaunchKernelGGL(k_stage_factor, dim3(Nn->batch), dim3(WAVE), lds, (hipStream_t)stream, *S, *Nn, d_mask, first_block, d_b0v);
-    return launch_status();
+    if (launch_status()) return -1;
+    return launch_stage_invert(S, Nn, d_mask, first_block, d_b0v, stream);
   }
   // matrix-core Schur complement (see k_stage_factor_r) when the result tiles fit the staging tile; RLDL_NO_MFMA=1: fma form
   static const int no_mfma = getenv("RLDL_NO_MFMA") ? 1 : 0;
@@ -3300,7 +3528,12 @@ static int launch_stage_factor(const rldl_dev_sym *S, const rldl_dev_num *Nn, co
   else if (sm == 24) SF(24);
   else SF(32);
 #undef SF
-  return launch_status();
+  if (launch_status()) return -1;
+  return launch_stage_invert(S, Nn, d_mask, first_block, d_b0v, stream);
+}
+// tiles of the product tri-solve from the factor as it stands (a handle that becomes stage-structured after its first factorisation)
+extern "C" int rldl_launch_stage_invert(const rldl_dev_sym *S, const rldl_dev_num *Nn, void *stream) {
+  return Nn->batch > 0 ? launch_stage_invert(S, Nn, 0, 0, 0, stream) : 0;
 }
 extern "C" int rldl_launch_stage_factor(const rldl_dev_sym *S, const rldl_dev_num *Nn, const int *d_mask, int first_block, void *stream) {
   return launch_stage_factor(S, Nn, d_mask, first_block, 0, stream);

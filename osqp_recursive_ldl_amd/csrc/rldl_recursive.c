@@ -46,7 +46,7 @@ void rldl_stage_maps_free(rldl_batch *h) {
 #define FRI(p) if (p) (void)hipFree((void *)(p))
   FRI(G->bs); FRI(G->kd_ptr); FRI(G->kd_src); FRI(G->kd_pos); FRI(G->kc_ptr); FRI(G->kc_src); FRI(G->kc_pos);
   FRI(G->ld_ptr); FRI(G->ld_slot); FRI(G->ld_pos); FRI(G->lc_ptr); FRI(G->lc_slot); FRI(G->lc_pos);
-  FRI(G->sv_pk); FRI(G->sv_prog);
+  FRI(G->sv_pk); FRI(G->sv_prog); FRI(G->pv_tab); FRI(G->pv_prog); FRI(G->pv_tinfo); FRI(G->pv_blk); FRI(G->pv_src);
 #undef FRI
   memset(G, 0, sizeof(*G));
   free(h->rec); h->rec = 0;
@@ -112,6 +112,159 @@ static void build_solve_tiles(rldl_batch *h, const int *bs, int nb, int ld, cons
   if (G->sv_pk && G->sv_prog) { G->sv_ok = 1; G->sv_ld = lds; G->sv_coff = rc | (rd << 8); G->sv_ntiles = 2 * nb; }
 out:
   free(pk); free(prog);
+}
+
+/* Tables of the product tri-solve (stage_prod_solve / k_stage_invert, layout in rldl_device.h).  The pattern of a diagonal
+ * tile is the pattern of the inverse of L_bb (its transitive closure inside the block).  Per tile: a row with n entries gets
+ * ceil(n / K) lanes of its own (K = steps of the tile = 4 x its groups, the fewest groups for which 64 lanes are enough) and
+ * deals its entries round robin to them; a lane takes one entry per step.  The entries of a step sit in Ti in LANE ORDER, so
+ * the kernel finds a lane's entry from the step's 64-bit lane mask alone (v_mbcnt), and the same mask predicates the backward
+ * pass's atomics.  Steps come in GROUPS of four, the unit of the kernel's load pipeline.  Which of its entries a lane takes in
+ * which step is chosen step by step against the column use of the step: the backward pass adds into the columns with LDS
+ * atomics, whose cost grows with the number of lanes on one word.  pv_prog is the kernel's STEP SEQUENCE: the groups in
+ * forward order, closing (empty) groups up to a multiple of the ring size, the groups in backward order, closing groups. */
+#define PV_KMAX 12
+#define PV_GS 4                                                     /* steps per group */
+#define PV_DW 12                                                    /* descriptor words per group */
+static void build_prod_tiles(rldl_batch *h, const int *bs, int nb, int ld, const int *dptr, const int *dpos, const int *cptr,
+                             const int *cslot, const int *cpos) {
+  rldl_dev_stage *G = &h->dsym.stage;
+  const int smax = G->smax, ntmax = 2 * nb, ngmax = 2 * nb * (PV_KMAX / PV_GS);
+  unsigned char *pat = 0;                       /* [smax][smax] pattern of the tile at hand */
+  int *rows_e = 0, *cnt = 0, *used = 0, *prog = 0, *seq = 0, *blk = 0, *tinfo = 0, *ent_src = 0, *colcnt = 0, *order = 0;
+  unsigned *tab = 0;
+  unsigned short *src = 0;
+  int b, t = 0, g = 0, nTi = 0, ntab = 0, kmax = 0, r, c, k, e, kind, ok = 0, i, NGp, nsteps = 0;
+  size_t tabcap = (size_t)ngmax * 64 + 256, srccap = 0;
+  if (getenv("RLDL_NO_STAGE_PROD") || h->dsym.ldF >= 65536 || (h->sym->N + 2) * 8 >= 65536 || smax > 32) return;
+  for (b = 0; b < nb; b++) srccap += (size_t)smax * (size_t)smax;
+  srccap += (size_t)cptr[nb];
+  pat = (unsigned char *)malloc((size_t)smax * smax);
+  rows_e = (int *)malloc(sizeof(int) * (size_t)smax * smax);     /* entries of the tile: column per (row, i) */
+  ent_src = (int *)malloc(sizeof(int) * (size_t)smax * smax);    /* ... and where the value comes from */
+  cnt = (int *)malloc(sizeof(int) * (size_t)smax);
+  order = (int *)malloc(sizeof(int) * (size_t)smax);
+  used = (int *)malloc(sizeof(int) * (size_t)smax * smax);
+  colcnt = (int *)malloc(sizeof(int) * (size_t)smax);
+  prog = (int *)calloc((size_t)PV_DW * (size_t)(ngmax + 1), sizeof(int));
+  seq = (int *)calloc((size_t)PV_DW * (size_t)(2 * ngmax + 4 * RLDL_PV_RING), sizeof(int));
+  tinfo = (int *)calloc((size_t)4 * (size_t)(ntmax + 1), sizeof(int));
+  blk = (int *)malloc(sizeof(int) * (size_t)(2 * nb));
+  tab = (unsigned *)calloc(tabcap, sizeof(unsigned));
+  src = (unsigned short *)malloc(sizeof(unsigned short) * (srccap + 1));
+  if (!pat || !rows_e || !ent_src || !cnt || !order || !used || !colcnt || !prog || !seq || !tinfo || !blk || !tab || !src) goto out;
+  ntab = 64;                                                          /* words [0, 64): zero = the closing groups' table words (no entries) */
+  for (b = 0; b < nb; b++) {
+    for (kind = 0; kind < 2; kind++) {
+      const int s = bs[b + 1] - bs[b];                                  /* columns of the tile */
+      const int R = kind == 0 ? s : (b + 1 < nb ? bs[b + 2] - bs[b + 1] : 0);
+      const int rowbase = kind == 0 ? bs[b] : bs[b + 1], colbase = bs[b];
+      int E = 0, K = 0, nzr = 0, NG = 0, lanes = 0;
+      int lane_row[64], lane_p[64], lane_h[64];
+      blk[2 * b + kind] = -1;
+      if (R <= 0) continue;
+      /* entries per row: column + source */
+      for (r = 0; r < R; r++) cnt[r] = 0;
+      if (kind == 0) {
+        memset(pat, 0, (size_t)smax * smax);
+        for (e = dptr[b]; e < dptr[b + 1]; e++) pat[(dpos[e] / ld) * smax + dpos[e] % ld] = 1;
+        for (r = 0; r < s; r++)                                           /* closure: inv(r, c) if L(r, k) and (k == c or inv(k, c)) */
+          for (c = 0; c < r; c++) {
+            int hit = pat[r * smax + c];
+            for (k = c + 1; k < r && !hit; k++) if (pat[r * smax + k] == 1 && pat[k * smax + c]) hit = 1;
+            if (hit && !pat[r * smax + c]) pat[r * smax + c] = 2;        /* 2: fill of the inverse (counts as an entry from here on) */
+          }
+        for (r = 0; r < s; r++)
+          for (c = 0; c < r; c++)
+            if (pat[r * smax + c]) { rows_e[r * smax + cnt[r]] = c; ent_src[r * smax + cnt[r]] = r * ld + c; cnt[r]++; }
+      } else {
+        for (e = cptr[b]; e < cptr[b + 1]; e++) {
+          r = cpos[e] / ld; c = cpos[e] % ld;
+          rows_e[r * smax + cnt[r]] = c; ent_src[r * smax + cnt[r]] = cslot[e]; cnt[r]++;
+        }
+      }
+      for (r = 0; r < R; r++) { E += cnt[r]; if (cnt[r]) order[nzr++] = r; }
+      if (!E) continue;
+      for (i = 1; i < nzr; i++) {                                         /* rows by entries descending (insertion sort, stable) */
+        const int v = order[i];
+        for (k = i; k > 0 && cnt[order[k - 1]] < cnt[v]; k--) order[k] = order[k - 1];
+        order[k] = v;
+      }
+      for (NG = 1; NG <= PV_KMAX / PV_GS; NG++) {                         /* fewest groups for which 64 lanes are enough */
+        K = NG * PV_GS;
+        for (lanes = 0, i = 0; i < nzr; i++) lanes += (cnt[order[i]] + K - 1) / K;
+        if (lanes <= 64) break;
+      }
+      if (NG > PV_KMAX / PV_GS || E >= 65535 || t >= ntmax || g + NG > ngmax || s > 32 || R > 32) goto out;
+      if (K > kmax) kmax = K;
+      for (lanes = 0, i = 0; i < nzr; i++) {
+        const int H = (cnt[order[i]] + K - 1) / K;
+        for (k = 0; k < H; k++) { lane_row[lanes] = order[i]; lane_p[lanes] = k; lane_h[lanes] = H; lanes++; }
+      }
+      /* one word per (group, lane): columns of the lane's four entries (5 bits each, relative to the tile's first column) |
+       * one bit per step << 20 (the lane has an entry) | row of the lane (relative to the tile's first row) << 24 | 1 << 29 for
+       * lanes with entries in this tile */
+      memset(used, 0, sizeof(int) * (size_t)smax * smax);
+      e = 0;                                                              /* running Ti offset inside the tile */
+      for (k = 0; k < K; k++) {
+        const int gi = g + k / PV_GS, j = k % PV_GS;
+        int *q = prog + PV_DW * gi, lane;
+        unsigned *gw;
+        if (j == 0) {
+          q[0] = nTi + e; q[1] = ntab; q[2] = (8 * colbase) | ((8 * rowbase) << 16);
+          q[3] = (k == 0 ? 1 : 0) | (k / PV_GS == NG - 1 ? 2 : 0);
+          for (i = 4; i < PV_DW; i++) q[i] = 0;
+          for (lane = 0; lane < lanes; lane++) tab[ntab + lane] = ((unsigned)lane_row[lane] << 24) | (1u << 29);
+          ntab += 64;
+        }
+        gw = tab + q[1];
+        for (c = 0; c < s; c++) colcnt[c] = 0;
+        for (lane = 0; lane < lanes; lane++) {
+          const int rr = lane_row[lane], p = lane_p[lane], H = lane_h[lane];
+          const int n = cnt[rr] > p ? (cnt[rr] - p + H - 1) / H : 0;
+          int best = -1, ii;
+          if (k >= n) continue;
+          for (ii = p; ii < cnt[rr]; ii += H)
+            if (!used[rr * smax + ii] && (best < 0 || colcnt[rows_e[rr * smax + ii]] < colcnt[rows_e[rr * smax + best]])) best = ii;
+          used[rr * smax + best] = 1;
+          c = rows_e[rr * smax + best];
+          colcnt[c]++;
+          gw[lane] |= ((unsigned)c << (5 * j)) | (1u << (20 + j));
+          q[4 + 2 * j + (lane >> 5)] |= (int)(1u << (lane & 31));         /* the step's lane mask */
+          src[nTi + e] = (unsigned short)ent_src[rr * smax + best];
+          e++;
+        }
+      }
+      if (e != E) goto out;
+      tinfo[4 * t] = nTi; tinfo[4 * t + 1] = E; tinfo[4 * t + 2] = kind; tinfo[4 * t + 3] = g;
+      blk[2 * b + kind] = t;
+      nTi += E; t++; g += NG;
+    }
+  }
+  /* the step sequence: forward, padding, backward, padding, one ring of closing groups for the loads issued ahead */
+  NGp = ((g + RLDL_PV_RING - 1) / RLDL_PV_RING) * RLDL_PV_RING;
+  for (i = 0; i < g; i++) memcpy(seq + PV_DW * i, prog + PV_DW * i, sizeof(int) * PV_DW);
+  for (i = 0; i < g; i++) memcpy(seq + PV_DW * (NGp + i), prog + PV_DW * (g - 1 - i), sizeof(int) * PV_DW);
+  nsteps = 2 * NGp;
+  G->pv_tab = (const unsigned *)upload_ints((const int *)tab, (size_t)ntab);
+  G->pv_prog = upload_ints(seq, (size_t)PV_DW * (size_t)(nsteps + 2 * RLDL_PV_RING));
+  G->pv_tinfo = upload_ints(tinfo, (size_t)4 * (size_t)(t + 1));
+  G->pv_blk = upload_ints(blk, (size_t)2 * (size_t)nb);
+  {
+    unsigned short *d = 0;
+    if (hipMalloc((void **)&d, sizeof(unsigned short) * (size_t)(nTi + 1)) == hipSuccess) {
+      if (hipMemcpy(d, src, sizeof(unsigned short) * (size_t)nTi, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); d = 0; }
+    } else d = 0;
+    G->pv_src = d;
+  }
+  if (G->pv_tab && G->pv_prog && G->pv_tinfo && G->pv_blk && G->pv_src) {
+    G->pv_ntiles = t; G->pv_ngroups = g; G->pv_nsteps = nsteps; G->pv_kmax = kmax; G->pv_nTi = nTi; G->pv_ntab = ntab;
+    G->pv_ldTi = (nTi + 1) & ~1;
+    ok = 1;
+  }
+out:
+  G->pv_ok = ok;
+  free(pat); free(rows_e); free(ent_src); free(cnt); free(order); free(used); free(colcnt); free(prog); free(seq); free(tinfo); free(blk); free(tab); free(src);
 }
 
 /* 0: maps built and uploaded (h->dsym.stage.nb > 0); 1: the pattern does not qualify (generic kernels stay in use) */
@@ -201,6 +354,7 @@ static int build_stage_maps(rldl_batch *h) {
   if (!G.bs || !G.kd_ptr || !G.kd_src || !G.kd_pos || !G.kc_ptr || !G.kc_src || !G.kc_pos || !G.ld_ptr || !G.ld_slot || !G.ld_pos ||
       !G.lc_ptr || !G.lc_slot || !G.lc_pos) { rldl_stage_maps_free(h); goto out; }
   build_solve_tiles(h, bs, nb, ld, ptr[2], a[2], b[2], tot[2], ptr[3], a[3], b[3], tot[3]);   /* optional: sv_ok stays 0 on failure */
+  if (h->dsym.stage.sv_ok) build_prod_tiles(h, bs, nb, ld, ptr[2], b[2], ptr[3], a[3], b[3]);   /* optional as well */
   h->rec = malloc(sizeof(int) * (size_t)(nb + 2));
   if (!h->rec) { rldl_stage_maps_free(h); goto out; }
   ((int *)h->rec)[0] = nb;
@@ -218,6 +372,13 @@ void rldl_batch_enable_stage(rldl_batch *h, const rldl_stage_dims *dims) {
   h->stage = *dims;
   h->recursive = 1;
   if (!getenv("RLDL_NO_STAGE_FACTOR")) (void)build_stage_maps(h);
+  if (h->dsym.stage.pv_ok) {                                    /* tile values of the product tri-solve (k_stage_invert writes them) */
+    const size_t bytes = sizeof(double) * (size_t)h->batch * (size_t)h->dsym.stage.pv_ldTi;
+    if (h->num.Ti || hipMalloc((void **)&h->num.Ti, bytes) != hipSuccess) { if (!h->dsym.tile_ok) h->num.Ti = 0; h->dsym.stage.pv_ok = 0; }
+    else if (hipMemset(h->num.Ti, 0, bytes) != hipSuccess) { (void)hipFree(h->num.Ti); h->num.Ti = 0; h->dsym.stage.pv_ok = 0; }
+    /* a handle that was factorised before it became stage-structured (osqp_batch_setup_recursive): tiles from that factor */
+    else if (rldl_launch_stage_invert(&h->dsym, &h->num, h->stream)) { (void)hipFree(h->num.Ti); h->num.Ti = 0; h->dsym.stage.pv_ok = 0; }
+  }
 }
 
 /* first column (in the permuted matrix) of cost block Q_k, k = 0..N */

@@ -209,6 +209,21 @@ class BatchLinsys:
             raise RuntimeError("export_factor failed")
         return dict(Lx=Lx[:d["nnzL"]], D=D, Dinv=Dinv, KKTx=Kx)
 
+    def export_prod(self, inst=0):
+        """Stage handles: tables of the product tri-solve and the tile values of one instance (None when the handle has none)."""
+        L = _lib.lib()
+        meta = np.zeros(8, np.int64)
+        if L.rldl_batch_export_prod(self.h, int(inst), _ip(meta), None, None, None, None, None, None):
+            return None
+        nt, nw, nTi, nb, ng = int(meta[1]), int(meta[2]), int(meta[3]), int(meta[4]), int(meta[7])
+        prog = np.zeros(12 * max(ng, 1), np.int32); tinfo = np.zeros(4 * (nt + 1), np.int32); tab = np.zeros(max(nw, 1), np.uint32)
+        src = np.zeros(max(nTi, 1), np.uint16); blk = np.zeros(2 * nb, np.int32); Ti = np.zeros(max(nTi, 1))
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        if L.rldl_batch_export_prod(self.h, int(inst), _ip(meta), vp(prog), vp(tinfo), vp(tab), vp(src), vp(blk), _fp(Ti)):
+            raise RuntimeError("export_prod failed")
+        return dict(tiles=nt, steps=ng, nb=nb, ld=int(meta[5]), kmax=int(meta[6]), prog=prog.reshape(-1, 12), tinfo=tinfo.reshape(-1, 4)[:nt],
+                    tab=tab[:nw], src=src[:nTi], blk=blk.reshape(-1, 2), Ti=Ti[:nTi])
+
     def factor_status(self):
         st = np.zeros(self.batch, np.int64)
         _lib.lib().rldl_batch_factor_status(self.h, _ip(st))
