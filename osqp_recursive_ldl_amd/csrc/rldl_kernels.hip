@@ -1521,15 +1521,17 @@ __device__ __forceinline__ void stage_prod_solve(const rldl_dev_sym &S, const do
   }
   sv_cptr_t qI = prog + 12 * (RLDL_PV_RING - 1), qC = prog;      // descriptors of the group to issue / to multiply
   PvGI dI = pv_gdesc_i(qI);
-  // one step: issue the loads of step s + RING - 1 into the slot that came free, then the products of step s
+  PvGC dC = pv_gdesc_c(qC, true);
+  // one step: issue the loads of step s + RING - 1 into the slot that came free, then the products of step s; both descriptors of
+  // the NEXT step are fetched first (scalar loads), so no step starts by waiting for its descriptors
 #define PV_STEP(FWD, PC, PN)                                                                                                    \
   {                                                                                                                            \
-    const PvGC dC = pv_gdesc_c(qC, FWD);                                                                                       \
     qI += 12; qC += 12;                                                                                                        \
     const PvGI nI = pv_gdesc_i(qI);                                                                                            \
+    const PvGC nC = pv_gdesc_c(qC, FWD);                                                                                       \
     pv_issue(rTi, rTab, dI, lane4, PN);                                                                                        \
     pv_group<FWD>(xb, xb32, dC, PC, acc, own);                                                                                 \
-    dI = nI;                                                                                                                   \
+    dI = nI; dC = nC;                                                                                                          \
   }
 #define PV_ROUND(FWD) PV_STEP(FWD, P0, P3) PV_STEP(FWD, P1, P0) PV_STEP(FWD, P2, P1) PV_STEP(FWD, P3, P2)
   for (int s = 0; s < NS / 2; s += RLDL_PV_RING) { PV_ROUND(true) }
@@ -1540,6 +1542,7 @@ __device__ __forceinline__ void stage_prod_solve(const rldl_dev_sym &S, const do
 #pragma unroll
     for (int u = 0; u < 4; u++) { const int j = j0 + u * WAVE + lane; if (j < S.N) xs[j] *= dd[u]; }
   }
+  dC = pv_gdesc_c(qC, false);                                    // (the backward products use the lane masks as well)
   for (int s = NS / 2; s < NS; s += RLDL_PV_RING) { PV_ROUND(false) }
 #undef PV_ROUND
 #undef PV_STEP
@@ -3163,11 +3166,20 @@ static bool prod_usable(const rldl_dev_sym *S, const rldl_dev_num *Nn) {
 }
 #define PROD_WPB 4
 static int prod_per_wave_doubles(const rldl_dev_sym *S) { return ((S->N + 1) & ~1) + 2; }
+// dynamic LDS per workgroup of the product kernels: what the waves need, or RLDL_PROD_LDS bytes when that is more (a diagnostic:
+// fewer resident workgroups per CU)
+static size_t prod_lds_bytes(const rldl_dev_sym *S, const void *kernel) {
+  static const long forced = getenv("RLDL_PROD_LDS") ? atol(getenv("RLDL_PROD_LDS")) : 0;
+  size_t lds = sizeof(double) * (size_t)prod_per_wave_doubles(S) * PROD_WPB;
+  if (forced > 0 && (size_t)forced > lds) lds = (size_t)forced;
+  if (lds > 64 * 1024) (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  return lds;
+}
 static int launch_blk_solve(const rldl_dev_sym *S, const rldl_dev_num *Nn, double *d_b, void *stream) {
   if (prod_usable(S, Nn)) {
     const int pw = prod_per_wave_doubles(S), grid = (Nn->batch + PROD_WPB - 1) / PROD_WPB;
-    hipLaunchKernelGGL((k_plan_solve<false, 1, true>), dim3(grid), dim3(PROD_WPB * WAVE), sizeof(double) * (size_t)pw * PROD_WPB, (hipStream_t)stream,
-                       *S, *Nn, d_b, pw);
+    hipLaunchKernelGGL((k_plan_solve<false, 1, true>), dim3(grid), dim3(PROD_WPB * WAVE), prod_lds_bytes(S, (const void *)k_plan_solve<false, 1, true>),
+                       (hipStream_t)stream, *S, *Nn, d_b, pw);
     return launch_status();
   }
   const int wpb = blk_pick_wpb(S), pw = blk_per_wave_doubles(S), grid = (Nn->batch + wpb - 1) / wpb;
@@ -3178,7 +3190,7 @@ static int launch_blk_solve(const rldl_dev_sym *S, const rldl_dev_num *Nn, doubl
 static int launch_blk_admm(const rldl_dev_sym *S, const rldl_dev_num *Nn, const rldl_dev_admm *W, void *stream) {
   if (prod_usable(S, Nn)) {
     const int pw = prod_per_wave_doubles(S), grid = (Nn->batch + PROD_WPB - 1) / PROD_WPB;
-    hipLaunchKernelGGL((k_plan_admm_loop<false, 1, true>), dim3(grid), dim3(PROD_WPB * WAVE), sizeof(double) * (size_t)pw * PROD_WPB,
+    hipLaunchKernelGGL((k_plan_admm_loop<false, 1, true>), dim3(grid), dim3(PROD_WPB * WAVE), prod_lds_bytes(S, (const void *)k_plan_admm_loop<false, 1, true>),
                        (hipStream_t)stream, *S, *Nn, *W, pw);
     return launch_status();
   }

@@ -31,9 +31,14 @@ elif mode == "mpc":
     B = 4096
     res = {"workload": "scripts/pmc_run_mpc.py (MPC shape N=20 nx=12 nu=4 ny=10 nt=12, batch 4096)", "batch": B,
            "units": "per wave (= per instance) and launch; SQ_WAVE_CYCLES, SQ_WAIT_*, SQ_ACTIVE_INST_* count quad-cycles; SQ_LDS_* count LDS-array cycles"}
-    for kern in ("k_stage_factor_r", "k_plan_solve", "k_plan_admm_loop"):
+    for kern in ("k_stage_factor_r", "k_stage_invert", "k_plan_solve", "k_plan_admm_loop"):
         c = collect(sys.argv[3:], kern)
         res[kern] = {"launches": {k: v[1] for k, v in c.items()}, "per_wave_and_launch": {k: v[0] / B for k, v in c.items()}}
+    # HBM traffic when the FETCH_SIZE / WRITE_SIZE passes are among the directories (KB per launch; gfx950 correction: reads x 2)
+    for kern in ("k_stage_factor_r", "k_stage_invert", "k_plan_solve", "k_plan_admm_loop"):
+        c = collect(sys.argv[3:], kern)
+        if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            res[kern]["traffic_bytes_per_launch"] = 2 * 1024 * c["FETCH_SIZE"][0] + 1024 * c["WRITE_SIZE"][0]
 else:
     fd, wd, kern, alg, B = sys.argv[3], sys.argv[4], sys.argv[5], int(sys.argv[6]), int(sys.argv[7])
     fe, wr = collect([fd], kern).get("FETCH_SIZE", (0.0, 0)), collect([wd], kern).get("WRITE_SIZE", (0.0, 0))
