@@ -194,6 +194,20 @@ c_int osqp_batch_last_loop(osqp_batch *w, c_float *ms, c_int *iterations, c_int 
 c_int osqp_batch_trace_iteration(osqp_batch *w, c_int iters, long long *host_out);
 void  osqp_batch_cleanup(osqp_batch *w);                                /* osqp.c:646-744 */
 
+/* Several workspaces as one set (batches whose instances fall into a few sparsity patterns: one workspace per pattern, the
+ * "per-instance pattern" variant of BASELINE config 2).  With a fixed number of iterations (check_termination = 0, adaptive_rho = 0,
+ * polish = 0) osqp_multi_solve runs osqp_solve (osqp.c:354-641) of ALL workspaces in a handful of launches over the stacked instances
+ * (solve_begin, the fused iterations once per kernel instantiation the patterns select, the closing check)
+ * and osqp_multi_get writes the OSQPSolution / OSQPInfo fields in the caller's instance order: dest[k] = caller row of stacked
+ * instance k (workspace 0's instances first).  osqp_multi_create returns 2 when the set does not qualify (other settings, patterns
+ * off the tile kernels): solve the workspaces one by one then.  The workspaces stay owned by the caller. */
+typedef struct osqp_multi osqp_multi;
+c_int osqp_multi_create(osqp_multi **mp, osqp_batch **ws, c_int count, const c_int *dest, void *stream);
+c_int osqp_multi_solve(osqp_multi *mm);
+c_int osqp_multi_get(osqp_multi *mm, c_float *d_x, c_float *d_y, c_float *d_z, int *d_status, int *d_iter, c_float *d_obj,
+                     c_float *d_pri_res, c_float *d_dua_res);
+void  osqp_multi_free(osqp_multi *mm);
+
 /* =====================================================================================
  * 4. Stage-recursive LDL for MPC-structured KKT (src/recursive_ldl.c)
  * ===================================================================================== */

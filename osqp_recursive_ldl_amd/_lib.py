@@ -71,6 +71,7 @@ EXPORTED = [
     "rldl_symbolic_analyze", "rldl_stage_permutation", "rldl_plan_export", "rldl_setup_AP_matrices", "rldl_csc_free",
     "osqp_horizon_setup", "osqp_horizon_update", "osqp_horizon_workspace", "osqp_horizon_N", "osqp_horizon_last_update",
     "osqp_horizon_free",
+    "osqp_multi_create", "osqp_multi_solve", "osqp_multi_get", "osqp_multi_free",
 ]
 
 
@@ -115,6 +116,14 @@ def _declare(L):
     L.rldl_batch_export_factor.restype = c_int
     L.rldl_batch_export_prod.argtypes = [VP, c_int, IP, VP, VP, VP, VP, VP, FP]
     L.rldl_batch_export_prod.restype = c_int
+    L.osqp_multi_create.argtypes = [C.POINTER(VP), C.POINTER(VP), c_int, IP, VP]
+    L.osqp_multi_create.restype = c_int
+    L.osqp_multi_solve.argtypes = [VP]
+    L.osqp_multi_solve.restype = c_int
+    L.osqp_multi_get.argtypes = [VP] + [VP] * 8
+    L.osqp_multi_get.restype = c_int
+    L.osqp_multi_free.argtypes = [VP]
+    L.osqp_multi_free.restype = None
     L.rldl_batch_factor_status.argtypes = [VP, IP]
     L.rldl_batch_factor_status.restype = c_int
     L.rldl_batch_time_solve.argtypes = [VP, VP, c_int, FP]

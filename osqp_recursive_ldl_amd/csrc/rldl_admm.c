@@ -499,6 +499,136 @@ c_int osqp_batch_get(osqp_batch *w, c_float **d_x, c_float **d_y, c_float **d_z,
   return 0;
 }
 
+/* ---------------------------------------------------------------------------------------------------------------------
+ * Several workspaces in one launch chain ("per-instance pattern" variant of config 2): a batch whose instances
+ * fall into a few sparsity patterns has one workspace per pattern; with a fixed number of iterations (no termination checks, no
+ * rho adaptation, no polish) a solve of ALL of them is three launches -- solve_begin, the fused iterations, the closing check --
+ * over the stacked instances, each workgroup running on the structs of its own group (rldl_dev_multi), plus one launch that
+ * writes the results in the caller's instance order.  The fused iterations take one launch per kernel instantiation the
+ * patterns select (rldl_multi_key: two for the eight random patterns of the benchmark).  Patterns off the tile kernels or
+ * settings outside the fixed-iteration case make osqp_multi_create return 2: the caller solves the workspaces one by one.
+ * --------------------------------------------------------------------------------------------------------------------- */
+struct osqp_multi {
+  c_int count, total, n, m;
+  osqp_batch **ws;                                   /* sorted by kernel instantiation (rldl_multi_key): partitions are ranges of it */
+  rldl_dev_multi M;                                  /* all groups (solve_begin, closing check, gather); S / N / W = the device arrays below */
+  int nparts, part_first[RLDL_MULTI_MAX + 1], part_xdw[RLDL_MULTI_MAX];   /* partition p = groups [part_first[p], part_first[p + 1]) */
+  rldl_dev_sym *dS; rldl_dev_num *dN; rldl_dev_admm *dW;
+  rldl_dev_admm *hW;                                 /* pinned staging of the W structs (write_delta is set per solve) */
+  int *d_dest;
+  void *stream;
+};
+
+void osqp_multi_free(osqp_multi *mm) {
+  if (!mm) return;
+  if (mm->dS) (void)hipFree(mm->dS);
+  if (mm->dN) (void)hipFree(mm->dN);
+  if (mm->dW) (void)hipFree(mm->dW);
+  if (mm->hW) (void)hipHostFree(mm->hW);
+  if (mm->d_dest) (void)hipFree(mm->d_dest);
+  free(mm->ws);
+  free(mm);
+}
+
+c_int osqp_multi_create(osqp_multi **mp, osqp_batch **ws, c_int count, const c_int *dest, void *stream) {
+  osqp_multi *mm;
+  c_int g, total = 0;
+  int keys[RLDL_MULTI_MAX], order[RLDL_MULTI_MAX], first_orig[RLDL_MULTI_MAX + 1], wpb = rldl_multi_tile_wpb(), *h_dest = 0, ok = 1, i, k;
+  if (!mp) return 1;
+  *mp = 0;
+  if (!ws || count <= 0 || count > RLDL_MULTI_MAX || !dest) return 1;
+  first_orig[0] = 0;
+  for (g = 0; g < count; g++) {                                   /* the fixed-iteration case on the tile kernels, same n and m */
+    const osqp_batch *w = ws[g];
+    if (!w || w->st.check_termination || w->st.adaptive_rho || w->st.polish || w->n != ws[0]->n || w->m != ws[0]->m ||
+        w->st.max_iter != ws[0]->st.max_iter || w->st.warm_start != ws[0]->st.warm_start) return 2;
+    keys[g] = rldl_multi_key(&w->ls->dsym, &w->ls->num, &w->W);
+    if (keys[g] < 0) return 2;
+    first_orig[g + 1] = first_orig[g] + (int)w->batch;
+    total += w->batch;
+  }
+  for (i = 0; i < count; i++) order[i] = i;                        /* groups by key (insertion sort, stable): one launch of the iterations per key */
+  for (i = 1; i < count; i++) {
+    const int v = order[i];
+    for (k = i; k > 0 && keys[order[k - 1]] > keys[v]; k--) order[k] = order[k - 1];
+    order[k] = v;
+  }
+  mm = (osqp_multi *)calloc(1, sizeof(osqp_multi));
+  if (!mm) return RLDL_MEM_ALLOC_ERROR;
+  mm->count = count; mm->total = total; mm->n = ws[0]->n; mm->m = ws[0]->m; mm->stream = stream;
+  mm->ws = (osqp_batch **)malloc(sizeof(osqp_batch *) * (size_t)count);
+  h_dest = (int *)malloc(sizeof(int) * (size_t)total);
+  if (!mm->ws || !h_dest) { free(h_dest); osqp_multi_free(mm); return RLDL_MEM_ALLOC_ERROR; }
+  if (!HIP_OK(hipMalloc((void **)&mm->dS, sizeof(rldl_dev_sym) * (size_t)count))) ok = 0;
+  if (ok && !HIP_OK(hipMalloc((void **)&mm->dN, sizeof(rldl_dev_num) * (size_t)count))) ok = 0;
+  if (ok && !HIP_OK(hipMalloc((void **)&mm->dW, sizeof(rldl_dev_admm) * (size_t)count))) ok = 0;
+  if (ok && !HIP_OK(hipHostMalloc((void **)&mm->hW, sizeof(rldl_dev_admm) * (size_t)count, hipHostMallocDefault))) { mm->hW = 0; ok = 0; }
+  if (ok && !HIP_OK(hipMalloc((void **)&mm->d_dest, sizeof(int) * (size_t)total))) ok = 0;
+  mm->M.ngroups = (int)count;
+  mm->M.first_tile[0] = mm->M.first_inst[0] = 0;
+  for (i = 0; ok && i < count; i++) {
+    const osqp_batch *w = ws[order[i]];
+    const int xdw = rldl_multi_tile_xdw(&w->ls->dsym), p = mm->nparts;
+    mm->ws[i] = ws[order[i]];
+    if (i == 0 || keys[order[i]] != keys[order[i - 1]]) { mm->part_first[p] = i; mm->part_xdw[p] = 0; mm->nparts++; }
+    if (xdw > mm->part_xdw[mm->nparts - 1]) mm->part_xdw[mm->nparts - 1] = xdw;
+    for (k = 0; k < (int)w->batch; k++) h_dest[mm->M.first_inst[i] + k] = (int)dest[first_orig[order[i]] + k];
+    mm->M.first_inst[i + 1] = mm->M.first_inst[i] + (int)w->batch;
+    mm->M.first_tile[i + 1] = mm->M.first_tile[i] + ((int)w->batch + wpb - 1) / wpb;
+    mm->M.xdw[i] = xdw;
+    if (!HIP_OK(hipMemcpy(mm->dS + i, &w->ls->dsym, sizeof(rldl_dev_sym), hipMemcpyHostToDevice))) ok = 0;
+    if (ok && !HIP_OK(hipMemcpy(mm->dN + i, &w->ls->num, sizeof(rldl_dev_num), hipMemcpyHostToDevice))) ok = 0;
+  }
+  mm->part_first[mm->nparts] = (int)count;
+  if (ok && !HIP_OK(hipMemcpy(mm->d_dest, h_dest, sizeof(int) * (size_t)total, hipMemcpyHostToDevice))) ok = 0;
+  free(h_dest);
+  mm->M.S = mm->dS; mm->M.N = mm->dN; mm->M.W = mm->dW;
+  if (!ok) { osqp_multi_free(mm); return RLDL_MEM_ALLOC_ERROR; }
+  *mp = mm;
+  return 0;
+}
+
+/* osqp_solve of every workspace of the set; returns when the results are there (osqp_multi_get reads them in caller order) */
+c_int osqp_multi_solve(osqp_multi *mm) {
+  c_int g;
+  int p;
+  osqp_batch *w0;
+  hipStream_t st;
+  if (!mm) return 7;
+  w0 = mm->ws[0]; st = (hipStream_t)mm->stream;
+  for (g = 0; g < mm->count; g++) {                               /* work still queued on the workspaces' own streams comes first */
+    if (mm->ws[g]->stream != mm->stream && !HIP_OK(hipStreamSynchronize((hipStream_t)mm->ws[g]->stream))) return 1;
+    mm->ws[g]->W.write_delta = 1;
+    mm->hW[g] = mm->ws[g]->W;
+  }
+  if (!HIP_OK(hipMemcpyAsync(mm->dW, mm->hW, sizeof(rldl_dev_admm) * (size_t)mm->count, hipMemcpyHostToDevice, st))) return 1;
+  if (rldl_launch_multi_solve_begin(&mm->M, (int)mm->total, (int)mm->n, (int)mm->m, w0->st.warm_start ? 0 : 1, mm->stream)) return 1;
+  for (p = 0; p < mm->nparts; p++) {                              /* the fused iterations: one launch per kernel instantiation */
+    const int gs = mm->part_first[p], ge = mm->part_first[p + 1];
+    const osqp_batch *wp = mm->ws[gs];
+    rldl_dev_multi Mp;
+    int i;
+    memset(&Mp, 0, sizeof(Mp));
+    Mp.ngroups = ge - gs;
+    for (i = 0; i <= ge - gs; i++) Mp.first_tile[i] = mm->M.first_tile[gs + i] - mm->M.first_tile[gs];
+    for (i = 0; i < ge - gs; i++) Mp.xdw[i] = mm->M.xdw[gs + i];
+    Mp.S = mm->dS + gs; Mp.N = mm->dN + gs; Mp.W = mm->dW + gs;
+    if (rldl_launch_multi_admm_iters(&Mp, &wp->ls->dsym, &wp->ls->num, &wp->W, (int)w0->st.max_iter, mm->part_xdw[p], mm->stream)) return 1;
+  }
+  if (rldl_launch_multi_check_final(&mm->M, &w0->ls->dsym, &w0->W, (int)mm->total, (int)w0->st.max_iter, (int)(mm->n + mm->m), mm->stream)) return 1;
+  for (g = 0; g < mm->count; g++) { mm->ws[g]->last_loop_launches = w0->st.max_iter; mm->ws[g]->last_loop_groups = 1; }
+  return HIP_OK(hipStreamSynchronize(st)) ? 0 : 1;
+}
+
+/* results of all workspaces in the caller's instance order (device arrays: x[total][n], y / z[total][m], the rest [total]; z may be null) */
+c_int osqp_multi_get(osqp_multi *mm, c_float *d_x, c_float *d_y, c_float *d_z, int *d_status, int *d_iter, c_float *d_obj,
+                     c_float *d_pri_res, c_float *d_dua_res) {
+  if (!mm || !d_x || !d_y || !d_status || !d_iter || !d_obj || !d_pri_res || !d_dua_res) return 1;
+  if (rldl_launch_multi_gather(&mm->M, (int)mm->total, (int)mm->n, (int)mm->m, mm->d_dest, d_x, d_y, d_z, d_status, d_iter, d_obj, d_pri_res,
+                               d_dua_res, mm->stream)) return 1;
+  return HIP_OK(hipStreamSynchronize((hipStream_t)mm->stream)) ? 0 : 1;
+}
+
 c_int osqp_batch_get_iterates(osqp_batch *w, c_float **d_x, c_float **d_y, c_float **d_z, c_float **d_delta_x, c_float **d_delta_y) {
   if (!w) return 1;
   if (d_x) *d_x = w->W.x;

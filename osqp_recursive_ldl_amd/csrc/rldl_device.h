@@ -127,6 +127,20 @@ typedef struct {
   double *sol_x, *sol_y;                               /* unscaled solution (store_solution, auxil.c:527-565) */
 } rldl_dev_admm;
 
+/* Several workspaces in ONE launch (batches whose instances fall into a few sparsity patterns, one workspace per pattern): the
+ * kernels that take this descriptor look their workgroup up in first_* and run it on the structs of its group.  ngroups = 0: an
+ * ordinary launch on the structs passed by value. */
+#define RLDL_MULTI_MAX 64
+typedef struct {
+  int ngroups;
+  int first_tile[RLDL_MULTI_MAX + 1];     /* first workgroup of each group in grids of TILE_WPB instances per workgroup (k_tile_admm) */
+  int first_inst[RLDL_MULTI_MAX + 1];     /* first workgroup in grids of one instance per workgroup (k_solve_begin, k_admm_check, k_multi_gather) */
+  int xdw[RLDL_MULTI_MAX];                /* per-wave LDS doubles of k_tile_admm */
+  const rldl_dev_sym *S;                  /* device arrays [ngroups] */
+  const rldl_dev_num *N;
+  const rldl_dev_admm *W;
+} rldl_dev_multi;
+
 /* shared-memory footprint (bytes) of the LDS-resident variants; the launchers pick the global-memory
  * variant by themselves when this exceeds RLDL_LDS_LIMIT */
 #define RLDL_LDS_LIMIT (64 * 1024)
@@ -173,6 +187,19 @@ int rldl_launch_ew_scale(int batch, int len, double *dst, const double *src, con
 int rldl_launch_matvec_A(const rldl_dev_sym *S, const rldl_dev_admm *W, const double *d_x, double *d_out, void *stream);
 /* *flag |= 1 when l[i] > u[i] for some i < count (osqp.c:805-813) */
 int rldl_launch_check_bounds(long long count, const double *l, const double *u, int *flag, void *stream);
+/* the fixed-iteration solve of several workspaces in three launches (osqp_multi_*, rldl_admm.c).  S0 / N0 / W0 = host copies of one
+ * group's structs (they select the kernel instantiation; rldl_multi_key tells which groups may share a launch) */
+int rldl_multi_key(const rldl_dev_sym *S, const rldl_dev_num *Nn, const rldl_dev_admm *W);
+int rldl_multi_tile_xdw(const rldl_dev_sym *S);
+int rldl_multi_tile_wpb(void);
+int rldl_launch_multi_solve_begin(const rldl_dev_multi *M, int total, int n, int m, int cold, void *stream);
+int rldl_launch_multi_admm_iters(const rldl_dev_multi *M, const rldl_dev_sym *S0, const rldl_dev_num *N0, const rldl_dev_admm *W0, int iters,
+                                 int max_xdw, void *stream);
+int rldl_launch_multi_check_final(const rldl_dev_multi *M, const rldl_dev_sym *S0, const rldl_dev_admm *W0, int total, int iter, int max_nm,
+                                  void *stream);
+/* results of all groups into caller-order arrays: dest[first_inst[g] + i] = row of instance i of group g */
+int rldl_launch_multi_gather(const rldl_dev_multi *M, int total, int n, int m, const int *dest, double *x, double *y, double *z, int *status,
+                             int *iter, double *obj, double *pri, double *dua, void *stream);
 const char *rldl_kernel_arch(void);
 
 #ifdef __cplusplus

@@ -507,6 +507,12 @@ __device__ __forceinline__ int dual_infeasible(const rldl_dev_sym &S, const doub
   return !wave_any(viol);
 }
 
+// Several workspaces in one launch (rldl_dev_multi): group of workgroup `bid` in a grid whose groups start at first[]
+__device__ __forceinline__ int multi_group(const int *first, int ng, int bid) {
+  int g = 0;
+  while (g + 1 < ng && bid >= first[g + 1]) g++;
+  return g;
+}
 // mode bits
 #define CHK_TERMINATION 1
 #define CHK_ADAPT 2
@@ -515,9 +521,11 @@ __device__ __forceinline__ int dual_infeasible(const rldl_dev_sym &S, const doub
 
 // STAGED: the instance's P and A values are copied to LDS first (coalesced), so the three SpMVs of update_info and
 // the ones of the infeasibility tests walk LDS instead of issuing dependent global loads entry by entry.
-template <bool STAGED>
-__global__ __launch_bounds__(WAVE, 4) void k_admm_check(rldl_dev_sym S, rldl_dev_admm W, int iter, int mode) {
-  const int inst = blockIdx.x, lane = threadIdx.x;
+template <bool STAGED, bool MULTI = false>
+__global__ __launch_bounds__(WAVE, 4) void k_admm_check(rldl_dev_sym S, rldl_dev_admm W, int iter, int mode, rldl_dev_multi M) {
+  int inst = blockIdx.x;
+  const int lane = threadIdx.x;
+  if (MULTI) { const int g = multi_group(M.first_inst, M.ngroups, inst); S = M.S[g]; W = M.W[g]; inst -= M.first_inst[g]; }
   const int n = S.n, m = S.m;
   extern __shared__ double sh[];
   double *vx = sh, *vy = vx + n, *vz = vy + m, *vAx = vz + m, *vPx = vAx + m, *vAty = vPx + n;
@@ -2899,11 +2907,13 @@ __global__ __launch_bounds__(256, 2) void k_tile_solve(rldl_dev_sym S, rldl_dev_
 // The permuted positions are dealt to (slot, lane) by the host (po_tpos): slot 0 holds the variables, slots 1 and 2 the
 // constraints, so the step code of a slot is uniform (S.tile_vslots == 1 is a condition of tile_admm_ok).
 #define TILE_SLOTS 3
-template <int TG, int TA, int TK, int SP, bool TRACE>
-__global__ __launch_bounds__(256, 2) void k_tile_admm(rldl_dev_sym S, rldl_dev_num Nn, rldl_dev_admm W, int xdw, int iters) {
+template <int TG, int TA, int TK, int SP, bool TRACE, bool MULTI = false>
+__global__ __launch_bounds__(256, 2) void k_tile_admm(rldl_dev_sym S, rldl_dev_num Nn, rldl_dev_admm W, int xdw, int iters, rldl_dev_multi M) {
   extern __shared__ __attribute__((aligned(16))) double sh[];
   const int lane = threadIdx.x & (WAVE - 1), wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wpb = blockDim.x >> 6;
-  const int inst = blockIdx.x * wpb + wv;
+  int bid = blockIdx.x;
+  if (MULTI) { const int g = multi_group(M.first_tile, M.ngroups, bid); S = M.S[g]; Nn = M.N[g]; W = M.W[g]; xdw = M.xdw[g]; bid -= M.first_tile[g]; }
+  const int inst = bid * wpb + wv;
   if (inst >= Nn.batch) return;
   if (W.status[inst] != ST_UNSOLVED) return;
   long long *tr = TRACE && W.trace ? W.trace + 8 * (size_t)inst : nullptr;
@@ -3311,7 +3321,8 @@ static int launch_arrow_solve(const rldl_dev_sym *S, const rldl_dev_num *Nn, dou
   return launch_arrow_solve_g<8>(S, Nn, d_b, stream);
 }
 static bool tile_admm_usable(const rldl_dev_sym *S, const rldl_dev_num *Nn, const rldl_dev_admm *W);
-static int launch_tile_admm(const rldl_dev_sym *S, const rldl_dev_num *Nn, const rldl_dev_admm *W, int iters, void *stream);
+static int launch_tile_admm(const rldl_dev_sym *S, const rldl_dev_num *Nn, const rldl_dev_admm *W, int iters, void *stream,
+                            const rldl_dev_multi *M = nullptr, int multi_grid = 0, int multi_xdw = 0);
 template <int TMAX, int TG>
 static int launch_arrow_admm_t(const rldl_dev_sym *S, const rldl_dev_num *Nn, const rldl_dev_admm *W, int iters, void *stream) {
   size_t lds = 0;
@@ -3391,18 +3402,25 @@ static int launch_tile_solve(const rldl_dev_sym *S, const rldl_dev_num *Nn, doub
 #undef TS
   return launch_status();
 }
-static int launch_tile_admm(const rldl_dev_sym *S, const rldl_dev_num *Nn, const rldl_dev_admm *W, int iters, void *stream) {
-  const int pw = tile_per_wave(S), grid = (Nn->batch + TILE_WPB - 1) / TILE_WPB;
-  const size_t lds = sizeof(double) * (size_t)(pw + WAVE + 4 * TILE_SLOTS * WAVE) * TILE_WPB;
+// M: several workspaces in one launch (S / Nn / W then only select the instantiation: every group must have the same rldl_multi_key);
+// multi_grid = workgroups of all groups, multi_xdw = the largest per-wave LDS need among them
+static const rldl_dev_multi k_no_multi = {};
+static int launch_tile_admm(const rldl_dev_sym *S, const rldl_dev_num *Nn, const rldl_dev_admm *W, int iters, void *stream,
+                            const rldl_dev_multi *M, int multi_grid, int multi_xdw) {
+  const int pw = tile_per_wave(S), grid = M ? multi_grid : (Nn->batch + TILE_WPB - 1) / TILE_WPB;
+  const size_t lds = sizeof(double) * (size_t)((M ? multi_xdw : pw) + WAVE + 4 * TILE_SLOTS * WAVE) * TILE_WPB;
+  const rldl_dev_multi &MM = M ? *M : k_no_multi;
   if (W->trace) {                                                 // the wave timeline exists for the metric shape's instantiation only
-    hipLaunchKernelGGL((k_tile_admm<18, 5, 24, 18, true>), dim3(grid), dim3(TILE_WPB * WAVE), lds, (hipStream_t)stream, *S, *Nn, *W, pw, iters);
+    if (M) return -1;
+    hipLaunchKernelGGL((k_tile_admm<18, 5, 24, 18, true>), dim3(grid), dim3(TILE_WPB * WAVE), lds, (hipStream_t)stream, *S, *Nn, *W, pw, iters, MM);
     return launch_status();
   }
   int launched = 0;
   // one instantiation per (virtual-row steps, tile size, owner-gather steps, split); combinations whose register need exceeds
   // 256 (tile_admm_usable rules them out) are not compiled
 #define TA_(TG, TA, TK, SP) do { if constexpr (2 * TG + 2 * TA * TA + (26 * TK) / 10 + 89 <= 256) { \
-    hipLaunchKernelGGL((k_tile_admm<TG, TA, TK, SP, false>), dim3(grid), dim3(TILE_WPB * WAVE), lds, (hipStream_t)stream, *S, *Nn, *W, pw, iters); launched = 1; } } while (0)
+    if (M) hipLaunchKernelGGL((k_tile_admm<TG, TA, TK, SP, false, true>), dim3(grid), dim3(TILE_WPB * WAVE), lds, (hipStream_t)stream, *S, *Nn, *W, pw, iters, MM); \
+    else hipLaunchKernelGGL((k_tile_admm<TG, TA, TK, SP, false>), dim3(grid), dim3(TILE_WPB * WAVE), lds, (hipStream_t)stream, *S, *Nn, *W, pw, iters, MM); launched = 1; } } while (0)
 #define TK_(TG, TA) switch (S->tile_tk * 100 + S->tile_sp) { case 1612: TA_(TG, TA, 16, 12); break; case 1610: TA_(TG, TA, 16, 10); break; \
     case 2418: TA_(TG, TA, 24, 18); break; case 2416: TA_(TG, TA, 24, 16); break; case 3224: TA_(TG, TA, 32, 24); break; case 3220: TA_(TG, TA, 32, 20); break; default: return -1; }
   if (S->arrow_vsteps <= 12) {
@@ -3454,8 +3472,9 @@ extern "C" int rldl_launch_kkt_assemble_keep(const rldl_dev_sym *S, const rldl_d
 }
 // start of osqp_solve for the whole batch in one launch: status = OSQP_UNSOLVED, rho_updates = 0 (reset_info, auxil.c:628-645),
 // the active-instance counter, and cold_start (auxil.c:158-162) when warm starting is off
-__global__ __launch_bounds__(256) void k_solve_begin(rldl_dev_admm W, int n, int m, int cold, int reset_rho_updates) {
-  const int inst = blockIdx.x;
+__global__ __launch_bounds__(256) void k_solve_begin(rldl_dev_admm W, int n, int m, int cold, int reset_rho_updates, rldl_dev_multi M) {
+  int inst = blockIdx.x;
+  if (M.ngroups > 0) { const int g = multi_group(M.first_inst, M.ngroups, inst); W = M.W[g]; inst -= M.first_inst[g]; }
   if (threadIdx.x == 0) {
     W.status[inst] = ST_UNSOLVED;
     if (reset_rho_updates) W.rho_updates[inst] = 0;
@@ -3469,7 +3488,7 @@ __global__ __launch_bounds__(256) void k_solve_begin(rldl_dev_admm W, int n, int
 }
 extern "C" int rldl_launch_solve_begin(const rldl_dev_admm *W, int n, int m, int cold, int reset_rho_updates, void *stream) {
   if (W->batch <= 0) return 0;
-  hipLaunchKernelGGL(k_solve_begin, dim3(W->batch), dim3(256), 0, (hipStream_t)stream, *W, n, m, cold, reset_rho_updates);
+  hipLaunchKernelGGL(k_solve_begin, dim3(W->batch), dim3(256), 0, (hipStream_t)stream, *W, n, m, cold, reset_rho_updates, k_no_multi);
   return launch_status();
 }
 
@@ -3631,9 +3650,9 @@ extern "C" int rldl_launch_admm_check(const rldl_dev_sym *S, const rldl_dev_admm
   if (final_pass == 2) mode |= CHK_FINAL_NEEDS_INFO;
   // entry-parallel products straight from global memory when the tables exist; else the row loops, on LDS copies of P / A if they fit
   if ((!S->flat_ok || getenv("RLDL_CHECK_STAGED")) && check_lds_staged(S) <= 40 * 1024)
-    hipLaunchKernelGGL(k_admm_check<true>, dim3(W->batch), dim3(WAVE), check_lds_staged(S), (hipStream_t)stream, *S, *W, iter, mode);
+    hipLaunchKernelGGL(k_admm_check<true>, dim3(W->batch), dim3(WAVE), check_lds_staged(S), (hipStream_t)stream, *S, *W, iter, mode, k_no_multi);
   else
-    hipLaunchKernelGGL(k_admm_check<false>, dim3(W->batch), dim3(WAVE), check_lds(S), (hipStream_t)stream, *S, *W, iter, mode);
+    hipLaunchKernelGGL(k_admm_check<false>, dim3(W->batch), dim3(WAVE), check_lds(S), (hipStream_t)stream, *S, *W, iter, mode, k_no_multi);
   return launch_status();
 }
 
@@ -3728,6 +3747,56 @@ extern "C" int rldl_launch_check_bounds(long long count, const double *l, const 
   if (count <= 0) return 0;
   const long long blocks = (count + 255) / 256;
   hipLaunchKernelGGL(k_check_bounds, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, (hipStream_t)stream, count, l, u, flag);
+  return launch_status();
+}
+
+// ---- several workspaces in one launch (osqp_multi_*, rldl_admm.c) ----
+// which groups may share the launches: the instantiation of k_tile_admm their pattern selects (-1: not on the tile kernels) and
+// the entry-parallel check kernel
+extern "C" int rldl_multi_key(const rldl_dev_sym *S, const rldl_dev_num *Nn, const rldl_dev_admm *W) {
+  if (!(arrow_usable(S) && S->N <= 8 * WAVE && tile_admm_usable(S, Nn, W)) || W->trace || !S->flat_ok || getenv("RLDL_CHECK_STAGED")) return -1;
+  const int tg = S->arrow_vsteps <= 12 ? 12 : S->arrow_vsteps <= 18 ? 18 : 24;
+  return ((tg * 16 + S->tile_ta) * 64 + S->tile_tk) * 64 + S->tile_sp;
+}
+extern "C" int rldl_multi_tile_xdw(const rldl_dev_sym *S) { return tile_per_wave(S); }
+extern "C" int rldl_multi_tile_wpb(void) { return TILE_WPB; }
+extern "C" int rldl_launch_multi_solve_begin(const rldl_dev_multi *M, int total, int n, int m, int cold, void *stream) {
+  if (total <= 0) return 0;
+  rldl_dev_admm W0 = {};
+  hipLaunchKernelGGL(k_solve_begin, dim3(total), dim3(256), 0, (hipStream_t)stream, W0, n, m, cold, 0, *M);
+  return launch_status();
+}
+extern "C" int rldl_launch_multi_admm_iters(const rldl_dev_multi *M, const rldl_dev_sym *S0, const rldl_dev_num *N0, const rldl_dev_admm *W0,
+                                            int iters, int max_xdw, void *stream) {
+  if (iters <= 0 || M->ngroups <= 0) return 0;
+  return launch_tile_admm(S0, N0, W0, iters, stream, M, M->first_tile[M->ngroups], max_xdw);
+}
+extern "C" int rldl_launch_multi_check_final(const rldl_dev_multi *M, const rldl_dev_sym *S0, const rldl_dev_admm *W0, int total, int iter,
+                                             int max_nm, void *stream) {
+  if (total <= 0) return 0;
+  const size_t lds = sizeof(double) * (size_t)(6 * max_nm + 8);   // (check_lds of the largest group; all groups share n and m)
+  hipLaunchKernelGGL((k_admm_check<false, true>), dim3(total), dim3(WAVE), lds, (hipStream_t)stream, *S0, *W0, iter, CHK_FINAL | CHK_FINAL_NEEDS_INFO, *M);
+  return launch_status();
+}
+// results of every group into caller-order arrays, one workgroup per instance
+__global__ __launch_bounds__(WAVE) void k_multi_gather(rldl_dev_multi M, int n, int m, const int *__restrict__ dest, double *__restrict__ x,
+                                                       double *__restrict__ y, double *__restrict__ z, int *__restrict__ status,
+                                                       int *__restrict__ iter, double *__restrict__ obj, double *__restrict__ pri,
+                                                       double *__restrict__ dua) {
+  const int bid = blockIdx.x, lane = threadIdx.x;
+  const int g = multi_group(M.first_inst, M.ngroups, bid), i = bid - M.first_inst[g], o = dest[bid];
+  const rldl_dev_admm &W = M.W[g];
+  const double *sx = W.sol_x, *sy = W.sol_y;                    // OSQPSolution (store_solution, auxil.c:527-565): what osqp_batch_get hands out
+  for (int k = lane; k < n; k += WAVE) x[(size_t)o * n + k] = sx[(size_t)i * n + k];
+  for (int k = lane; k < m; k += WAVE) { y[(size_t)o * m + k] = sy[(size_t)i * m + k]; if (z) z[(size_t)o * m + k] = W.z[(size_t)i * m + k]; }
+  if (lane == 0) {
+    status[o] = W.status[i]; iter[o] = W.iter[i]; obj[o] = W.obj[i]; pri[o] = W.pri_res[i]; dua[o] = W.dua_res[i];
+  }
+}
+extern "C" int rldl_launch_multi_gather(const rldl_dev_multi *M, int total, int n, int m, const int *dest, double *x, double *y, double *z,
+                                        int *status, int *iter, double *obj, double *pri, double *dua, void *stream) {
+  if (total <= 0) return 0;
+  hipLaunchKernelGGL(k_multi_gather, dim3(total), dim3(WAVE), 0, (hipStream_t)stream, *M, n, m, dest, x, y, z, status, iter, obj, pri, dua);
   return launch_status();
 }
 

@@ -1,12 +1,16 @@
 """Batches whose instances do NOT share one sparsity pattern ("per-instance pattern" variant of config 2).
 
 The backend factorises one pattern per handle, so the instances are bucketed by pattern: one OSQPBatch per distinct
-(P pattern, A pattern), each on its own HIP stream, all enqueued before any is waited for -- with a fixed number of
-iterations nothing in a solve needs the host, so the groups share the GPU concurrently -- and the results are scattered
-back into the caller's instance order.  All instances must have the same (n, m).
+(P pattern, A pattern).  With a fixed number of iterations (no termination checks, no rho adaptation, no polish) and patterns
+that select the same kernel instantiation, a solve of ALL groups is three launches over the stacked instances plus one that
+writes the results in the caller's instance order (osqp_multi_*, include/osqp_rldl_hip.h).  Otherwise every group is enqueued
+on its own HIP stream before any is waited for, and the results are gathered with torch.  All instances must have the same
+(n, m).
 """
+import ctypes as C
 import numpy as np
 
+from . import _lib
 from .linsys import CscPattern
 from .osqp_batch import OSQPBatch
 
@@ -16,8 +20,9 @@ def _key(P, A):
 
 
 class OSQPBatchGroups:
-    def __init__(self, problems, device="cuda:0", **settings):
-        """problems: sequence of (P, q, A, l, u) with scipy sparse P (upper triangular part is used) and A, numpy q, l, u."""
+    def __init__(self, problems, device="cuda:0", one_launch=True, **settings):
+        """problems: sequence of (P, q, A, l, u) with scipy sparse P (upper triangular part is used) and A, numpy q, l, u.
+        one_launch=False keeps every group on its own stream even when the set qualifies for the single launch chain."""
         import torch
         from scipy import sparse
         self.count = len(problems)
@@ -49,14 +54,43 @@ class OSQPBatchGroups:
         # position of every original instance in the concatenation of the groups' result arrays
         order = np.concatenate([np.asarray(idx) for idx in buckets.values()])
         self._inv = torch.as_tensor(np.argsort(order, kind="stable"), device=dev)
+        # all groups in one launch chain when the set qualifies (osqp_multi_create returns 2 otherwise)
+        self._multi = None
+        self._mstream = torch.cuda.Stream(device=dev)
+        hs = (C.c_void_p * len(self.groups))(*[w.h for _, w in self.groups])
+        dest = np.ascontiguousarray(order, dtype=np.int64)
+        mh = C.c_void_p()
+        rc = _lib.lib().osqp_multi_create(C.byref(mh), hs, len(self.groups), dest.ctypes.data_as(_lib.IP), C.c_void_p(self._mstream.cuda_stream)) if one_launch else 2
+        if rc == 0:
+            self._multi = mh
+            B, n, m = self.count, self.n, self.m
+            f = lambda *shape: torch.empty(shape, dtype=torch.float64, device=dev)
+            i = lambda *shape: torch.empty(shape, dtype=torch.int32, device=dev)
+            self._out = dict(x=f(B, n), y=f(B, m), z=f(B, m), status=i(B), iter=i(B), obj=f(B), pri_res=f(B), dua_res=f(B))
+        elif rc != 2:
+            raise RuntimeError("osqp_multi_create failed (%d)" % rc)
 
     @property
     def n_patterns(self):
         return len(self.groups)
 
+    @property
+    def one_launch(self):
+        """True when a solve of all groups is one launch chain (osqp_multi_solve)."""
+        return self._multi is not None
+
     def solve(self):
-        """Solve every group (concurrently where the settings allow) and return results in the original instance order."""
+        """Solve every group and return results in the original instance order (the arrays are reused by the next solve)."""
         import torch
+        if self._multi is not None:
+            L = _lib.lib()
+            if L.osqp_multi_solve(self._multi):
+                raise RuntimeError("osqp_multi_solve failed")
+            o = self._out
+            p = lambda t: C.c_void_p(t.data_ptr())
+            if L.osqp_multi_get(self._multi, p(o["x"]), p(o["y"]), p(o["z"]), p(o["status"]), p(o["iter"]), p(o["obj"]), p(o["pri_res"]), p(o["dua_res"])):
+                raise RuntimeError("osqp_multi_get failed")
+            return dict(o)
         for _, w in self.groups:
             w.solve_async()
         parts = [w.wait(clone=False) for _, w in self.groups]
@@ -64,6 +98,9 @@ class OSQPBatchGroups:
         return {key: torch.cat([res[key] for res in parts], 0)[self._inv] for key in parts[0]}
 
     def cleanup(self):
+        if self._multi is not None:
+            _lib.lib().osqp_multi_free(self._multi)
+            self._multi = None
         for _, w in self.groups:
             w.cleanup()
         self.groups = []

@@ -116,9 +116,20 @@ def pattern_groups():
     kw = dict(rho=0.1, sigma=1e-6, alpha=1.6, max_iter=200, check_termination=0, adaptive_rho=0, warm_start=0, scaling=0)
     g = R.OSQPBatchGroups(probs, **kw)
     ms = timed(lambda: g.solve(), reps=3)
-    emit(name="config2_pattern_groups_8x512_200_iters", batch=len(probs), patterns=g.n_patterns, ms_per_solve=ms,
+    emit(name="config2_pattern_groups_8x512_200_iters", batch=len(probs), patterns=g.n_patterns, one_launch_chain=bool(g.one_launch),
+         ms_per_solve=ms, qp_solves_per_sec=len(probs) / (ms * 1e-3))
+    g.cleanup()
+    g = R.OSQPBatchGroups(probs, one_launch=False, **kw)            # every group on its own stream (what patterns off the tile kernels get)
+    ms = timed(lambda: g.solve(), reps=3)
+    emit(name="config2_pattern_groups_8x512_200_iters_one_stream_per_pattern", batch=len(probs), patterns=g.n_patterns, ms_per_solve=ms,
          qp_solves_per_sec=len(probs) / (ms * 1e-3))
     g.cleanup()
+    wl = R.workloads.SharedPatternQPs(pattern_seed=2000)           # the same solve (no refactorisation) on ONE pattern, for the ratio
+    Px, Ax, q, l, u = wl.values(len(probs))
+    w = R.OSQPBatch(wl.P_pattern, wl.A_pattern, t(Px), t(Ax), t(q), t(l), t(u), **kw)
+    ms1 = timed(lambda: w.solve(), reps=3)
+    emit(name="config2_single_pattern_4096_200_iters_solve_only", batch=len(probs), ms_per_solve=ms1)
+    w.cleanup()
 
 
 def mpc_shape():

@@ -519,6 +519,31 @@ def test_pattern_groups_solve_mixed_sparsity_batches(R):
     g.cleanup(); g2.cleanup()
 
 
+def test_pattern_groups_in_one_launch_chain(R):
+    """Metric-shape instances of several sparsity patterns: when the patterns select the same kernel instantiation the solve of all
+    groups is one launch chain over the stacked instances (osqp_multi_*); results equal the per-stream path bit for bit (the same
+    kernels run on the same data) and the oracle per instance."""
+    seeds = (2000, 2001, 2002, 2003)
+    wls = [R.workloads.SharedPatternQPs(pattern_seed=s) for s in seeds]
+    problems = [wls[k % 4].instance(k // 4) for k in range(4 * 9 + 2)]            # interleaved, ragged group sizes (10, 10, 9, 9)
+    kw = dict(rho=0.1, sigma=1e-6, alpha=1.6, max_iter=40, check_termination=0, adaptive_rho=0, warm_start=0, scaling=0)
+    g1 = R.OSQPBatchGroups(problems, **kw)
+    g0 = R.OSQPBatchGroups(problems, one_launch=False, **kw)
+    assert g1.n_patterns == 4 and not g0.one_launch
+    r1 = {k: v.clone() for k, v in g1.solve().items()}
+    r1b = g1.solve()                                                                # a second solve of the same set: cold start again
+    r0 = g0.solve()
+    for key in ("x", "y", "z", "obj", "pri_res", "dua_res", "iter", "status"):
+        assert torch.equal(r1[key], r0[key]) and torch.equal(r1b[key], r0[key]), key
+    for k in (0, 5, 37):
+        P, q, A, l, u = problems[k]
+        w = [w for idx, w in g1.groups if int(k) in idx.tolist()][0]
+        ro = ob.OracleOSQP(P, q, A, l, u, perm=w.linsys().export_symbolic()["perm"], **kw).solve()
+        assert relerr(r1["x"][k].cpu().numpy(), ro["x"]) < 1e-8 and relerr(r1["y"][k].cpu().numpy(), ro["y"]) < 1e-8
+    assert g1.one_launch                                                           # arrowhead patterns on the tile kernels (two instantiations here)
+    g1.cleanup(); g0.cleanup()
+
+
 def test_update_settings_mirrors_the_reference_setters(R):
     """osqp_update_max_iter / _eps_abs / ... (src/osqp.c:1321-1560): range checks as in test_basic_qp.h:88-160, and the
     new values take effect (tighter eps -> more iterations, same count as a fresh workspace with those settings)."""
