@@ -154,15 +154,15 @@ int rldl_launch_factor(const rldl_dev_sym *S, const rldl_dev_num *Nn, const int 
 int rldl_launch_stage_factor(const rldl_dev_sym *S, const rldl_dev_num *Nn, const int *d_mask, int first_block, void *stream);
 int rldl_launch_stage_invert(const rldl_dev_sym *S, const rldl_dev_num *Nn, void *stream);
 /* stage recursion where instance b restarts at block d_b0v[b] (0 = from the first block) */
-int rldl_launch_stage_factor_each(const rldl_dev_sym *S, const rldl_dev_num *Nn, const int *d_b0v, void *stream);
+int rldl_launch_stage_factor_each(const rldl_dev_sym *S, const rldl_dev_num *Nn, const int *d_b0v, int tiles_adopted, void *stream);
 /* horizon change (src/recursive_ldl.c:1973-2016): old horizon's workspace (So, Wo / No) -> new horizon's (Sn, Nn) */
 int rldl_launch_horizon_values(const rldl_dev_sym *So, const rldl_dev_admm *Wo, const double *oPx, const double *oAx, int col_keep,
                                double *nPx, int ldP, double *nAx, int ldA, void *stream);
 int rldl_launch_horizon_state(const rldl_dev_sym *So, const rldl_dev_admm *Wo, int n_new, int m_new, int n_keep, int m_keep, int nt,
                               double *xs, double *ys, void *stream);
 int rldl_launch_horizon_adopt(const rldl_dev_sym *So, const rldl_dev_num *No, const rldl_dev_sym *Sn, const rldl_dev_num *Nn,
-                              const double *rvo, const double *rvn, int m_keep, int c0, int b_pivot, int *d_b0v, int *d_n_reused,
-                              void *stream);
+                              const double *rvo, const double *rvn, int m_keep, int c0, int b_pivot, int ti_prefix, int *d_b0v,
+                              int *d_n_reused, void *stream);
 int rldl_launch_factor_from(const rldl_dev_sym *S, const rldl_dev_num *Nn, int c_start, void *stream);
 int rldl_launch_solve(const rldl_dev_sym *S, const rldl_dev_num *Nn, double *d_b, void *stream);
 int rldl_launch_admm_iter(const rldl_dev_sym *S, const rldl_dev_num *Nn, const rldl_dev_admm *W, void *stream);

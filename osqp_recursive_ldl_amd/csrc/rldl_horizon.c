@@ -221,10 +221,14 @@ c_int osqp_horizon_update(osqp_horizon *h, c_int Nnew, const c_float *d_q, const
           !getenv("RLDL_HORIZON_FULL") && prefix_agrees(h, h->N, Nnew, c0);
   if (adopt) {
     (void)hipMemsetAsync(h->n_reused, 0, sizeof(int) * RLDL_NACT_SLOTS, st);
+    /* the tiles of the product tri-solve travel with the adopted columns when both handles lay them out alike up to the pivot block */
+    const int bp = (int)(2 * p);
+    const int ti_prefix = w->ls->dsym.stage.pv_ok && o->ls->dsym.stage.pv_ok && w->ls->pv_tiD && o->ls->pv_tiD &&
+                          bp <= w->ls->dsym.stage.nb && bp <= o->ls->dsym.stage.nb && w->ls->pv_tiD[bp] == o->ls->pv_tiD[bp] ? w->ls->pv_tiD[bp] : 0;
     if (rldl_launch_horizon_adopt(&o->ls->dsym, &o->ls->num, &w->ls->dsym, &w->ls->num, o->W.rho_vec, w->W.rho_vec, (int)m_keep, c0,
-                                  (int)(2 * p), h->b0v, h->n_reused, w->stream))
+                                  bp, ti_prefix, h->b0v, h->n_reused, w->stream))
       return 1;
-    if (rldl_launch_stage_factor_each(&w->ls->dsym, &w->ls->num, h->b0v, w->stream)) return 1;
+    if (rldl_launch_stage_factor_each(&w->ls->dsym, &w->ls->num, h->b0v, ti_prefix > 0, w->stream)) return 1;
     if (!HIP_OK(hipMemcpyAsync(h->h_reused, h->n_reused, sizeof(int) * RLDL_NACT_SLOTS, hipMemcpyDeviceToHost, st))) return 1;
   } else if (rldl_launch_factor(&w->ls->dsym, &w->ls->num, 0, w->stream)) return 1;
   if (rldl_batch_check_status(w->ls)) return RLDL_NONCVX_ERROR;   /* synchronises the stream */

@@ -19,6 +19,7 @@ struct rldl_batch {
   rldl_stage_dims stage;
   int recursive;
   void *rec;               /* rldl_rec_state* */
+  int *pv_tiD;             /* host, stage handles with product tiles: first Ti entry of every diagonal block's tile [nb + 1] */
 };
 
 /* batched ADMM workspace (rldl_admm.c) */

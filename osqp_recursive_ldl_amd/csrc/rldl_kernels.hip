@@ -3077,7 +3077,7 @@ __global__ __launch_bounds__(WAVE) void k_horizon_state(rldl_dev_sym So, rldl_de
 
 __global__ __launch_bounds__(WAVE) void k_horizon_adopt(rldl_dev_sym So, rldl_dev_num No, rldl_dev_sym Sn, rldl_dev_num Nn,
                                                         const double *__restrict__ rvo, const double *__restrict__ rvn, int m_keep, int c0,
-                                                        int b_pivot, int *__restrict__ b0v, int *__restrict__ n_reused) {
+                                                        int b_pivot, int ti_prefix, int *__restrict__ b0v, int *__restrict__ n_reused) {
   const int inst = blockIdx.x, lane = threadIdx.x;
   const double *ro = rvo + (size_t)inst * So.m, *rn = rvn + (size_t)inst * Sn.m;
   int differ = No.status[inst] < 0 ? 1 : 0;                      // an old factor with a zero pivot is not adopted
@@ -3090,6 +3090,11 @@ __global__ __launch_bounds__(WAVE) void k_horizon_adopt(rldl_dev_sym So, rldl_de
   const int nl = So.Lp[c0];                                      // the two L patterns agree on columns < c0 (host check)
   for (int p = lane; p < nl; p += WAVE) Fn[Sn.LtoS[p]] = Fo[So.LtoS[p]];
   for (int j = lane; j < c0; j += WAVE) { Dn[j] = Do[j]; Fn[Sn.nS + j] = Fo[So.nS + j]; }
+  if (ti_prefix > 0) {                                           // the product tri-solve's tiles of the adopted blocks (same order in both handles: host check)
+    const double *To = No.Ti + (size_t)inst * So.stage.pv_ldTi;
+    double *Tn = Nn.Ti + (size_t)inst * Sn.stage.pv_ldTi;
+    for (int p = lane; p < ti_prefix; p += WAVE) Tn[p] = To[p];
+  }
 }
 
 }  // namespace
@@ -3518,9 +3523,9 @@ static int launch_factor(const rldl_dev_sym *S, const rldl_dev_num *Nn, const in
 }
 
 // tiles of the product tri-solve (k_stage_invert) behind a stage factorisation.  Per-instance restart blocks come from a horizon
-// change, whose adopted columns arrive without their tiles: every block is redone then.
+// change: when the adopted columns did not bring their tiles along (tiles_adopted = 0), every block is redone.
 static int launch_stage_invert(const rldl_dev_sym *S, const rldl_dev_num *Nn, const int *d_mask, int first_block, const int *d_b0v,
-                               void *stream) {
+                               int tiles_adopted, void *stream) {
   const rldl_dev_stage *G = &S->stage;
   if (!G->pv_ok || !Nn->Ti || G->smax > 32) return 0;
   const int sm = G->smax <= 8 ? 8 : G->smax <= 16 ? 16 : G->smax <= 24 ? 24 : 32;
@@ -3528,14 +3533,15 @@ static int launch_stage_invert(const rldl_dev_sym *S, const rldl_dev_num *Nn, co
   const size_t lds = sizeof(double) * (size_t)(2 * sm * (sm + 2));
   const dim3 grid(Nn->batch), blk(WAVE);
   const int b0 = d_b0v ? 0 : first_block;
-  if (sm == 8) hipLaunchKernelGGL(k_stage_invert<8>, grid, blk, lds, (hipStream_t)stream, *S, *Nn, d_mask, b0, (const int *)0);
-  else if (sm == 16) hipLaunchKernelGGL(k_stage_invert<16>, grid, blk, lds, (hipStream_t)stream, *S, *Nn, d_mask, b0, (const int *)0);
-  else if (sm == 24) hipLaunchKernelGGL(k_stage_invert<24>, grid, blk, lds, (hipStream_t)stream, *S, *Nn, d_mask, b0, (const int *)0);
-  else hipLaunchKernelGGL(k_stage_invert<32>, grid, blk, lds, (hipStream_t)stream, *S, *Nn, d_mask, b0, (const int *)0);
+  const int *bv = tiles_adopted ? d_b0v : (const int *)0;
+  if (sm == 8) hipLaunchKernelGGL(k_stage_invert<8>, grid, blk, lds, (hipStream_t)stream, *S, *Nn, d_mask, b0, bv);
+  else if (sm == 16) hipLaunchKernelGGL(k_stage_invert<16>, grid, blk, lds, (hipStream_t)stream, *S, *Nn, d_mask, b0, bv);
+  else if (sm == 24) hipLaunchKernelGGL(k_stage_invert<24>, grid, blk, lds, (hipStream_t)stream, *S, *Nn, d_mask, b0, bv);
+  else hipLaunchKernelGGL(k_stage_invert<32>, grid, blk, lds, (hipStream_t)stream, *S, *Nn, d_mask, b0, bv);
   return launch_status();
 }
 static int launch_stage_factor(const rldl_dev_sym *S, const rldl_dev_num *Nn, const int *d_mask, int first_block, const int *d_b0v,
-                               void *stream) {
+                               int tiles_adopted, void *stream) {
   if (Nn->batch <= 0) return 0;
   const rldl_dev_stage *G = &S->stage;
   if (G->nb <= 0 || first_block < 0 || first_block >= G->nb) return -1;
@@ -3543,7 +3549,7 @@ static int launch_stage_factor(const rldl_dev_sym *S, const rldl_dev_num *Nn, co
     const size_t lds = sizeof(double) * (size_t)(3 * G->smax * G->ld + 2 * G->ld);
     hipLaunchKernelGGL(k_stage_factor, dim3(Nn->batch), dim3(WAVE), lds, (hipStream_t)stream, *S, *Nn, d_mask, first_block, d_b0v);
     if (launch_status()) return -1;
-    return launch_stage_invert(S, Nn, d_mask, first_block, d_b0v, stream);
+    return launch_stage_invert(S, Nn, d_mask, first_block, d_b0v, tiles_adopted, stream);
   }
   // matrix-core Schur complement (see k_stage_factor_r) when the result tiles fit the staging tile; RLDL_NO_MFMA=1: fma form
   static const int no_mfma = getenv("RLDL_NO_MFMA") ? 1 : 0;
@@ -3560,18 +3566,18 @@ static int launch_stage_factor(const rldl_dev_sym *S, const rldl_dev_num *Nn, co
   else SF(32);
 #undef SF
   if (launch_status()) return -1;
-  return launch_stage_invert(S, Nn, d_mask, first_block, d_b0v, stream);
+  return launch_stage_invert(S, Nn, d_mask, first_block, d_b0v, tiles_adopted, stream);
 }
 // tiles of the product tri-solve from the factor as it stands (a handle that becomes stage-structured after its first factorisation)
 extern "C" int rldl_launch_stage_invert(const rldl_dev_sym *S, const rldl_dev_num *Nn, void *stream) {
-  return Nn->batch > 0 ? launch_stage_invert(S, Nn, 0, 0, 0, stream) : 0;
+  return Nn->batch > 0 ? launch_stage_invert(S, Nn, 0, 0, 0, 0, stream) : 0;
 }
 extern "C" int rldl_launch_stage_factor(const rldl_dev_sym *S, const rldl_dev_num *Nn, const int *d_mask, int first_block, void *stream) {
-  return launch_stage_factor(S, Nn, d_mask, first_block, 0, stream);
+  return launch_stage_factor(S, Nn, d_mask, first_block, 0, 0, stream);
 }
 // every instance restarts at its own block d_b0v[inst] (0 = full factorisation)
-extern "C" int rldl_launch_stage_factor_each(const rldl_dev_sym *S, const rldl_dev_num *Nn, const int *d_b0v, void *stream) {
-  return d_b0v ? launch_stage_factor(S, Nn, 0, 0, d_b0v, stream) : -1;
+extern "C" int rldl_launch_stage_factor_each(const rldl_dev_sym *S, const rldl_dev_num *Nn, const int *d_b0v, int tiles_adopted, void *stream) {
+  return d_b0v ? launch_stage_factor(S, Nn, 0, 0, d_b0v, tiles_adopted, stream) : -1;
 }
 
 extern "C" int rldl_launch_factor(const rldl_dev_sym *S, const rldl_dev_num *Nn, const int *d_mask, void *stream) {
@@ -3817,11 +3823,12 @@ extern "C" int rldl_launch_horizon_state(const rldl_dev_sym *So, const rldl_dev_
   return launch_status();
 }
 extern "C" int rldl_launch_horizon_adopt(const rldl_dev_sym *So, const rldl_dev_num *No, const rldl_dev_sym *Sn, const rldl_dev_num *Nn,
-                                         const double *rvo, const double *rvn, int m_keep, int c0, int b_pivot, int *d_b0v,
+                                         const double *rvo, const double *rvn, int m_keep, int c0, int b_pivot, int ti_prefix, int *d_b0v,
                                          int *d_n_reused, void *stream) {
+  if (ti_prefix > 0 && (!No->Ti || !Nn->Ti || ti_prefix > So->stage.pv_nTi || ti_prefix > Sn->stage.pv_nTi)) return -1;
   if (Nn->batch <= 0) return 0;
   if (No->batch != Nn->batch || c0 <= 0 || c0 > So->N || c0 > Sn->N || m_keep > So->m || m_keep > Sn->m) return -1;
-  hipLaunchKernelGGL(k_horizon_adopt, dim3(Nn->batch), dim3(WAVE), 0, (hipStream_t)stream, *So, *No, *Sn, *Nn, rvo, rvn, m_keep, c0, b_pivot,
+  hipLaunchKernelGGL(k_horizon_adopt, dim3(Nn->batch), dim3(WAVE), 0, (hipStream_t)stream, *So, *No, *Sn, *Nn, rvo, rvn, m_keep, c0, b_pivot, ti_prefix,
                      d_b0v, d_n_reused);
   return launch_status();
 }

@@ -50,6 +50,7 @@ void rldl_stage_maps_free(rldl_batch *h) {
 #undef FRI
   memset(G, 0, sizeof(*G));
   free(h->rec); h->rec = 0;
+  free(h->pv_tiD); h->pv_tiD = 0;
 }
 
 /* Tables of the block tri-solve (k_plan_solve<.., true> and friends): per stage block the L entries of the diagonal block
@@ -131,7 +132,7 @@ static void build_prod_tiles(rldl_batch *h, const int *bs, int nb, int ld, const
   rldl_dev_stage *G = &h->dsym.stage;
   const int smax = G->smax, ntmax = 2 * nb, ngmax = 2 * nb * (PV_KMAX / PV_GS);
   unsigned char *pat = 0;                       /* [smax][smax] pattern of the tile at hand */
-  int *rows_e = 0, *cnt = 0, *used = 0, *prog = 0, *seq = 0, *blk = 0, *tinfo = 0, *ent_src = 0, *colcnt = 0, *order = 0;
+  int *rows_e = 0, *cnt = 0, *used = 0, *prog = 0, *seq = 0, *blk = 0, *tinfo = 0, *ent_src = 0, *colcnt = 0, *order = 0, *tiD = 0;
   unsigned *tab = 0;
   unsigned short *src = 0;
   int b, t = 0, g = 0, nTi = 0, ntab = 0, kmax = 0, r, c, k, e, kind, ok = 0, i, NGp, nsteps = 0;
@@ -154,7 +155,10 @@ static void build_prod_tiles(rldl_batch *h, const int *bs, int nb, int ld, const
   src = (unsigned short *)malloc(sizeof(unsigned short) * (srccap + 1));
   if (!pat || !rows_e || !ent_src || !cnt || !order || !used || !colcnt || !prog || !seq || !tinfo || !blk || !tab || !src) goto out;
   ntab = 64;                                                          /* words [0, 64): zero = the closing groups' table words (no entries) */
+  tiD = (int *)malloc(sizeof(int) * (size_t)(nb + 1));
+  if (!tiD) goto out;
   for (b = 0; b < nb; b++) {
+    tiD[b] = nTi;
     for (kind = 0; kind < 2; kind++) {
       const int s = bs[b + 1] - bs[b];                                  /* columns of the tile */
       const int R = kind == 0 ? s : (b + 1 < nb ? bs[b + 2] - bs[b + 1] : 0);
@@ -260,11 +264,12 @@ static void build_prod_tiles(rldl_batch *h, const int *bs, int nb, int ld, const
   if (G->pv_tab && G->pv_prog && G->pv_tinfo && G->pv_blk && G->pv_src) {
     G->pv_ntiles = t; G->pv_ngroups = g; G->pv_nsteps = nsteps; G->pv_kmax = kmax; G->pv_nTi = nTi; G->pv_ntab = ntab;
     G->pv_ldTi = (nTi + 1) & ~1;
+    tiD[nb] = nTi; free(h->pv_tiD); h->pv_tiD = tiD; tiD = 0;
     ok = 1;
   }
 out:
   G->pv_ok = ok;
-  free(pat); free(rows_e); free(ent_src); free(cnt); free(order); free(used); free(colcnt); free(prog); free(seq); free(tinfo); free(blk); free(tab); free(src);
+  free(pat); free(rows_e); free(ent_src); free(cnt); free(order); free(used); free(colcnt); free(prog); free(seq); free(tinfo); free(blk); free(tab); free(src); free(tiD);
 }
 
 /* 0: maps built and uploaded (h->dsym.stage.nb > 0); 1: the pattern does not qualify (generic kernels stay in use) */

@@ -15,10 +15,12 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/mst
 cp $O/mstats/*/*kernel_stats.csv $O/mpc_kernel_stats.csv &&
 timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS --output-format csv -d $O/m1 -- python3 scripts/pmc_run_mpc.py > $O/m1.log 2>&1 &&
 timeout -k 10 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA --output-format csv -d $O/m2 -- python3 scripts/pmc_run_mpc.py > $O/m2.log 2>&1 &&
-python3 scripts/pmc_reduce.py mpc $O/pmc_mpc.json $O/m1 $O/m2 > /dev/null &&
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/m3 -- python3 scripts/pmc_run_mpc.py > $O/m3.log 2>&1 &&
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/m4 -- python3 scripts/pmc_run_mpc.py > $O/m4.log 2>&1 &&
+python3 scripts/pmc_reduce.py mpc $O/pmc_mpc.json $O/m1 $O/m2 $O/m3 $O/m4 > /dev/null &&
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/stats.log 2>&1 &&
 cp $O/stats/*/*kernel_stats.csv $O/kernel_stats.csv &&
 timeout -k 10 600 python3 bench.py > $O/bench.log 2>&1 && tail -1 $O/bench.log > $O/bench.json &&
 timeout -k 10 600 python3 scripts/bench_configs.py all > $O/configs.log 2>&1 && grep '^{' $O/configs.log > $O/configs.jsonl
 echo "rc=$?"; cut -c1-300 $O/bench.json; head -c 400 $O/pmc_traffic_solve.json
-rm -rf $O/sq1 $O/sq2 $O/pf $O/pw $O/stats $O/mstats $O/m1 $O/m2
+rm -rf $O/sq1 $O/sq2 $O/pf $O/pw $O/stats $O/mstats $O/m1 $O/m2 $O/m3 $O/m4
