@@ -9,6 +9,8 @@ Tolerances (north_star "within a stated fp64 tolerance"):
   ADMM iterates after 200 fixed-rho iterations         rel 1e-8
   reference known answers (x, y, obj)                  1e-4 = TESTS_TOL (tests/minunit.h:13)
 """
+import os
+
 import numpy as np
 import pytest
 from scipy import sparse
@@ -540,7 +542,8 @@ def test_pattern_groups_in_one_launch_chain(R):
         w = [w for idx, w in g1.groups if int(k) in idx.tolist()][0]
         ro = ob.OracleOSQP(P, q, A, l, u, perm=w.linsys().export_symbolic()["perm"], **kw).solve()
         assert relerr(r1["x"][k].cpu().numpy(), ro["x"]) < 1e-8 and relerr(r1["y"][k].cpu().numpy(), ro["y"]) < 1e-8
-    assert g1.one_launch                                                           # arrowhead patterns on the tile kernels (two instantiations here)
+    if not any(os.environ.get(k) for k in ("RLDL_NO_TILE", "RLDL_NO_ARROW", "RLDL_CHECK_STAGED")):   # (kernel-selection switches take the set off the single chain)
+        assert g1.one_launch                                                       # arrowhead patterns on the tile kernels (two instantiations here)
     g1.cleanup(); g0.cleanup()
 
 

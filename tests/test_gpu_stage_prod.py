@@ -4,13 +4,17 @@ every diagonal block of L replaced by its inverse at factor time.  Three links a
 names its place: (1) the tile values k_stage_invert wrote against numpy inverses of the exported L blocks, (2) a numpy
 emulation of the two passes driven by the exported tables against a triangular solve with the exported L, D, (3) the
 kernel's solve against that emulation and against the dense KKT solve."""
+import os
+
 import numpy as np
 import pytest
 from scipy import sparse
 from scipy.linalg import solve_triangular
 
 torch = pytest.importorskip("torch")
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(any(os.environ.get(k) for k in ("RLDL_NO_STAGE_PROD", "RLDL_NO_STAGE_FACTOR")),
+                                 reason="the product tri-solve is switched off")]
 SIGMA = 1e-6
 
 
