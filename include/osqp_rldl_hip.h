@@ -214,6 +214,11 @@ void  osqp_multi_free(osqp_multi *mm);
 typedef struct {           /* stage sizes: include/recursive_ldl.h:17-50 (N, nx, nu, ny, nt) */
   c_int N, nx, nu, ny, nt;
 } rldl_stage_dims;
+/* Host-only export of the product tri-solve's tables of a stage-structured pattern (csrc/rldl_device.h: rldl_dev_stage.pv_*), for
+ * inspection / CPU emulation in tests.  meta[8] and the arrays as in rldl_batch_export_prod (without tile values); LtoS[nnzL]
+ * maps the CSC entries of L to the factor slots the coupling tiles name.  2: the pattern does not qualify. */
+c_int rldl_stage_prod_export(const csc *P, const csc *A, const rldl_stage_dims *dims, c_int *meta, int *prog, int *tinfo, unsigned *tab,
+                             unsigned short *src, int *blk, c_int *LtoS);
 
 /* Replaces LDL_factorize_recursive (src/recursive_ldl.c:1139-1318) + init_linsys_solver_qdldl_recursive
  * (:1555-1672): the batch handle is built from the ASSEMBLED P, A of setup_AP_matrices (:1873-1970)

@@ -68,7 +68,7 @@ EXPORTED = [
     "osqp_batch_get", "osqp_batch_get_iterates", "osqp_batch_get_scaling", "osqp_batch_get_polish_status", "osqp_batch_get_rho", "osqp_batch_linsys", "osqp_batch_solve_async", "osqp_batch_wait", "osqp_batch_setup_recursive", "osqp_batch_update_recursive", "osqp_batch_partial_update_bounds",
     "osqp_batch_time_iteration", "osqp_batch_last_loop", "osqp_batch_trace_iteration", "osqp_batch_cleanup",
     "rldl_batch_init_recursive", "rldl_batch_update_from_stage", "rldl_version",
-    "rldl_symbolic_analyze", "rldl_stage_permutation", "rldl_plan_export", "rldl_setup_AP_matrices", "rldl_csc_free",
+    "rldl_symbolic_analyze", "rldl_stage_permutation", "rldl_plan_export", "rldl_stage_prod_export", "rldl_setup_AP_matrices", "rldl_csc_free",
     "osqp_horizon_setup", "osqp_horizon_update", "osqp_horizon_workspace", "osqp_horizon_N", "osqp_horizon_last_update",
     "osqp_horizon_free",
     "osqp_multi_create", "osqp_multi_solve", "osqp_multi_get", "osqp_multi_free",
@@ -116,6 +116,8 @@ def _declare(L):
     L.rldl_batch_export_factor.restype = c_int
     L.rldl_batch_export_prod.argtypes = [VP, c_int, IP, VP, VP, VP, VP, VP, FP]
     L.rldl_batch_export_prod.restype = c_int
+    L.rldl_stage_prod_export.argtypes = [VP, VP, C.POINTER(StageDims), IP, VP, VP, VP, VP, VP, IP]
+    L.rldl_stage_prod_export.restype = c_int
     L.osqp_multi_create.argtypes = [C.POINTER(VP), C.POINTER(VP), c_int, IP, VP]
     L.osqp_multi_create.restype = c_int
     L.osqp_multi_solve.argtypes = [VP]

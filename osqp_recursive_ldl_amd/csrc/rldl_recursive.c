@@ -127,17 +127,26 @@ out:
 #define PV_KMAX 12
 #define PV_GS 4                                                     /* steps per group */
 #define PV_DW 12                                                    /* descriptor words per group */
-static void build_prod_tiles(rldl_batch *h, const int *bs, int nb, int ld, const int *dptr, const int *dpos, const int *cptr,
-                             const int *cslot, const int *cpos) {
-  rldl_dev_stage *G = &h->dsym.stage;
-  const int smax = G->smax, ntmax = 2 * nb, ngmax = 2 * nb * (PV_KMAX / PV_GS);
+typedef struct {                                                     /* host arrays of the product tri-solve (owned; prod_tiles_free) */
+  unsigned *tab; int *seq, *tinfo, *blk, *tiD; unsigned short *src;
+  int ntab, nsteps, ntiles, ngroups, kmax, nTi;
+} prod_tiles_t;
+static void prod_tiles_free(prod_tiles_t *T) {
+  free(T->tab); free(T->seq); free(T->tinfo); free(T->blk); free(T->tiD); free(T->src);
+  memset(T, 0, sizeof(*T));
+}
+/* 0: built, 1: the pattern does not qualify */
+static int prod_tiles_host(int smax, int ldF, int N, const int *bs, int nb, int ld, const int *dptr, const int *dpos, const int *cptr,
+                           const int *cslot, const int *cpos, prod_tiles_t *out) {
+  const int ntmax = 2 * nb, ngmax = 2 * nb * (PV_KMAX / PV_GS);
   unsigned char *pat = 0;                       /* [smax][smax] pattern of the tile at hand */
   int *rows_e = 0, *cnt = 0, *used = 0, *prog = 0, *seq = 0, *blk = 0, *tinfo = 0, *ent_src = 0, *colcnt = 0, *order = 0, *tiD = 0;
   unsigned *tab = 0;
   unsigned short *src = 0;
   int b, t = 0, g = 0, nTi = 0, ntab = 0, kmax = 0, r, c, k, e, kind, ok = 0, i, NGp, nsteps = 0;
   size_t tabcap = (size_t)ngmax * 64 + 256, srccap = 0;
-  if (getenv("RLDL_NO_STAGE_PROD") || h->dsym.ldF >= 65536 || (h->sym->N + 2) * 8 >= 65536 || smax > 32) return;
+  memset(out, 0, sizeof(*out));
+  if (ldF >= 65536 || (N + 2) * 8 >= 65536 || smax > 32) return 1;
   for (b = 0; b < nb; b++) srccap += (size_t)smax * (size_t)smax;
   srccap += (size_t)cptr[nb];
   pat = (unsigned char *)malloc((size_t)smax * smax);
@@ -250,41 +259,65 @@ static void build_prod_tiles(rldl_batch *h, const int *bs, int nb, int ld, const
   for (i = 0; i < g; i++) memcpy(seq + PV_DW * i, prog + PV_DW * i, sizeof(int) * PV_DW);
   for (i = 0; i < g; i++) memcpy(seq + PV_DW * (NGp + i), prog + PV_DW * (g - 1 - i), sizeof(int) * PV_DW);
   nsteps = 2 * NGp;
-  G->pv_tab = (const unsigned *)upload_ints((const int *)tab, (size_t)ntab);
-  G->pv_prog = upload_ints(seq, (size_t)PV_DW * (size_t)(nsteps + 2 * RLDL_PV_RING));
-  G->pv_tinfo = upload_ints(tinfo, (size_t)4 * (size_t)(t + 1));
-  G->pv_blk = upload_ints(blk, (size_t)2 * (size_t)nb);
+  tiD[nb] = nTi;
+  out->tab = tab; out->seq = seq; out->tinfo = tinfo; out->blk = blk; out->tiD = tiD; out->src = src;
+  out->ntab = ntab; out->nsteps = nsteps; out->ntiles = t; out->ngroups = g; out->kmax = kmax; out->nTi = nTi;
+  tab = 0; seq = 0; tinfo = 0; blk = 0; tiD = 0; src = 0;
+  ok = 1;
+out:
+  free(pat); free(rows_e); free(ent_src); free(cnt); free(order); free(used); free(colcnt); free(prog); free(seq); free(tinfo); free(blk); free(tab); free(src); free(tiD);
+  return ok ? 0 : 1;
+}
+
+
+/* the same tables on the device (optional: pv_ok stays 0 on failure) */
+static void build_prod_tiles(rldl_batch *h, const int *bs, int nb, int ld, const int *dptr, const int *dpos, const int *cptr,
+                             const int *cslot, const int *cpos) {
+  rldl_dev_stage *G = &h->dsym.stage;
+  prod_tiles_t T;
+  G->pv_ok = 0;
+  if (getenv("RLDL_NO_STAGE_PROD")) return;
+  if (prod_tiles_host(G->smax, h->dsym.ldF, h->sym->N, bs, nb, ld, dptr, dpos, cptr, cslot, cpos, &T)) return;
+  G->pv_tab = (const unsigned *)upload_ints((const int *)T.tab, (size_t)T.ntab);
+  G->pv_prog = upload_ints(T.seq, (size_t)PV_DW * (size_t)(T.nsteps + 2 * RLDL_PV_RING));
+  G->pv_tinfo = upload_ints(T.tinfo, (size_t)4 * (size_t)(T.ntiles + 1));
+  G->pv_blk = upload_ints(T.blk, (size_t)2 * (size_t)nb);
   {
     unsigned short *d = 0;
-    if (hipMalloc((void **)&d, sizeof(unsigned short) * (size_t)(nTi + 1)) == hipSuccess) {
-      if (hipMemcpy(d, src, sizeof(unsigned short) * (size_t)nTi, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); d = 0; }
+    if (hipMalloc((void **)&d, sizeof(unsigned short) * (size_t)(T.nTi + 1)) == hipSuccess) {
+      if (hipMemcpy(d, T.src, sizeof(unsigned short) * (size_t)T.nTi, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); d = 0; }
     } else d = 0;
     G->pv_src = d;
   }
   if (G->pv_tab && G->pv_prog && G->pv_tinfo && G->pv_blk && G->pv_src) {
-    G->pv_ntiles = t; G->pv_ngroups = g; G->pv_nsteps = nsteps; G->pv_kmax = kmax; G->pv_nTi = nTi; G->pv_ntab = ntab;
-    G->pv_ldTi = (nTi + 1) & ~1;
-    tiD[nb] = nTi; free(h->pv_tiD); h->pv_tiD = tiD; tiD = 0;
-    ok = 1;
+    G->pv_ntiles = T.ntiles; G->pv_ngroups = T.ngroups; G->pv_nsteps = T.nsteps; G->pv_kmax = T.kmax; G->pv_nTi = T.nTi; G->pv_ntab = T.ntab;
+    G->pv_ldTi = (T.nTi + 1) & ~1;
+    free(h->pv_tiD); h->pv_tiD = T.tiD; T.tiD = 0;
+    G->pv_ok = 1;
   }
-out:
-  G->pv_ok = ok;
-  free(pat); free(rows_e); free(ent_src); free(cnt); free(order); free(used); free(colcnt); free(prog); free(seq); free(tinfo); free(blk); free(tab); free(src); free(tiD);
+  prod_tiles_free(&T);
 }
 
-/* 0: maps built and uploaded (h->dsym.stage.nb > 0); 1: the pattern does not qualify (generic kernels stay in use) */
-static int build_stage_maps(rldl_batch *h) {
-  const rldl_symbolic *s = h->sym;
-  const rldl_stage_dims *d = &h->stage;
+/* Host part of the stage-block view: block starts and, per block, the entries of the permuted KKT matrix and of L that fall into
+ * the diagonal block and into the coupling block below it.  lists: 0 = K diagonal, 1 = K coupling, 2 = L diagonal, 3 = L coupling;
+ * a[k][e] = source (Kx index / factor slot), b[k][e] = tile position row * ld + col.  0: ok, 1: the pattern does not qualify. */
+typedef struct { int nb, smax, ld, *bs, *ptr[4], *a[4], *b[4], tot[4]; } stage_lists_t;
+static void stage_lists_free(stage_lists_t *L) {
+  int k;
+  free(L->bs);
+  for (k = 0; k < 4; k++) { free(L->ptr[k]); free(L->a[k]); free(L->b[k]); }
+  memset(L, 0, sizeof(*L));
+}
+static int stage_lists(const rldl_symbolic *s, const rldl_stage_dims *d, stage_lists_t *L) {
   const int N = s->N, nb = 2 * (int)d->N + 2;
-  int *bs = 0, *blk = 0, *cnt = 0, *ptr[4] = {0, 0, 0, 0}, *a[4] = {0, 0, 0, 0}, *b[4] = {0, 0, 0, 0}, *fill = 0;
-  int i, j, k, p, smax = 0, ld, rc = 1, tot[4] = {0, 0, 0, 0};
-  rldl_dev_stage G;
-  memset(&G, 0, sizeof(G));
+  int *bs = 0, *blk = 0, *cnt = 0, *fill = 0, **ptr = L->ptr, **a = L->a, **b = L->b, *tot = L->tot;
+  int i, j, k, p, smax = 0, ld, rc = 1;
+  memset(L, 0, sizeof(*L));
   bs = (int *)malloc(sizeof(int) * (size_t)(nb + 2));
   blk = (int *)malloc(sizeof(int) * (size_t)(N + 1));
   cnt = (int *)calloc((size_t)4 * (size_t)(nb + 1), sizeof(int));
   fill = (int *)calloc((size_t)4 * (size_t)(nb + 1), sizeof(int));
+  L->bs = bs;
   if (!bs || !blk || !cnt || !fill) goto out;
   bs[0] = 0; k = 1;
   bs[1] = (int)d->nu;                                                                 /* Q0 */
@@ -300,7 +333,7 @@ static int build_stage_maps(rldl_batch *h) {
   }
   if (smax > STAGE_BLOCK_MAX) goto out;
   ld = ((smax + 7) & ~7) + 1;                                                         /* register-kernel bound SM = 8/16/24/32, tiles SM + 1 wide (odd) */
-  /* pass 1: classify and count; lists: 0 = K diagonal, 1 = K coupling, 2 = L diagonal, 3 = L coupling */
+  /* pass 1: classify and count */
   for (j = 0; j < N; j++)
     for (p = s->Kp[j]; p < s->Kp[j + 1]; p++) {
       i = s->Ki[p];
@@ -349,8 +382,24 @@ static int build_stage_maps(rldl_batch *h) {
         b[k][e] = (i - bs[blk[i]]) * ld + (j - bs[blk[j]]);
       }
     }
-  G.nb = nb; G.ld = ld; G.smax = smax;
-  G.bs = upload_ints(bs, (size_t)nb + 1);
+  L->nb = nb; L->smax = smax; L->ld = ld;
+  rc = 0;
+out:
+  free(blk); free(cnt); free(fill);
+  if (rc) stage_lists_free(L);
+  return rc;
+}
+
+/* 0: maps built and uploaded (h->dsym.stage.nb > 0); 1: the pattern does not qualify (generic kernels stay in use) */
+static int build_stage_maps(rldl_batch *h) {
+  stage_lists_t L;
+  rldl_dev_stage G;
+  int rc = 1, nb, **ptr = L.ptr, **a = L.a, **b = L.b, *tot = L.tot;
+  if (stage_lists(h->sym, &h->stage, &L)) return 1;
+  nb = L.nb;
+  memset(&G, 0, sizeof(G));
+  G.nb = nb; G.ld = L.ld; G.smax = L.smax;
+  G.bs = upload_ints(L.bs, (size_t)nb + 1);
   G.kd_ptr = upload_ints(ptr[0], (size_t)nb + 1); G.kd_src = upload_ints(a[0], (size_t)tot[0]); G.kd_pos = upload_ints(b[0], (size_t)tot[0]);
   G.kc_ptr = upload_ints(ptr[1], (size_t)nb + 1); G.kc_src = upload_ints(a[1], (size_t)tot[1]); G.kc_pos = upload_ints(b[1], (size_t)tot[1]);
   G.ld_ptr = upload_ints(ptr[2], (size_t)nb + 1); G.ld_slot = upload_ints(a[2], (size_t)tot[2]); G.ld_pos = upload_ints(b[2], (size_t)tot[2]);
@@ -358,16 +407,49 @@ static int build_stage_maps(rldl_batch *h) {
   h->dsym.stage = G;
   if (!G.bs || !G.kd_ptr || !G.kd_src || !G.kd_pos || !G.kc_ptr || !G.kc_src || !G.kc_pos || !G.ld_ptr || !G.ld_slot || !G.ld_pos ||
       !G.lc_ptr || !G.lc_slot || !G.lc_pos) { rldl_stage_maps_free(h); goto out; }
-  build_solve_tiles(h, bs, nb, ld, ptr[2], a[2], b[2], tot[2], ptr[3], a[3], b[3], tot[3]);   /* optional: sv_ok stays 0 on failure */
-  if (h->dsym.stage.sv_ok) build_prod_tiles(h, bs, nb, ld, ptr[2], b[2], ptr[3], a[3], b[3]);   /* optional as well */
+  build_solve_tiles(h, L.bs, nb, L.ld, ptr[2], a[2], b[2], tot[2], ptr[3], a[3], b[3], tot[3]);   /* optional: sv_ok stays 0 on failure */
+  if (h->dsym.stage.sv_ok) build_prod_tiles(h, L.bs, nb, L.ld, ptr[2], b[2], ptr[3], a[3], b[3]);   /* optional as well */
   h->rec = malloc(sizeof(int) * (size_t)(nb + 2));
   if (!h->rec) { rldl_stage_maps_free(h); goto out; }
   ((int *)h->rec)[0] = nb;
-  memcpy((int *)h->rec + 1, bs, sizeof(int) * (size_t)(nb + 1));
+  memcpy((int *)h->rec + 1, L.bs, sizeof(int) * (size_t)(nb + 1));
   rc = 0;
 out:
-  free(bs); free(blk); free(cnt); free(fill);
-  for (k = 0; k < 4; k++) { free(ptr[k]); free(a[k]); free(b[k]); }
+  stage_lists_free(&L);
+  return rc;
+}
+
+/* Host-only export of the product tri-solve's tables for a stage-structured pattern (no device needed): the symbolic analysis on
+ * the stage-interleaved order, the block lists and the tables exactly as a handle would upload them.  meta[8] = { usable, tiles,
+ * table words, Ti entries, nb, ld (tile positions in src are row * ld + col), kmax, steps }; with null arrays only meta is filled.
+ * src: D-tile entries = position in the block's tile, C-tile entries = factor slot (LtoS maps the CSC entries of L to slots). */
+c_int rldl_stage_prod_export(const csc *P, const csc *A, const rldl_stage_dims *dims, c_int *meta, int *prog, int *tinfo, unsigned *tab,
+                             unsigned short *src, int *blk, c_int *LtoS) {
+  rldl_symbolic *s = 0;
+  stage_lists_t L;
+  prod_tiles_t T;
+  c_int *perm, i, rc = 1;
+  if (!P || !A || !dims || !meta) return 1;
+  for (i = 0; i < 8; i++) meta[i] = 0;
+  perm = (c_int *)malloc(sizeof(c_int) * (size_t)(P->n + A->m));
+  if (!perm) return RLDL_MEM_ALLOC_ERROR;
+  rldl_stage_permutation(dims->N, dims->nx, dims->nu, dims->ny, dims->nt, perm);
+  if (rldl_symbolic_create(&s, P->n, A->m, P->p, P->i, A->p, A->i, 0, perm)) { free(perm); return RLDL_LINSYS_SOLVER_INIT_ERROR; }
+  free(perm);
+  if (stage_lists(s, dims, &L)) { rldl_symbolic_free(s); return 2; }
+  if (!prod_tiles_host(L.smax, (s->nS + s->N + 1) & ~1, s->N, L.bs, L.nb, L.ld, L.ptr[2], L.b[2], L.ptr[3], L.a[3], L.b[3], &T)) {
+    meta[0] = 1; meta[1] = T.ntiles; meta[2] = T.ntab; meta[3] = T.nTi; meta[4] = L.nb; meta[5] = L.ld; meta[6] = T.kmax; meta[7] = T.nsteps;
+    if (prog) memcpy(prog, T.seq, sizeof(int) * PV_DW * (size_t)T.nsteps);
+    if (tinfo) memcpy(tinfo, T.tinfo, sizeof(int) * 4 * (size_t)(T.ntiles + 1));
+    if (tab) memcpy(tab, T.tab, sizeof(unsigned) * (size_t)T.ntab);
+    if (src) memcpy(src, T.src, sizeof(unsigned short) * (size_t)T.nTi);
+    if (blk) memcpy(blk, T.blk, sizeof(int) * 2 * (size_t)L.nb);
+    if (LtoS) for (i = 0; i < s->nnzL; i++) LtoS[i] = s->LtoS[i];
+    prod_tiles_free(&T);
+    rc = 0;
+  } else rc = 2;
+  stage_lists_free(&L);
+  rldl_symbolic_free(s);
   return rc;
 }
 

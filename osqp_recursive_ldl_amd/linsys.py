@@ -300,6 +300,26 @@ def plan_export(P, A, polish=0, perm=None):
     return out
 
 
+def stage_prod_export(dims, P, A):
+    """Host-only (no GPU): tables of the product tri-solve of a stage-structured pattern, or None when it does not qualify."""
+    L = _lib.lib()
+    Pc = P if isinstance(P, CscPattern) else CscPattern(P)
+    Ac = A if isinstance(A, CscPattern) else CscPattern(A)
+    sd = _lib.StageDims(*[int(v) for v in dims])
+    meta = np.zeros(8, np.int64)
+    if L.rldl_stage_prod_export(Pc.ref, Ac.ref, C.byref(sd), _ip(meta), None, None, None, None, None, None):
+        return None
+    nt, nw, nTi, nb, ns = int(meta[1]), int(meta[2]), int(meta[3]), int(meta[4]), int(meta[7])
+    sym = symbolic_analyze(Pc, Ac, perm=__import__("osqp_recursive_ldl_amd").workloads.stage_permutation(*dims))
+    prog = np.zeros(12 * max(ns, 1), np.int32); tinfo = np.zeros(4 * (nt + 1), np.int32); tab = np.zeros(max(nw, 1), np.uint32)
+    src = np.zeros(max(nTi, 1), np.uint16); blk = np.zeros(2 * nb, np.int32); LtoS = np.zeros(max(sym["nnzL"], 1), np.int64)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    if L.rldl_stage_prod_export(Pc.ref, Ac.ref, C.byref(sd), _ip(meta), vp(prog), vp(tinfo), vp(tab), vp(src), vp(blk), _ip(LtoS)):
+        raise RuntimeError("rldl_stage_prod_export failed")
+    return dict(tiles=nt, steps=ns, nb=nb, ld=int(meta[5]), kmax=int(meta[6]), prog=prog.reshape(-1, 12), tinfo=tinfo.reshape(-1, 4)[:nt],
+                tab=tab[:nw], src=src[:nTi], blk=blk.reshape(-1, 2), LtoS=LtoS[:sym["nnzL"]], sym=sym)
+
+
 def plan_emulate_solve(plan, S, Dinv, x):
     """CPU emulation of the device schedule (plan_tri_solve in csrc/rldl_kernels.hip), one instance:
     S = factor in plan slot order [nS], Dinv [N], x = permuted right-hand side [N] -> L^-T D^-1 L^-1 x."""

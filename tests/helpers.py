@@ -107,3 +107,56 @@ def shared_pattern_batch(B, n=50, m=100, density=0.15, pattern_seed=1000):
         assert P.nnz == nnzP and A.nnz == nnzA and (P.indices == P0.indices).all()
         Px[b], Ax[b], q[b], l[b], u[b] = P.data, A.data, qq, ll, uu
     return P0, A0, Px, Ax, q, l, u
+
+
+# ---- product form of the block tri-solve (csrc/rldl_recursive.c: build_prod_tiles; kernels: stage_prod_solve) ----
+def prod_block_starts(dims):
+    """First permuted index of every stage block (compute_permutations order, src/recursive_ldl.c:1350-1362)."""
+    N, nx, nu, ny, nt = dims
+    bs = [0, nu]
+    for _ in range(1, N):
+        bs.append(bs[-1] + ny + nx); bs.append(bs[-1] + nx + nu)
+    bs.append(bs[-1] + ny + nx); bs.append(bs[-1] + nx); bs.append(bs[-1] + nt)
+    return np.array(bs)
+
+
+def prod_emulate(pr, Dinv, b):
+    """The two passes exactly as stage_prod_solve runs them (per step of the sequence, per lane), on the permuted right-hand side b."""
+    xs = b.copy()
+    tab, Ti, prog = pr["tab"], pr["Ti"], pr["prog"]
+    state = dict(acc=np.zeros(64), own=np.zeros(64))
+    NS = pr["steps"]
+
+    def group(step, fwd):
+        d = [int(v) & 0xffffffff for v in prog[step]]
+        ti0, wo, base, fl = d[:4]
+        masks = [d[4 + 2 * j] | (d[5 + 2 * j] << 32) for j in range(4)]
+        w = tab[wo:wo + 64].astype(np.int64)
+        row = (base >> 16) // 8 + ((w >> 24) & 31)
+        has = (w >> 29) & 1
+        if fwd and (fl & 1):
+            state["acc"][:] = 0.0
+        if not fwd and (fl & 2):
+            state["own"] = xs[row].copy()
+        off = ti0
+        for j in range(4):
+            col = (base & 0xffff) // 8 + ((w >> (5 * j)) & 31)
+            for lane in range(64):
+                if (masks[j] >> lane) & 1:
+                    assert (w[lane] >> (20 + j)) & 1
+                    v = Ti[off]; off += 1                          # entries of a step in lane order
+                    if fwd:
+                        state["acc"][lane] += v * xs[col[lane]]
+                    else:
+                        xs[col[lane]] -= v * state["own"][lane]
+        if fwd and (fl & 2):
+            for lane in range(64):
+                if has[lane]:
+                    xs[row[lane]] -= state["acc"][lane]
+
+    for st in range(NS // 2):
+        group(st, True)
+    xs *= Dinv
+    for st in range(NS // 2, NS):
+        group(st, False)
+    return xs
