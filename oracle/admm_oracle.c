@@ -18,7 +18,7 @@
  *   - adaptive_rho with adaptive_rho_interval == 0 uses the reference's PROFILING-off rule
  *     (osqp.c:266-279): 4*check_termination, or 100 when check_termination == 0.  The shipped
  *     default picks the interval from wall-clock time (osqp.c:459-485), which is not reproducible.
- *   - polish is not restated (out of scope).
+ *   (polish IS restated: src/polish.c :19-103, :212-350 -> `polish` below.)
  */
 #include <math.h>
 #include <stdlib.h>
