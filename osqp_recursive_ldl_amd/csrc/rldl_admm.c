@@ -536,7 +536,8 @@ c_int osqp_multi_create(osqp_multi **mp, osqp_batch **ws, c_int count, const c_i
   int keys[RLDL_MULTI_MAX], order[RLDL_MULTI_MAX], first_orig[RLDL_MULTI_MAX + 1], wpb = rldl_multi_tile_wpb(), *h_dest = 0, ok = 1, i, k;
   if (!mp) return 1;
   *mp = 0;
-  if (!ws || count <= 0 || count > RLDL_MULTI_MAX || !dest) return 1;
+  if (!ws || count <= 0 || !dest) return 1;
+  if (count > RLDL_MULTI_MAX) return 2;                            /* more patterns than one descriptor holds: the per-workspace route */
   first_orig[0] = 0;
   for (g = 0; g < count; g++) {                                   /* the fixed-iteration case on the tile kernels, same n and m */
     const osqp_batch *w = ws[g];
