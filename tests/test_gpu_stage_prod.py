@@ -74,3 +74,34 @@ def test_tiles_tables_and_solve(N):
         got[wl.n:] = (got[wl.n:] - rhs[inst][wl.n:]) * rho[inst]
         assert np.max(np.abs(got - sol)) <= 1e-9 * scale
     ls.free()
+
+
+@pytest.mark.parametrize("shape", ["mpc", "metric"])
+def test_inverse_based_solves_keep_the_residual_small_under_extreme_rho(shape):
+    """Both round-2 tri-solves multiply by explicitly inverted triangles (the tail of the arrowhead factor, the diagonal blocks of
+    the stage factor) where QDLDL substitutes.  rho_vec spanning 1e-6 .. 1e6 (what adaptive rho and the equality-row rule can
+    produce, osqp.c:1268-1319, auxil.c:88-91) stretches those triangles; the scaled residual of K x = b must stay at rounding level."""
+    import osqp_recursive_ldl_amd as R
+    from helpers import full_kkt
+    rng = np.random.default_rng(17)
+    B = 3
+    if shape == "mpc":
+        wl = R.workloads.MPCStageQPs(N=8)
+        Px, Ax, q, l, u = wl.values(B)
+        make = lambda rho: R.BatchLinsys.recursive(wl.dims, wl.P_pattern, wl.A_pattern, dev(Px), dev(Ax), SIGMA, dev(rho))
+    else:
+        wl = R.workloads.SharedPatternQPs()
+        Px, Ax, q, l, u = wl.values(B)
+        make = lambda rho: R.BatchLinsys(wl.P_pattern, wl.A_pattern, dev(Px), dev(Ax), SIGMA, dev(rho))
+    for rho in (10.0 ** rng.uniform(-6, 6, (B, wl.m)), np.full((B, wl.m), 1e6), np.full((B, wl.m), 1e-6)):
+        ls = make(rho)
+        assert ls.status == 0
+        rhs = rng.standard_normal((B, wl.n + wl.m))
+        out = ls.solve(dev(rhs.copy())).cpu().numpy()
+        for b in range(B):
+            P, qq, A, ll, uu = wl.instance(b)
+            K = full_kkt(sparse.triu(P), A, SIGMA, rho[b])
+            x = out[b].copy()
+            x[wl.n:] = (x[wl.n:] - rhs[b][wl.n:]) * rho[b]                    # nu from z_tilde (qdldl_interface.c:577-579)
+            assert np.max(np.abs(K @ x - rhs[b])) <= 1e-10 * max(1.0, np.max(np.abs(x)))
+        ls.free()
