@@ -1802,7 +1802,7 @@ __global__ __launch_bounds__(1024) void k_plan_admm(rldl_dev_sym S, rldl_dev_num
 // Large-N variant of the fused iteration: the per-position vectors do not fit in registers, so the right-hand side is
 // built and the x/z/y update applied in batches of four positions per lane (two extra memory latencies per batch).
 template <bool STAGE, int BLK = 0, bool PROD = false>
-__global__ __launch_bounds__(PROD ? 256 : 1024, PROD ? 4 : 1) void k_plan_admm_loop(rldl_dev_sym S, rldl_dev_num Nn, rldl_dev_admm W, int per_wave) {
+__global__ __launch_bounds__(PROD ? 256 : 1024, PROD ? 4 : 1) void k_plan_admm_loop(rldl_dev_sym S, rldl_dev_num Nn, rldl_dev_admm W, int per_wave, int iters) {
   extern __shared__ __attribute__((aligned(16))) double sh[];
   const int lane = threadIdx.x & (WAVE - 1), wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wpb = blockDim.x >> 6;
   const int inst = blockIdx.x * wpb + wv;
@@ -1845,48 +1845,60 @@ __global__ __launch_bounds__(PROD ? 256 : 1024, PROD ? 4 : 1) void k_plan_admm_l
   wait_dma();
   __syncthreads();
   if (!live) return;
-  if constexpr (PROD) stage_prod_solve(S, Sv, Nn.Ti + io * S.stage.pv_ldTi, xs, lane);
-  else if constexpr (BLK > 0) stage_tri_solve<BLK>(S, Sv, xs, xs + ((S.N + 1) & ~1), lane);
-  else plan_tri_solve(S, wl, Sv, xs, lane);
   const double alpha = W.alpha;
   double *dx = W.delta_x + io * n, *dy = W.delta_y + io * m;
   const int *perm = BLK ? permg : wl + S.po_perm;
-  for (int j0 = 0; j0 < S.N; j0 += 4 * WAVE) {
-    int oo[4];
-    double va[4], vb[4], vr[4], vl[4], vu[4], vrho[4];
+  // `iters` iterations per launch (the product tri-solve of stage patterns: the launcher passes the whole group; else 1): the
+  // update of an iteration leaves the NEXT right-hand side in xs, so only the first one is built from global memory above and
+  // x / z / y / rho_inv are read once per iteration instead of twice.  Same arithmetic on the same values as one launch per
+  // iteration: bit-identical iterates.
+  for (int it = 0; it < iters; it++) {
+    const bool last = it + 1 == iters;
+    if constexpr (PROD) stage_prod_solve(S, Sv, Nn.Ti + io * S.stage.pv_ldTi, xs, lane);
+    else if constexpr (BLK > 0) stage_tri_solve<BLK>(S, Sv, xs, xs + ((S.N + 1) & ~1), lane);
+    else plan_tri_solve(S, wl, Sv, xs, lane);
+    for (int j0 = 0; j0 < S.N; j0 += 4 * WAVE) {
+      int oo[4];
+      double va[4], vb[4], vr[4], vl[4], vu[4], vrho[4];
 #pragma unroll
-    for (int t = 0; t < 4; t++) {
-      const int j = j0 + t * WAVE + lane;
-      const int o = j < S.N ? perm[j] : -1;
-      oo[t] = o;
-      const bool con = o >= n;
-      const int iv = con || o < 0 ? 0 : o, ic = con ? o - n : 0;
-      const double *pa = con ? z + ic : x + iv;
-      va[t] = *pa; vb[t] = y[ic]; vr[t] = ri[ic]; vl[t] = l[ic]; vu[t] = u[ic]; vrho[t] = rv[ic];
-    }
+      for (int t = 0; t < 4; t++) {
+        const int j = j0 + t * WAVE + lane;
+        const int o = j < S.N ? perm[j] : -1;
+        oo[t] = o;
+        const bool con = o >= n;
+        const int iv = con || o < 0 ? 0 : o, ic = con ? o - n : 0;
+        const double *pa = con ? z + ic : x + iv;
+        const double *pb = con ? y + ic : q + iv;                  // (q: only the next right-hand side needs it)
+        va[t] = *pa; vb[t] = *pb; vr[t] = ri[ic]; vl[t] = l[ic]; vu[t] = u[ic]; vrho[t] = rv[ic];
+      }
 #pragma unroll
-    for (int t = 0; t < 4; t++) {
-      const int o = oo[t];
-      if (o < 0) continue;
-      const double s = xs[j0 + t * WAVE + lane];
-      if (o < n) {
-        const double xp = va[t];
-        const double xn = alpha * s + (1.0 - alpha) * xp;     // update_x :188-201
-        x[o] = xn;
-        if (W.write_delta) dx[o] = xn - xp;
-      } else {
-        const int i = o - n;
-        const double zp = va[t], yi = vb[t], r = vr[t];
-        const double zt = (zp - r * yi) + r * s;               // z_tilde, qdldl_interface.c:577-579
-        const double mix = alpha * zt + (1.0 - alpha) * zp;
-        double zn = mix + r * yi;                              // update_z :203-215
-        zn = fmin(fmax(zn, vl[t]), vu[t]);                     // project, proj.c:4-14
-        const double d = vrho[t] * (mix - zn);                 // update_y :217-228
-        z[i] = zn;
-        if (W.write_delta) dy[i] = d;
-        y[i] = yi + d;
+      for (int t = 0; t < 4; t++) {
+        const int o = oo[t], j = j0 + t * WAVE + lane;
+        if (o < 0) continue;
+        const double s = xs[j];
+        if (o < n) {
+          const double xp = va[t];
+          const double xn = alpha * s + (1.0 - alpha) * xp;     // update_x :188-201
+          x[o] = xn;
+          if (last && W.write_delta) dx[o] = xn - xp;
+          if (!last) xs[j] = W.sigma * xn - vb[t];                // compute_rhs of the next iteration (auxil.c:164-178)
+        } else {
+          const int i = o - n;
+          const double zp = va[t], yi = vb[t], r = vr[t];
+          const double zt = (zp - r * yi) + r * s;               // z_tilde, qdldl_interface.c:577-579
+          const double mix = alpha * zt + (1.0 - alpha) * zp;
+          double zn = mix + r * yi;                              // update_z :203-215
+          zn = fmin(fmax(zn, vl[t]), vu[t]);                     // project, proj.c:4-14
+          const double d = vrho[t] * (mix - zn);                 // update_y :217-228
+          const double yn = yi + d;
+          z[i] = zn;
+          if (last && W.write_delta) dy[i] = d;
+          y[i] = yn;
+          if (!last) xs[j] = zn - r * yn;
+        }
       }
     }
+    if (!last) wave_sync();
   }
 }
 
@@ -3202,16 +3214,17 @@ static int launch_blk_solve(const rldl_dev_sym *S, const rldl_dev_num *Nn, doubl
   BLK_DISPATCH(k_plan_solve, *S, *Nn, d_b, pw)
   return launch_status();
 }
-static int launch_blk_admm(const rldl_dev_sym *S, const rldl_dev_num *Nn, const rldl_dev_admm *W, void *stream) {
+static int launch_blk_admm(const rldl_dev_sym *S, const rldl_dev_num *Nn, const rldl_dev_admm *W, void *stream, int iters = 1) {
   if (prod_usable(S, Nn)) {
     const int pw = prod_per_wave_doubles(S), grid = (Nn->batch + PROD_WPB - 1) / PROD_WPB;
     hipLaunchKernelGGL((k_plan_admm_loop<false, 1, true>), dim3(grid), dim3(PROD_WPB * WAVE), prod_lds_bytes(S, (const void *)k_plan_admm_loop<false, 1, true>),
-                       (hipStream_t)stream, *S, *Nn, *W, pw);
+                       (hipStream_t)stream, *S, *Nn, *W, pw, iters);
     return launch_status();
   }
+  if (iters != 1) return -1;
   const int wpb = blk_pick_wpb(S), pw = blk_per_wave_doubles(S), grid = (Nn->batch + wpb - 1) / wpb;
   const size_t lds = sizeof(double) * (size_t)pw * wpb;
-  BLK_DISPATCH(k_plan_admm_loop, *S, *Nn, *W, pw)
+  BLK_DISPATCH(k_plan_admm_loop, *S, *Nn, *W, pw, 1)
   return launch_status();
 }
 
@@ -3242,8 +3255,8 @@ static int launch_plan_admm_loop(const rldl_dev_sym *S, const rldl_dev_num *Nn, 
   const void *k = g.stage ? (const void *)k_plan_admm_loop<true> : (const void *)k_plan_admm_loop<false>;
   if (g.lds > 64 * 1024 && hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds) != hipSuccess) return -1;
   const int grid = (Nn->batch + g.wpb - 1) / g.wpb, pw = plan_per_wave_doubles(S, g.stage);
-  if (g.stage) hipLaunchKernelGGL(k_plan_admm_loop<true>, dim3(grid), dim3(g.wpb * WAVE), g.lds, (hipStream_t)stream, *S, *Nn, *W, pw);
-  else hipLaunchKernelGGL(k_plan_admm_loop<false>, dim3(grid), dim3(g.wpb * WAVE), g.lds, (hipStream_t)stream, *S, *Nn, *W, pw);
+  if (g.stage) hipLaunchKernelGGL(k_plan_admm_loop<true>, dim3(grid), dim3(g.wpb * WAVE), g.lds, (hipStream_t)stream, *S, *Nn, *W, pw, 1);
+  else hipLaunchKernelGGL(k_plan_admm_loop<false>, dim3(grid), dim3(g.wpb * WAVE), g.lds, (hipStream_t)stream, *S, *Nn, *W, pw, 1);
   return launch_status();
 }
 static int launch_plan_admm(const rldl_dev_sym *S, const rldl_dev_num *Nn, const rldl_dev_admm *W, void *stream) {
@@ -3620,6 +3633,7 @@ extern "C" int rldl_launch_admm_iters(const rldl_dev_sym *S, const rldl_dev_num 
     }
     return 0;
   }
+  if (one <= 0 && blk_usable(S) && prod_usable(S, Nn)) return launch_blk_admm(S, Nn, W, stream, iters);   // the whole group in one launch
   rldl_dev_admm Wi = *W;
   for (int k = 0; k < iters; k++) {
     Wi.write_delta = k + 1 == iters ? W->write_delta : 0;

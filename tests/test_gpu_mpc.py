@@ -139,6 +139,28 @@ def test_block_tri_solve_and_fused_iteration_match_oracle(N):
     w.cleanup()
 
 
+def test_iterations_of_one_launch_equal_one_launch_per_iteration():
+    """Stage handles run a whole group of ADMM iterations in one launch (k_plan_admm_loop with the product tri-solve: an iteration's
+    update leaves the next right-hand side on chip).  Thirty iterations in one solve and thirty warm-started solves of one
+    iteration each are the same arithmetic on the same values: bit-identical iterates."""
+    import osqp_recursive_ldl_amd as R
+    wl = R.workloads.MPCStageQPs(N=5)
+    B = 6
+    Px, Ax, q, l, u = wl.values(B)
+    kw = dict(rho=0.1, sigma=1e-6, alpha=1.6, check_termination=0, adaptive_rho=0, warm_start=0, scaling=0)
+    w30 = R.OSQPBatch.recursive(wl.dims, wl.Q0, wl.Qi, wl.QN, wl.A0, wl.Ai, wl.Aij, wl.AN, dev(q), dev(l), dev(u), max_iter=30, **kw)
+    w1 = R.OSQPBatch.recursive(wl.dims, wl.Q0, wl.Qi, wl.QN, wl.A0, wl.Ai, wl.Aij, wl.AN, dev(q), dev(l), dev(u), max_iter=1, **kw)
+    assert w30.update_P_A(dev(Px), dev(Ax)) == 0 and w1.update_P_A(dev(Px), dev(Ax)) == 0
+    r30 = w30.solve()
+    r1 = w1.solve()                                                 # cold start, one iteration
+    assert w1.update_settings(warm_start=1) == 0
+    for _ in range(29):
+        r1 = w1.solve()
+    for key in ("x_iter", "y_iter", "z", "delta_x", "delta_y"):
+        assert torch.equal(r30[key], r1[key]), key
+    w30.cleanup(); w1.cleanup()
+
+
 def test_full_size_mpc_batch_4096_properties():
     """BASELINE config 3 at full size (N = 20, KKT 772, batch 4096), stage-structured handle: size-independent properties
     instead of an oracle sweep -- linearity of the block tri-solve, residual of the permuted system on a spread sample,
