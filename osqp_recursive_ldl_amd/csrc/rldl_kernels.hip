@@ -3249,14 +3249,14 @@ static int launch_plan_admm_t(const rldl_dev_sym *S, const rldl_dev_num *Nn, con
   else hipLaunchKernelGGL((k_plan_admm<TMAX, false>), dim3(grid), dim3(g.wpb * WAVE), g.lds, (hipStream_t)stream, *S, *Nn, *W, pw);
   return launch_status();
 }
-static int launch_plan_admm_loop(const rldl_dev_sym *S, const rldl_dev_num *Nn, const rldl_dev_admm *W, void *stream) {
+static int launch_plan_admm_loop(const rldl_dev_sym *S, const rldl_dev_num *Nn, const rldl_dev_admm *W, void *stream, int iters = 1) {
   const PlanGeom g = plan_geometry(S, (const void *)k_plan_admm_loop<true>, (const void *)k_plan_admm_loop<false>);
   if (g.wpb <= 0) return -1;
   const void *k = g.stage ? (const void *)k_plan_admm_loop<true> : (const void *)k_plan_admm_loop<false>;
   if (g.lds > 64 * 1024 && hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds) != hipSuccess) return -1;
   const int grid = (Nn->batch + g.wpb - 1) / g.wpb, pw = plan_per_wave_doubles(S, g.stage);
-  if (g.stage) hipLaunchKernelGGL(k_plan_admm_loop<true>, dim3(grid), dim3(g.wpb * WAVE), g.lds, (hipStream_t)stream, *S, *Nn, *W, pw, 1);
-  else hipLaunchKernelGGL(k_plan_admm_loop<false>, dim3(grid), dim3(g.wpb * WAVE), g.lds, (hipStream_t)stream, *S, *Nn, *W, pw, 1);
+  if (g.stage) hipLaunchKernelGGL(k_plan_admm_loop<true>, dim3(grid), dim3(g.wpb * WAVE), g.lds, (hipStream_t)stream, *S, *Nn, *W, pw, iters);
+  else hipLaunchKernelGGL(k_plan_admm_loop<false>, dim3(grid), dim3(g.wpb * WAVE), g.lds, (hipStream_t)stream, *S, *Nn, *W, pw, iters);
   return launch_status();
 }
 static int launch_plan_admm(const rldl_dev_sym *S, const rldl_dev_num *Nn, const rldl_dev_admm *W, void *stream) {
@@ -3634,6 +3634,9 @@ extern "C" int rldl_launch_admm_iters(const rldl_dev_sym *S, const rldl_dev_num 
     return 0;
   }
   if (one <= 0 && blk_usable(S) && prod_usable(S, Nn)) return launch_blk_admm(S, Nn, W, stream, iters);   // the whole group in one launch
+  // generic patterns on the grouped plan: the whole group in one launch of the loop kernel (the factor row, when it fits, stays in LDS
+  // across the iterations instead of being streamed once per iteration)
+  if (one <= 0 && iters > 1 && !blk_usable(S) && plan_admm_usable(S)) return launch_plan_admm_loop(S, Nn, W, stream, iters);
   rldl_dev_admm Wi = *W;
   for (int k = 0; k < iters; k++) {
     Wi.write_delta = k + 1 == iters ? W->write_delta : 0;
