@@ -24,7 +24,7 @@ def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to("cuda:0")
 
 
-@pytest.mark.parametrize("N", [1, 3, 20])
+@pytest.mark.parametrize("N", [1, 3, 20, 45])
 def test_tiles_tables_and_solve(N):
     import osqp_recursive_ldl_amd as R
     wl = R.workloads.MPCStageQPs(N=N)

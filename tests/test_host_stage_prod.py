@@ -11,7 +11,7 @@ from scipy.linalg import solve_triangular
 from helpers import prod_block_starts, prod_emulate
 
 
-@pytest.mark.parametrize("N", [1, 2, 5, 20])
+@pytest.mark.parametrize("N", [1, 2, 5, 20, 45])
 def test_tables_cover_the_factor_and_the_emulated_passes_solve(N):
     import osqp_recursive_ldl_amd as R
     wl = R.workloads.MPCStageQPs(N=N)
