@@ -124,7 +124,7 @@ c_int rldl_batch_export_factor(const rldl_batch *h, c_int inst, c_float *Lx, c_f
                                c_float *KKTx);                      /* host buffers, CSC order */
 c_int rldl_batch_factor_status(const rldl_batch *h, c_int *status); /* host[batch]: #positive D, or -1 */
 /* Stage handles: tables of the product tri-solve (csrc/rldl_device.h, rldl_dev_stage.pv_*) and the tile values of one instance,
- * copied back for inspection / CPU emulation in tests.  meta[8] = { usable, tiles, table words, Ti entries, nb, ld, kmax, steps };
+ * copied back for inspection / CPU emulation in tests.  meta[8] = { usable, tiles, table words, Ti entries, nb, row length of the inverted tiles (positions in src), kmax, steps };
  * with null arrays only meta is filled; prog int32[12 steps], tinfo int32[4 (tiles + 1)], tab uint32[table words],
  * src uint16[Ti entries], blk int32[2 nb], Ti double[Ti entries].  Returns 1 when the handle has no such tables. */
 c_int rldl_batch_export_prod(const rldl_batch *h, c_int inst, c_int *meta, int *prog, int *tinfo, unsigned *tab, unsigned short *src,

@@ -40,12 +40,14 @@ typedef struct {
    *   pv_tab        : one word per (group, lane) = columns of the lane's four entries (5 bits each, relative to the tile's first
    *                   column) | one bit per step << 20 (lane has an entry) | the lane's row (relative) << 24 | 1 << 29 (lane has entries)
    *   pv_tinfo[4 t] = { first Ti entry, entries, kind (0 = D, 1 = C), first group }
-   *   pv_src[i]     = where Ti entry i comes from: position row * ld + col in the inverted diagonal tile (D) / factor slot (C)
+   *   pv_src[i]     = where Ti entry i comes from: position row * pv_ldT + col in the inverted diagonal tile (D) / factor slot (C)
+   *   pv_dpos[e]    = ld_pos[e] in k_stage_invert's tile geometry (rows pv_ldT = its SM + 2 long)
+   *   pv_cidx[pv_cptr[b] .. pv_cptr[b + 1]) = the Ti entries of C_b (one flat list over the blocks: one batched copy loop)
    *   pv_blk[2 b], pv_blk[2 b + 1] = tile id of D_b, C_b or -1 */
   const unsigned *pv_tab;
-  const int *pv_prog, *pv_tinfo, *pv_blk;
+  const int *pv_prog, *pv_tinfo, *pv_blk, *pv_dpos, *pv_cptr, *pv_cidx;
   const unsigned short *pv_src;
-  int pv_ok, pv_ntiles, pv_ngroups, pv_nsteps, pv_kmax, pv_nTi, pv_ldTi, pv_ntab;
+  int pv_ok, pv_ntiles, pv_ngroups, pv_nsteps, pv_kmax, pv_nTi, pv_ldTi, pv_ntab, pv_ldT;
 } rldl_dev_stage;
 
 typedef struct {

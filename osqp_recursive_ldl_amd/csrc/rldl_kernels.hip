@@ -1586,40 +1586,74 @@ __device__ __forceinline__ void invert_block(const double *T, double *X, int ldT
   }
 }
 template <int SM>
-__global__ __launch_bounds__(WAVE) void k_stage_invert(rldl_dev_sym S, rldl_dev_num Nn, const int *__restrict__ mask, int b0,
-                                                       const int *__restrict__ b0v) {
+__global__ __launch_bounds__(WAVE, 4) void k_stage_invert(rldl_dev_sym S, rldl_dev_num Nn, const int *__restrict__ mask, int b0,
+                                                          const int *__restrict__ b0v) {
   const int inst = blockIdx.x, lane = threadIdx.x;
   if (mask && !mask[inst]) return;
   if (b0v) b0 = __builtin_amdgcn_readfirstlane(b0v[inst]);
   const rldl_dev_stage &G = S.stage;
-  const int ld = G.ld, nb = G.nb;
-  constexpr int ldT = SM + 2;                                     // even
+  const int nb = G.nb;
+  constexpr int ldT = SM + 2;                                     // even (= G.pv_ldT)
+  constexpr int PR = (SM * (SM - 1) / 2 + WAVE - 1) / WAVE;       // rounds of 64 entries that cover a diagonal block
   extern __shared__ __attribute__((aligned(16))) double sh[];
   double *T = sh, *X = sh + SM * ldT;                             // [SM][ldT] each
   const double *F = Nn.F + (size_t)inst * S.ldF;
   double *To = Nn.Ti + (size_t)inst * G.pv_ldTi;
   sv_cptr_t tinfo = (sv_cptr_t)(unsigned long long)G.pv_tinfo;
   sv_cptr_t blk = (sv_cptr_t)(unsigned long long)G.pv_blk;
-  for (int b = b0; b < nb; b++) {
-    const int td = blk[2 * b], tc = blk[2 * b + 1];
-    if (tc >= 0) {                                               // coupling tile L(b + 1, b): slot -> Ti
-      const int t0 = tinfo[4 * tc], E = tinfo[4 * tc + 1];
-      for (int e = lane; e < E; e += WAVE) To[t0 + e] = F[G.pv_src[t0 + e]];
+  sv_cptr_t ldp = (sv_cptr_t)(unsigned long long)G.ld_ptr;
+  // The index words of block b + 1 (factor slot and tile position of every entry of L_bb, source position of every tile entry) are
+  // fetched while block b is inverted: a block then waits for ONE memory round trip (its factor values), not for two in a row.
+  int slotN[PR], posN[PR];
+  auto load_idx = [&](int b) {
+    const int e0 = b < nb ? ldp[b] : 0, e1 = b < nb ? ldp[b + 1] : 0;
+#pragma unroll
+    for (int r = 0; r < PR; r++) {
+      const int e = e0 + r * WAVE + lane, ec = min(e, max(e1, 1) - 1);
+      slotN[r] = G.ld_slot[ec];
+      posN[r] = e < e1 ? G.pv_dpos[ec] : -1;                      // (the host's positions are in this kernel's tile geometry)
     }
+  };
+  load_idx(b0);
+  {                                                              // coupling tiles L(b + 1, b), b >= b0: factor slot -> Ti, one flat list, eight rounds of loads in flight
+    sv_cptr_t cpt = (sv_cptr_t)(unsigned long long)G.pv_cptr;
+    const int k1 = cpt[nb];
+    for (int k0 = cpt[b0]; k0 < k1; k0 += 8 * WAVE) {
+      int ti[8], sl[8];
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) ti[u] = G.pv_cidx[min(k0 + u * WAVE + lane, k1 - 1)];
+#pragma unroll
+      for (int u = 0; u < 8; u++) sl[u] = G.pv_src[ti[u]];
+#pragma unroll
+      for (int u = 0; u < 8; u++) v[u] = F[sl[u]];
+#pragma unroll
+      for (int u = 0; u < 8; u++) if (k0 + u * WAVE + lane < k1) To[ti[u]] = v[u];
+    }
+  }
+  for (int b = b0; b < nb; b++) {
+    const int td = blk[2 * b];
+    const int t0 = td >= 0 ? tinfo[4 * td] : 0, E = td >= 0 ? tinfo[4 * td + 1] : 0;
+    double val[PR];
+    int pos[PR], src[PR];
+#pragma unroll
+    for (int r = 0; r < PR; r++) {                               // this block's factor values start travelling (and the sources of its tile entries)
+      val[r] = F[slotN[r]]; pos[r] = posN[r];
+      src[r] = r * WAVE + lane < E ? (int)G.pv_src[t0 + min(r * WAVE + lane, max(E, 1) - 1)] : -1;
+    }
+    load_idx(b + 1);
     if (td < 0) continue;
     const int s = G.bs[b + 1] - G.bs[b];
     for (int p = lane; p < SM * ldT; p += WAVE) T[p] = 0.0;
     wave_sync();
-    for (int e = G.ld_ptr[b] + lane; e < G.ld_ptr[b + 1]; e += WAVE) {
-      const int pos = G.ld_pos[e];
-      T[(pos / ld) * ldT + pos % ld] = F[G.ld_slot[e]];
-    }
+#pragma unroll
+    for (int r = 0; r < PR; r++) if (pos[r] >= 0) T[pos[r]] = val[r];
     wave_sync();
     if (SM > 16 && s <= 16) invert_block<16>(T, X, ldT, lane, s);
     else invert_block<SM>(T, X, ldT, lane, s);
     wave_sync();
-    const int t0 = tinfo[4 * td], E = tinfo[4 * td + 1];
-    for (int e = lane; e < E; e += WAVE) { const int pos = G.pv_src[t0 + e]; To[t0 + e] = -X[(pos / ld) * ldT + pos % ld]; }
+#pragma unroll
+    for (int r = 0; r < PR; r++) if (src[r] >= 0) To[t0 + r * WAVE + lane] = -X[src[r]];
     wave_sync();
   }
 }
@@ -3542,7 +3576,7 @@ static int launch_stage_invert(const rldl_dev_sym *S, const rldl_dev_num *Nn, co
   const rldl_dev_stage *G = &S->stage;
   if (!G->pv_ok || !Nn->Ti || G->smax > 32) return 0;
   const int sm = G->smax <= 8 ? 8 : G->smax <= 16 ? 16 : G->smax <= 24 ? 24 : 32;
-  if (G->ld < sm + 1) return -1;
+  if (G->pv_ldT != sm + 2) return -1;
   const size_t lds = sizeof(double) * (size_t)(2 * sm * (sm + 2));
   const dim3 grid(Nn->batch), blk(WAVE);
   const int b0 = d_b0v ? 0 : first_block;

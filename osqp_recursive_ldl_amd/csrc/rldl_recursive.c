@@ -46,7 +46,7 @@ void rldl_stage_maps_free(rldl_batch *h) {
 #define FRI(p) if (p) (void)hipFree((void *)(p))
   FRI(G->bs); FRI(G->kd_ptr); FRI(G->kd_src); FRI(G->kd_pos); FRI(G->kc_ptr); FRI(G->kc_src); FRI(G->kc_pos);
   FRI(G->ld_ptr); FRI(G->ld_slot); FRI(G->ld_pos); FRI(G->lc_ptr); FRI(G->lc_slot); FRI(G->lc_pos);
-  FRI(G->sv_pk); FRI(G->sv_prog); FRI(G->pv_tab); FRI(G->pv_prog); FRI(G->pv_tinfo); FRI(G->pv_blk); FRI(G->pv_src);
+  FRI(G->sv_pk); FRI(G->sv_prog); FRI(G->pv_tab); FRI(G->pv_prog); FRI(G->pv_tinfo); FRI(G->pv_blk); FRI(G->pv_src); FRI(G->pv_dpos); FRI(G->pv_cptr); FRI(G->pv_cidx);
 #undef FRI
   memset(G, 0, sizeof(*G));
   free(h->rec); h->rec = 0;
@@ -128,17 +128,18 @@ out:
 #define PV_GS 4                                                     /* steps per group */
 #define PV_DW 12                                                    /* descriptor words per group */
 typedef struct {                                                     /* host arrays of the product tri-solve (owned; prod_tiles_free) */
-  unsigned *tab; int *seq, *tinfo, *blk, *tiD; unsigned short *src;
-  int ntab, nsteps, ntiles, ngroups, kmax, nTi;
+  unsigned *tab; int *seq, *tinfo, *blk, *tiD, *dposT, *cidx, *cptr; unsigned short *src;
+  int ntab, nsteps, ntiles, ngroups, kmax, nTi, ldT;
 } prod_tiles_t;
 static void prod_tiles_free(prod_tiles_t *T) {
-  free(T->tab); free(T->seq); free(T->tinfo); free(T->blk); free(T->tiD); free(T->src);
+  free(T->tab); free(T->seq); free(T->tinfo); free(T->blk); free(T->tiD); free(T->dposT); free(T->cidx); free(T->cptr); free(T->src);
   memset(T, 0, sizeof(*T));
 }
 /* 0: built, 1: the pattern does not qualify */
 static int prod_tiles_host(int smax, int ldF, int N, const int *bs, int nb, int ld, const int *dptr, const int *dpos, const int *cptr,
                            const int *cslot, const int *cpos, prod_tiles_t *out) {
   const int ntmax = 2 * nb, ngmax = 2 * nb * (PV_KMAX / PV_GS);
+  const int ldT = (smax <= 8 ? 8 : smax <= 16 ? 16 : smax <= 24 ? 24 : 32) + 2;   /* row length of k_stage_invert's tiles (its SM + 2) */
   unsigned char *pat = 0;                       /* [smax][smax] pattern of the tile at hand */
   int *rows_e = 0, *cnt = 0, *used = 0, *prog = 0, *seq = 0, *blk = 0, *tinfo = 0, *ent_src = 0, *colcnt = 0, *order = 0, *tiD = 0;
   unsigned *tab = 0;
@@ -189,7 +190,7 @@ static int prod_tiles_host(int smax, int ldF, int N, const int *bs, int nb, int 
           }
         for (r = 0; r < s; r++)
           for (c = 0; c < r; c++)
-            if (pat[r * smax + c]) { rows_e[r * smax + cnt[r]] = c; ent_src[r * smax + cnt[r]] = r * ld + c; cnt[r]++; }
+            if (pat[r * smax + c]) { rows_e[r * smax + cnt[r]] = c; ent_src[r * smax + cnt[r]] = r * ldT + c; cnt[r]++; }
       } else {
         for (e = cptr[b]; e < cptr[b + 1]; e++) {
           r = cpos[e] / ld; c = cpos[e] % ld;
@@ -260,6 +261,19 @@ static int prod_tiles_host(int smax, int ldF, int N, const int *bs, int nb, int 
   for (i = 0; i < g; i++) memcpy(seq + PV_DW * (NGp + i), prog + PV_DW * (g - 1 - i), sizeof(int) * PV_DW);
   nsteps = 2 * NGp;
   tiD[nb] = nTi;
+  out->dposT = (int *)malloc(sizeof(int) * (size_t)(dptr[nb] + 1));    /* ld_pos in the geometry of k_stage_invert's tiles */
+  if (!out->dposT) goto out;
+  for (e = 0; e < dptr[nb]; e++) out->dposT[e] = (dpos[e] / ld) * ldT + dpos[e] % ld;
+  out->ldT = ldT;
+  /* the Ti entries of the coupling tiles, block after block: k_stage_invert copies them from their factor slots in one batched loop */
+  out->cptr = (int *)malloc(sizeof(int) * (size_t)(nb + 1));
+  out->cidx = (int *)malloc(sizeof(int) * (size_t)(cptr[nb] + 1));
+  if (!out->cptr || !out->cidx) { free(out->dposT); free(out->cptr); free(out->cidx); out->dposT = out->cptr = out->cidx = 0; goto out; }
+  for (b = 0, k = 0; b < nb; b++) {
+    out->cptr[b] = k;
+    if (blk[2 * b + 1] >= 0) { const int tc = blk[2 * b + 1]; for (e = 0; e < tinfo[4 * tc + 1]; e++) out->cidx[k++] = tinfo[4 * tc] + e; }
+  }
+  out->cptr[nb] = k;
   out->tab = tab; out->seq = seq; out->tinfo = tinfo; out->blk = blk; out->tiD = tiD; out->src = src;
   out->ntab = ntab; out->nsteps = nsteps; out->ntiles = t; out->ngroups = g; out->kmax = kmax; out->nTi = nTi;
   tab = 0; seq = 0; tinfo = 0; blk = 0; tiD = 0; src = 0;
@@ -282,6 +296,9 @@ static void build_prod_tiles(rldl_batch *h, const int *bs, int nb, int ld, const
   G->pv_prog = upload_ints(T.seq, (size_t)PV_DW * (size_t)(T.nsteps + 2 * RLDL_PV_RING));
   G->pv_tinfo = upload_ints(T.tinfo, (size_t)4 * (size_t)(T.ntiles + 1));
   G->pv_blk = upload_ints(T.blk, (size_t)2 * (size_t)nb);
+  G->pv_dpos = upload_ints(T.dposT, (size_t)dptr[nb]);
+  G->pv_cptr = upload_ints(T.cptr, (size_t)nb + 1);
+  G->pv_cidx = upload_ints(T.cidx, (size_t)T.cptr[nb]);
   {
     unsigned short *d = 0;
     if (hipMalloc((void **)&d, sizeof(unsigned short) * (size_t)(T.nTi + 1)) == hipSuccess) {
@@ -289,7 +306,8 @@ static void build_prod_tiles(rldl_batch *h, const int *bs, int nb, int ld, const
     } else d = 0;
     G->pv_src = d;
   }
-  if (G->pv_tab && G->pv_prog && G->pv_tinfo && G->pv_blk && G->pv_src) {
+  if (G->pv_tab && G->pv_prog && G->pv_tinfo && G->pv_blk && G->pv_src && G->pv_dpos && G->pv_cptr && G->pv_cidx) {
+    G->pv_ldT = T.ldT;
     G->pv_ntiles = T.ntiles; G->pv_ngroups = T.ngroups; G->pv_nsteps = T.nsteps; G->pv_kmax = T.kmax; G->pv_nTi = T.nTi; G->pv_ntab = T.ntab;
     G->pv_ldTi = (T.nTi + 1) & ~1;
     free(h->pv_tiD); h->pv_tiD = T.tiD; T.tiD = 0;
@@ -438,7 +456,7 @@ c_int rldl_stage_prod_export(const csc *P, const csc *A, const rldl_stage_dims *
   free(perm);
   if (stage_lists(s, dims, &L)) { rldl_symbolic_free(s); return 2; }
   if (!prod_tiles_host(L.smax, (s->nS + s->N + 1) & ~1, s->N, L.bs, L.nb, L.ld, L.ptr[2], L.b[2], L.ptr[3], L.a[3], L.b[3], &T)) {
-    meta[0] = 1; meta[1] = T.ntiles; meta[2] = T.ntab; meta[3] = T.nTi; meta[4] = L.nb; meta[5] = L.ld; meta[6] = T.kmax; meta[7] = T.nsteps;
+    meta[0] = 1; meta[1] = T.ntiles; meta[2] = T.ntab; meta[3] = T.nTi; meta[4] = L.nb; meta[5] = T.ldT; meta[6] = T.kmax; meta[7] = T.nsteps;
     if (prog) memcpy(prog, T.seq, sizeof(int) * PV_DW * (size_t)T.nsteps);
     if (tinfo) memcpy(tinfo, T.tinfo, sizeof(int) * 4 * (size_t)(T.ntiles + 1));
     if (tab) memcpy(tab, T.tab, sizeof(unsigned) * (size_t)T.ntab);
