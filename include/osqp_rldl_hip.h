@@ -204,6 +204,10 @@ void  osqp_batch_cleanup(osqp_batch *w);                                /* osqp.
 typedef struct osqp_multi osqp_multi;
 c_int osqp_multi_create(osqp_multi **mp, osqp_batch **ws, c_int count, const c_int *dest, void *stream);
 c_int osqp_multi_solve(osqp_multi *mm);
+/* osqp_update_P_A of every workspace of the set in one chain (scatter, numeric factorisation, tail inverse over the stacked instances);
+ * d_Px[g] / d_Ax[g] = new values of ws[g], device arrays.  Enqueue-only; a failed refactorisation surfaces at the next osqp_multi_solve
+ * (RLDL_NONCVX_ERROR).  2: the set does not qualify (equilibration on, different factor kernels): update the workspaces one by one. */
+c_int osqp_multi_update_P_A(osqp_multi *mm, const c_float *const *d_Px, const c_float *const *d_Ax);
 c_int osqp_multi_get(osqp_multi *mm, c_float *d_x, c_float *d_y, c_float *d_z, int *d_status, int *d_iter, c_float *d_obj,
                      c_float *d_pri_res, c_float *d_dua_res);
 void  osqp_multi_free(osqp_multi *mm);

@@ -71,7 +71,7 @@ EXPORTED = [
     "rldl_symbolic_analyze", "rldl_stage_permutation", "rldl_plan_export", "rldl_stage_prod_export", "rldl_setup_AP_matrices", "rldl_csc_free",
     "osqp_horizon_setup", "osqp_horizon_update", "osqp_horizon_workspace", "osqp_horizon_N", "osqp_horizon_last_update",
     "osqp_horizon_free",
-    "osqp_multi_create", "osqp_multi_solve", "osqp_multi_get", "osqp_multi_free",
+    "osqp_multi_create", "osqp_multi_solve", "osqp_multi_update_P_A", "osqp_multi_get", "osqp_multi_free",
 ]
 
 
@@ -120,6 +120,8 @@ def _declare(L):
     L.rldl_stage_prod_export.restype = c_int
     L.osqp_multi_create.argtypes = [C.POINTER(VP), C.POINTER(VP), c_int, IP, VP]
     L.osqp_multi_create.restype = c_int
+    L.osqp_multi_update_P_A.argtypes = [VP, C.POINTER(VP), C.POINTER(VP)]
+    L.osqp_multi_update_P_A.restype = c_int
     L.osqp_multi_solve.argtypes = [VP]
     L.osqp_multi_solve.restype = c_int
     L.osqp_multi_get.argtypes = [VP] + [VP] * 8

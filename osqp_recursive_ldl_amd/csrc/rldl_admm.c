@@ -516,6 +516,10 @@ struct osqp_multi {
   rldl_dev_sym *dS; rldl_dev_num *dN; rldl_dev_admm *dW;
   rldl_dev_admm *hW;                                 /* pinned staging of the W structs (write_delta is set per solve) */
   int *d_dest;
+  int orig_of[RLDL_MULTI_MAX];                       /* group i of the set = ws[orig_of[i]] of the caller's array */
+  int upd_key, upd_flds, upd_ilds;                   /* one update chain for all groups: factor kernel instantiation (-1: not available), LDS sizes */
+  const double **hPA; const double **dPA;            /* pinned / device: [4][count] pointers (new P, new A, the workspaces' P copy, A copy) */
+  int *h_fail, *d_fail;                              /* pinned / device [count]: factorisation verdicts read back by osqp_multi_solve */
   void *stream;
 };
 
@@ -526,6 +530,10 @@ void osqp_multi_free(osqp_multi *mm) {
   if (mm->dW) (void)hipFree(mm->dW);
   if (mm->hW) (void)hipHostFree(mm->hW);
   if (mm->d_dest) (void)hipFree(mm->d_dest);
+  if (mm->dPA) (void)hipFree((void *)mm->dPA);
+  if (mm->d_fail) (void)hipFree(mm->d_fail);
+  if (mm->h_fail) (void)hipHostFree(mm->h_fail);
+  if (mm->hPA) (void)hipHostFree((void *)mm->hPA);
   free(mm->ws);
   free(mm);
 }
@@ -565,12 +573,25 @@ c_int osqp_multi_create(osqp_multi **mp, osqp_batch **ws, c_int count, const c_i
   if (ok && !HIP_OK(hipMalloc((void **)&mm->dW, sizeof(rldl_dev_admm) * (size_t)count))) ok = 0;
   if (ok && !HIP_OK(hipHostMalloc((void **)&mm->hW, sizeof(rldl_dev_admm) * (size_t)count, hipHostMallocDefault))) { mm->hW = 0; ok = 0; }
   if (ok && !HIP_OK(hipMalloc((void **)&mm->d_dest, sizeof(int) * (size_t)total))) ok = 0;
+  if (ok && !HIP_OK(hipMalloc((void **)&mm->dPA, sizeof(double *) * 4 * (size_t)count))) ok = 0;
+  if (ok && !HIP_OK(hipHostMalloc((void **)&mm->hPA, sizeof(double *) * 4 * (size_t)count, hipHostMallocDefault))) { mm->hPA = 0; ok = 0; }
+  if (ok && !HIP_OK(hipMalloc((void **)&mm->d_fail, sizeof(int) * RLDL_MULTI_MAX))) ok = 0;
+  if (ok && !HIP_OK(hipHostMalloc((void **)&mm->h_fail, sizeof(int) * RLDL_MULTI_MAX, hipHostMallocDefault))) { mm->h_fail = 0; ok = 0; }
+  mm->upd_key = -2;
   mm->M.ngroups = (int)count;
   mm->M.first_tile[0] = mm->M.first_inst[0] = 0;
   for (i = 0; ok && i < count; i++) {
     const osqp_batch *w = ws[order[i]];
     const int xdw = rldl_multi_tile_xdw(&w->ls->dsym), p = mm->nparts;
     mm->ws[i] = ws[order[i]];
+    mm->orig_of[i] = order[i];
+    {                                                             /* the update chain needs one factor kernel instantiation and no equilibration */
+      const int uk = w->st.scaling ? -1 : rldl_multi_update_key(&w->ls->dsym, &w->ls->num), fl = rldl_multi_update_lds(&w->ls->dsym, 0),
+                il = rldl_multi_update_lds(&w->ls->dsym, 1);
+      if (mm->upd_key == -2) mm->upd_key = uk; else if (mm->upd_key != uk) mm->upd_key = -1;
+      if (fl > mm->upd_flds) mm->upd_flds = fl;
+      if (il > mm->upd_ilds) mm->upd_ilds = il;
+    }
     if (i == 0 || keys[order[i]] != keys[order[i - 1]]) { mm->part_first[p] = i; mm->part_xdw[p] = 0; mm->nparts++; }
     if (xdw > mm->part_xdw[mm->nparts - 1]) mm->part_xdw[mm->nparts - 1] = xdw;
     for (k = 0; k < (int)w->batch; k++) h_dest[mm->M.first_inst[i] + k] = (int)dest[first_orig[order[i]] + k];
@@ -603,7 +624,7 @@ c_int osqp_multi_solve(osqp_multi *mm) {
     mm->hW[g] = mm->ws[g]->W;
   }
   if (!HIP_OK(hipMemcpyAsync(mm->dW, mm->hW, sizeof(rldl_dev_admm) * (size_t)mm->count, hipMemcpyHostToDevice, st))) return 1;
-  if (rldl_launch_multi_solve_begin(&mm->M, (int)mm->total, (int)mm->n, (int)mm->m, w0->st.warm_start ? 0 : 1, mm->stream)) return 1;
+  if (rldl_launch_multi_solve_begin(&mm->M, (int)mm->total, (int)mm->n, (int)mm->m, w0->st.warm_start ? 0 : 1, 0, mm->stream)) return 1;
   for (p = 0; p < mm->nparts; p++) {                              /* the fused iterations: one launch per kernel instantiation */
     const int gs = mm->part_first[p], ge = mm->part_first[p + 1];
     const osqp_batch *wp = mm->ws[gs];
@@ -618,7 +639,46 @@ c_int osqp_multi_solve(osqp_multi *mm) {
   }
   if (rldl_launch_multi_check_final(&mm->M, &w0->ls->dsym, &w0->W, (int)mm->total, (int)w0->st.max_iter, (int)(mm->n + mm->m), mm->stream)) return 1;
   for (g = 0; g < mm->count; g++) { mm->ws[g]->last_loop_launches = w0->st.max_iter; mm->ws[g]->last_loop_groups = 1; }
-  return HIP_OK(hipStreamSynchronize(st)) ? 0 : 1;
+  {                                                               /* verdict of the refactorisations enqueued since the last solve (osqp_multi_update_P_A, _async updates) */
+    int pending = 0, bad = 0;
+    for (g = 0; g < mm->count; g++) pending |= mm->ws[g]->refactor_pending;
+    if (pending) {
+      if (rldl_launch_multi_fail(&mm->M, mm->d_fail, mm->stream)) return 1;
+      if (!HIP_OK(hipMemcpyAsync(mm->h_fail, mm->d_fail, sizeof(int) * (size_t)mm->count, hipMemcpyDeviceToHost, st))) return 1;
+    }
+    if (!HIP_OK(hipStreamSynchronize(st))) return 1;
+    if (pending)
+      for (g = 0; g < mm->count; g++) { mm->ws[g]->refactor_pending = 0; bad |= mm->h_fail[g]; }
+    return bad ? RLDL_NONCVX_ERROR : 0;
+  }
+}
+
+/* osqp_update_P_A (src/osqp.c:1158-1266) of every workspace of the set in one chain: d_Px[g] / d_Ax[g] = new values of ws[g] (the caller's
+ * order; device arrays [batch_g][nnz], both required).  Enqueue-only like osqp_batch_update_P_A_async: a failed refactorisation is
+ * reported by the next osqp_multi_solve.  2: the set does not qualify (equilibration on, different factor kernels): update the
+ * workspaces one by one. */
+c_int osqp_multi_update_P_A(osqp_multi *mm, const c_float *const *d_Px, const c_float *const *d_Ax) {
+  rldl_dev_multi_pa PA;
+  c_int i, C;
+  if (!mm || !d_Px || !d_Ax) return 1;
+  if (mm->upd_key < 0) return 2;
+  C = mm->count;
+  for (i = 0; i < C; i++) {
+    osqp_batch *w = mm->ws[i];
+    if (!d_Px[mm->orig_of[i]] || !d_Ax[mm->orig_of[i]]) return 1;
+    if (w->stream != mm->stream && !HIP_OK(hipStreamSynchronize((hipStream_t)w->stream))) return 1;
+    mm->hPA[0 * C + i] = d_Px[mm->orig_of[i]]; mm->hPA[1 * C + i] = d_Ax[mm->orig_of[i]];
+    mm->hPA[2 * C + i] = w->Px; mm->hPA[3 * C + i] = w->Ax;
+    mm->hW[i] = w->W;
+  }
+  if (!HIP_OK(hipMemcpyAsync((void *)mm->dPA, (const void *)mm->hPA, sizeof(double *) * 4 * (size_t)C, hipMemcpyHostToDevice, (hipStream_t)mm->stream))) return 1;
+  if (!HIP_OK(hipMemcpyAsync(mm->dW, mm->hW, sizeof(rldl_dev_admm) * (size_t)C, hipMemcpyHostToDevice, (hipStream_t)mm->stream))) return 1;
+  PA.Px = mm->dPA; PA.Ax = mm->dPA + C; PA.keepP = (double *const *)(mm->dPA + 2 * C); PA.keepA = (double *const *)(mm->dPA + 3 * C);
+  if (rldl_launch_multi_update(&mm->M, &PA, (int)mm->total, mm->upd_key, mm->upd_flds, mm->upd_ilds, mm->stream)) return 1;
+  /* reset_info (auxil.c:628-645) of every workspace in one launch */
+  if (rldl_launch_multi_solve_begin(&mm->M, (int)mm->total, (int)mm->n, (int)mm->m, 0, 1, mm->stream)) return 1;
+  for (i = 0; i < C; i++) mm->ws[i]->refactor_pending = 1;
+  return 0;
 }
 
 /* results of all workspaces in the caller's instance order (device arrays: x[total][n], y / z[total][m], the rest [total]; z may be null) */

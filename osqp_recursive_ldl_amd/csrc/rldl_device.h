@@ -142,6 +142,9 @@ typedef struct {
   const rldl_dev_num *N;
   const rldl_dev_admm *W;
 } rldl_dev_multi;
+/* per-group value arrays of an update of all groups (device arrays [ngroups] of device pointers): the caller's new P / A values and the
+ * workspaces' own copies, which the scatter writes on the way */
+typedef struct { const double *const *Px, *const *Ax; double *const *keepP, *const *keepA; } rldl_dev_multi_pa;
 
 /* shared-memory footprint (bytes) of the LDS-resident variants; the launchers pick the global-memory
  * variant by themselves when this exceeds RLDL_LDS_LIMIT */
@@ -194,7 +197,12 @@ int rldl_launch_check_bounds(long long count, const double *l, const double *u, 
 int rldl_multi_key(const rldl_dev_sym *S, const rldl_dev_num *Nn, const rldl_dev_admm *W);
 int rldl_multi_tile_xdw(const rldl_dev_sym *S);
 int rldl_multi_tile_wpb(void);
-int rldl_launch_multi_solve_begin(const rldl_dev_multi *M, int total, int n, int m, int cold, void *stream);
+int rldl_launch_multi_solve_begin(const rldl_dev_multi *M, int total, int n, int m, int cold, int reset_rho_updates, void *stream);
+/* new P / A values for every group in one chain: scatter (+ the workspaces' own copies), arrowhead factorisation, tail inverse */
+int rldl_multi_update_key(const rldl_dev_sym *S, const rldl_dev_num *Nn);
+int rldl_multi_update_lds(const rldl_dev_sym *S, int which);
+int rldl_launch_multi_fail(const rldl_dev_multi *M, int *d_out, void *stream);   /* d_out[g] = sticky factorisation verdict of group g, cleared */
+int rldl_launch_multi_update(const rldl_dev_multi *M, const rldl_dev_multi_pa *PA, int total, int key, int factor_lds, int invert_lds, void *stream);
 int rldl_launch_multi_admm_iters(const rldl_dev_multi *M, const rldl_dev_sym *S0, const rldl_dev_num *N0, const rldl_dev_admm *W0, int iters,
                                  int max_xdw, void *stream);
 int rldl_launch_multi_check_final(const rldl_dev_multi *M, const rldl_dev_sym *S0, const rldl_dev_admm *W0, int total, int iter, int max_nm,

@@ -64,11 +64,16 @@ __device__ __forceinline__ int wave_any(int p) { return __any(p); }
 // KKT value scatter: Kx[PtoK[i]] = Px[i] (+sigma on the diagonal), Kx[AtoK[i]] = Ax[i],
 // Kx[rhotoK[j]] = -1/rho[j], sigma-only slots.  One workgroup of 256 threads per instance.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_kkt_assemble(rldl_dev_sym S, rldl_dev_num Nn, const double *__restrict__ Px,
-                                                      const double *__restrict__ Ax, const double *__restrict__ rho_vec,
-                                                      int set_sigma_only, const int *__restrict__ mask,
-                                                      double *__restrict__ keepP, double *__restrict__ keepA) {
-  const int inst = blockIdx.x;
+// Several workspaces in one launch (rldl_dev_multi): group of workgroup `bid` in a grid whose groups start at first[]
+__device__ __forceinline__ int multi_group(const int *first, int ng, int bid) {
+  int g = 0;
+  while (g + 1 < ng && bid >= first[g + 1]) g++;
+  return g;
+}
+__device__ __forceinline__ void kkt_assemble_body(const rldl_dev_sym &S, const rldl_dev_num &Nn, const double *__restrict__ Px,
+                                                  const double *__restrict__ Ax, const double *__restrict__ rho_vec,
+                                                  int set_sigma_only, const int *__restrict__ mask,
+                                                  double *__restrict__ keepP, double *__restrict__ keepA, int inst) {
   if (mask && !mask[inst]) return;
   double *K = Nn.Kx + (size_t)inst * S.nnzK;
   // four rounds of loads (value, slot, diagonal flag) in flight per thread before the first store
@@ -113,6 +118,17 @@ __global__ __launch_bounds__(256) void k_kkt_assemble(rldl_dev_sym S, rldl_dev_n
       K[S.rhotoK[j]] = -v;
     }
   }
+}
+__global__ __launch_bounds__(256) void k_kkt_assemble(rldl_dev_sym S, rldl_dev_num Nn, const double *__restrict__ Px,
+                                                      const double *__restrict__ Ax, const double *__restrict__ rho_vec,
+                                                      int set_sigma_only, const int *__restrict__ mask,
+                                                      double *__restrict__ keepP, double *__restrict__ keepA) {
+  kkt_assemble_body(S, Nn, Px, Ax, rho_vec, set_sigma_only, mask, keepP, keepA, blockIdx.x);
+}
+// the same for the stacked instances of several workspaces: new P / A values of every group (osqp_multi_update_P_A)
+__global__ __launch_bounds__(256) void k_kkt_assemble_multi(rldl_dev_multi M, rldl_dev_multi_pa PA) {
+  const int g = multi_group(M.first_inst, M.ngroups, blockIdx.x);
+  kkt_assemble_body(M.S[g], M.N[g], PA.Px[g], PA.Ax[g], nullptr, 0, nullptr, PA.keepP[g], PA.keepA[g], (int)blockIdx.x - M.first_inst[g]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -507,12 +523,6 @@ __device__ __forceinline__ int dual_infeasible(const rldl_dev_sym &S, const doub
   return !wave_any(viol);
 }
 
-// Several workspaces in one launch (rldl_dev_multi): group of workgroup `bid` in a grid whose groups start at first[]
-__device__ __forceinline__ int multi_group(const int *first, int ng, int bid) {
-  int g = 0;
-  while (g + 1 < ng && bid >= first[g + 1]) g++;
-  return g;
-}
 // mode bits
 #define CHK_TERMINATION 1
 #define CHK_ADAPT 2
@@ -2200,8 +2210,8 @@ __global__ __launch_bounds__(WAVE) void k_stage_factor_r(rldl_dev_sym S, rldl_de
 // Same outputs as k_factor (factor in plan slot order, D, Dinv, status); summation order of the Schur complement differs.
 // ------------------------------------------------------------------------------------------------
 template <int SM>
-__global__ __launch_bounds__(WAVE) void k_arrow_factor(rldl_dev_sym S, rldl_dev_num Nn, const int *__restrict__ mask) {
-  const int inst = blockIdx.x, lane = threadIdx.x;
+__device__ __forceinline__ void arrow_factor_body(const rldl_dev_sym &S, const rldl_dev_num &Nn, const int *__restrict__ mask, int inst) {
+  const int lane = threadIdx.x;
   if (mask && !mask[inst]) return;
   extern __shared__ double sh[];                                  // W = [L values, CSC order | D] as in k_factor, then scratch
   const int nW = S.nnzL + S.N, g0 = S.arrow_g0, g = S.arrow_g;
@@ -2297,6 +2307,15 @@ __global__ __launch_bounds__(WAVE) void k_arrow_factor(rldl_dev_sym S, rldl_dev_
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { npos += __shfl_xor(npos, o); zero |= __shfl_xor(zero, o); }
   if (lane == 0) { Nn.status[inst] = zero ? -1 : npos; if (Nn.fail && (zero || npos < S.n)) atomicOr(Nn.fail, 1); }
+}
+template <int SM>
+__global__ __launch_bounds__(WAVE) void k_arrow_factor(rldl_dev_sym S, rldl_dev_num Nn, const int *__restrict__ mask) {
+  arrow_factor_body<SM>(S, Nn, mask, blockIdx.x);
+}
+template <int SM>
+__global__ __launch_bounds__(WAVE) void k_arrow_factor_multi(rldl_dev_multi M) {
+  const int g = multi_group(M.first_inst, M.ngroups, blockIdx.x);
+  arrow_factor_body<SM>(M.S[g], M.N[g], nullptr, (int)blockIdx.x - M.first_inst[g]);
 }
 
 // ================================================================================================
@@ -2847,8 +2866,8 @@ __device__ __forceinline__ void col_gather(const ColRegs<TK> &Q, const char *shb
 // the rows of L22 as LDS broadcast reads (one address per wave), X in registers; the columns then go through LDS into
 // the (k, lane) tile order of Ti.  SM = compile-time bound on g.  One wave per instance.
 template <int SM>
-__global__ __launch_bounds__(WAVE) void k_tile_invert(rldl_dev_sym S, rldl_dev_num Nn, const int *__restrict__ mask) {
-  const int inst = blockIdx.x, lane = threadIdx.x;
+__device__ __forceinline__ void tile_invert_body(const rldl_dev_sym &S, const rldl_dev_num &Nn, const int *__restrict__ mask, int inst) {
+  const int lane = threadIdx.x;
   if (mask && !mask[inst]) return;
   extern __shared__ double sh[];                                 // g (g - 1) / 2 doubles: the triangle, then the staging buffer
   const int g = S.arrow_g, tri = (g * (g - 1)) >> 1;
@@ -2882,6 +2901,15 @@ __global__ __launch_bounds__(WAVE) void k_tile_invert(rldl_dev_sym S, rldl_dev_n
   wave_sync();
   double *To = Nn.Ti + (size_t)inst * S.ldTi;
   for (int p = lane; p < S.nTi; p += WAVE) To[p] = sh[p];
+}
+template <int SM>
+__global__ __launch_bounds__(WAVE) void k_tile_invert(rldl_dev_sym S, rldl_dev_num Nn, const int *__restrict__ mask) {
+  tile_invert_body<SM>(S, Nn, mask, blockIdx.x);
+}
+template <int SM>
+__global__ __launch_bounds__(WAVE) void k_tile_invert_multi(rldl_dev_multi M) {
+  const int g = multi_group(M.first_inst, M.ngroups, blockIdx.x);
+  tile_invert_body<SM>(M.S[g], M.N[g], nullptr, (int)blockIdx.x - M.first_inst[g]);
 }
 
 // LDS per wave of the tile kernels (pws doubles): x (xdw doubles, incl. the padding rows of the last block row), 64 dummy words
@@ -3808,6 +3836,32 @@ extern "C" int rldl_launch_check_bounds(long long count, const double *l, const 
 }
 
 // ---- several workspaces in one launch (osqp_multi_*, rldl_admm.c) ----
+// which groups may share the launches of an update of all groups (new P / A values -> scatter, numeric factorisation, tail inverse):
+// the arrowhead factor kernel's instantiation, or -1 (another factor path)
+extern "C" int rldl_multi_update_key(const rldl_dev_sym *S, const rldl_dev_num *Nn) {
+  if (!(S->arrow_ok && S->arrow_dense && S->arrow_g <= 64) || getenv("RLDL_NO_ARROW_FACTOR") || S->polish) return -1;
+  if (sizeof(double) * (size_t)(S->nnzL + S->N + S->arrow_g0 + 2 + 128) > RLDL_LDS_LIMIT) return -1;
+  if (!S->tile_ok || !Nn->Ti || S->arrow_tb != 0) return -1;
+  const int g = S->arrow_g;
+  return g <= 16 ? 16 : g <= 32 ? 32 : g <= 48 ? 48 : g <= 56 ? 56 : 64;
+}
+extern "C" int rldl_multi_update_lds(const rldl_dev_sym *S, int which) {     // dynamic LDS bytes of the factor (0) / tail inverse (1) kernel
+  const int g = S->arrow_g;
+  return which == 0 ? (int)(sizeof(double) * (size_t)(S->nnzL + S->N + S->arrow_g0 + 2 + 128)) : (int)(sizeof(double) * (size_t)((g * (g - 1)) / 2 + 2));
+}
+extern "C" int rldl_launch_multi_update(const rldl_dev_multi *M, const rldl_dev_multi_pa *PA, int total, int key, int factor_lds, int invert_lds,
+                                        void *stream) {
+  if (total <= 0) return 0;
+  const dim3 grid(total), blk(WAVE);
+  hipLaunchKernelGGL(k_kkt_assemble_multi, grid, dim3(256), 0, (hipStream_t)stream, *M, *PA);
+  if (launch_status()) return -1;
+#define MU(SMV) do { hipLaunchKernelGGL(k_arrow_factor_multi<SMV>, grid, blk, (size_t)factor_lds, (hipStream_t)stream, *M); \
+                     if (launch_status()) return -1; \
+                     hipLaunchKernelGGL(k_tile_invert_multi<SMV>, grid, blk, (size_t)invert_lds, (hipStream_t)stream, *M); } while (0)
+  switch (key) { case 16: MU(16); break; case 32: MU(32); break; case 48: MU(48); break; case 56: MU(56); break; case 64: MU(64); break; default: return -1; }
+#undef MU
+  return launch_status();
+}
 // which groups may share the launches: the instantiation of k_tile_admm their pattern selects (-1: not on the tile kernels) and
 // the entry-parallel check kernel
 extern "C" int rldl_multi_key(const rldl_dev_sym *S, const rldl_dev_num *Nn, const rldl_dev_admm *W) {
@@ -3817,10 +3871,10 @@ extern "C" int rldl_multi_key(const rldl_dev_sym *S, const rldl_dev_num *Nn, con
 }
 extern "C" int rldl_multi_tile_xdw(const rldl_dev_sym *S) { return tile_per_wave(S); }
 extern "C" int rldl_multi_tile_wpb(void) { return TILE_WPB; }
-extern "C" int rldl_launch_multi_solve_begin(const rldl_dev_multi *M, int total, int n, int m, int cold, void *stream) {
+extern "C" int rldl_launch_multi_solve_begin(const rldl_dev_multi *M, int total, int n, int m, int cold, int reset_rho_updates, void *stream) {
   if (total <= 0) return 0;
   rldl_dev_admm W0 = {};
-  hipLaunchKernelGGL(k_solve_begin, dim3(total), dim3(256), 0, (hipStream_t)stream, W0, n, m, cold, 0, *M);
+  hipLaunchKernelGGL(k_solve_begin, dim3(total), dim3(256), 0, (hipStream_t)stream, W0, n, m, cold, reset_rho_updates, *M);
   return launch_status();
 }
 extern "C" int rldl_launch_multi_admm_iters(const rldl_dev_multi *M, const rldl_dev_sym *S0, const rldl_dev_num *N0, const rldl_dev_admm *W0,
@@ -3833,6 +3887,15 @@ extern "C" int rldl_launch_multi_check_final(const rldl_dev_multi *M, const rldl
   if (total <= 0) return 0;
   const size_t lds = sizeof(double) * (size_t)(6 * max_nm + 8);   // (check_lds of the largest group; all groups share n and m)
   hipLaunchKernelGGL((k_admm_check<false, true>), dim3(total), dim3(WAVE), lds, (hipStream_t)stream, *S0, *W0, iter, CHK_FINAL | CHK_FINAL_NEEDS_INFO, *M);
+  return launch_status();
+}
+// verdicts of the factorisations enqueued since the last read, one word per group: the sticky flags of rldl_dev_num.fail, read and cleared
+__global__ void k_multi_fail(rldl_dev_multi M, int *__restrict__ out) {
+  const int g = threadIdx.x;
+  if (g < M.ngroups) out[g] = M.N[g].fail ? atomicExch(M.N[g].fail, 0) : 0;
+}
+extern "C" int rldl_launch_multi_fail(const rldl_dev_multi *M, int *d_out, void *stream) {
+  hipLaunchKernelGGL(k_multi_fail, dim3(1), dim3(RLDL_MULTI_MAX), 0, (hipStream_t)stream, *M, d_out);
   return launch_status();
 }
 // results of every group into caller-order arrays, one workgroup per instance

@@ -93,9 +93,36 @@ class OSQPBatchGroups:
             return dict(o)
         for _, w in self.groups:
             w.solve_async()
-        parts = [w.wait(clone=False) for _, w in self.groups]
+        parts, err = [], None
+        for _, w in self.groups:                             # wait for every group before raising: a verdict must not linger in another group
+            try:
+                parts.append(w.wait(clone=False))
+            except RuntimeError as e:
+                err = e
+        if err is not None:
+            raise err
         # one concatenation + one gather per result field (not one indexed copy per field and group)
         return {key: torch.cat([res[key] for res in parts], 0)[self._inv] for key in parts[0]}
+
+    def update_P_A(self, values):
+        """New P / A values for every group: values[k] = (Px, Ax) device tensors [batch_k, nnz] of group k (the order of self.groups).
+        One launch chain over all groups when the set qualifies, else one asynchronous update per workspace; a failed
+        refactorisation surfaces at the next solve."""
+        if len(values) != len(self.groups):
+            raise ValueError("one (Px, Ax) pair per pattern group")
+        if self._multi is not None:
+            G = len(values)
+            px = (C.c_void_p * G)(*[C.c_void_p(v[0].data_ptr()) for v in values])
+            ax = (C.c_void_p * G)(*[C.c_void_p(v[1].data_ptr()) for v in values])
+            rc = _lib.lib().osqp_multi_update_P_A(self._multi, px, ax)
+            if rc == 0:
+                self._keep = values                       # the arrays must outlive the enqueued chain
+                return
+            if rc != 2:
+                raise RuntimeError("osqp_multi_update_P_A failed (%d)" % rc)
+        for (_, w), (Px, Ax) in zip(self.groups, values):
+            if w.update_P_A(Px, Ax, wait=False):
+                raise RuntimeError("update_P_A failed")
 
     def cleanup(self):
         if self._multi is not None:

@@ -24,7 +24,9 @@ def wall(fn, reps=5):
     torch.cuda.synchronize()
     return 1e3 * (time.perf_counter() - t0) / reps
 def updates():
+    g.update_P_A(vals)
+def updates_per_stream():
     for (idx, w), (Px, Ax) in zip(g.groups, vals): w.update_P_A(Px, Ax, wait=False)
 def step():
     updates(); g.solve()
-print(json.dumps(dict(one_launch=g.one_launch, updates_ms=wall(updates), solve_ms=wall(g.solve), step_ms=wall(step))))
+print(json.dumps(dict(one_launch=g.one_launch, updates_ms=wall(updates), updates_one_stream_per_pattern_ms=wall(updates_per_stream), solve_ms=wall(g.solve), step_ms=wall(step))))

@@ -544,6 +544,33 @@ def test_pattern_groups_in_one_launch_chain(R):
         assert relerr(r1["x"][k].cpu().numpy(), ro["x"]) < 1e-8 and relerr(r1["y"][k].cpu().numpy(), ro["y"]) < 1e-8
     if not any(os.environ.get(k) for k in ("RLDL_NO_TILE", "RLDL_NO_ARROW", "RLDL_CHECK_STAGED")):   # (kernel-selection switches take the set off the single chain)
         assert g1.one_launch                                                       # arrowhead patterns on the tile kernels (two instantiations here)
+    # new P / A values for every group: one update chain over the stacked instances (osqp_multi_update_P_A) against one asynchronous
+    # update per workspace -- same scatter, factor and tail-inverse kernels on the same data, so the next solve is bit-identical too
+    def values(g, fp, fa):
+        out = []
+        for idx, w in g.groups:
+            Pu = [sparse.triu(sparse.csc_matrix(problems[i][0]), format="csc") for i in idx.tolist()]
+            Ac = [sparse.csc_matrix(problems[i][2]) for i in idx.tolist()]
+            for M in Pu + Ac:
+                M.sort_indices()
+            out.append((dev(np.stack([M.data for M in Pu]) * fp), dev(np.stack([M.data for M in Ac]) * fa)))
+        return out
+    g1.update_P_A(values(g1, 1.05, 0.97)); g0.update_P_A(values(g0, 1.05, 0.97))
+    u1, u0 = g1.solve(), g0.solve()
+    for key in ("x", "y", "z", "obj", "pri_res", "dua_res", "iter", "status"):
+        assert torch.equal(u1[key], u0[key]), key
+    assert not torch.equal(u1["x"], r0["x"])                                        # (the update took effect)
+    P, q, A, l, u = problems[5]
+    w = [w for idx, w in g1.groups if 5 in idx.tolist()][0]
+    ro = ob.OracleOSQP(P * 1.05, q, A * 0.97, l, u, perm=w.linsys().export_symbolic()["perm"], **kw).solve()
+    assert relerr(u1["x"][5].cpu().numpy(), ro["x"]) < 1e-8 and relerr(u1["y"][5].cpu().numpy(), ro["y"]) < 1e-8
+    # a refactorisation that fails (P -> -P: wrong inertia, osqp.c:1246-1262) is reported by the next solve of the set, once
+    g1.update_P_A(values(g1, -1.0, 1.0))
+    with pytest.raises(RuntimeError):
+        g1.solve()
+    g1.update_P_A(values(g1, 1.05, 0.97))
+    u2 = g1.solve()
+    assert torch.equal(u2["x"], u1["x"])
     g1.cleanup(); g0.cleanup()
 
 
