@@ -518,8 +518,8 @@ struct osqp_multi {
   int *d_dest;
   int orig_of[RLDL_MULTI_MAX];                       /* group i of the set = ws[orig_of[i]] of the caller's array */
   int upd_key, upd_flds, upd_ilds;                   /* one update chain for all groups: factor kernel instantiation (-1: not available), LDS sizes */
-  const double **hPA; const double **dPA;            /* pinned / device: [4][count] pointers (new P, new A, the workspaces' P copy, A copy) */
   int *h_fail, *d_fail;                              /* pinned / device [count]: factorisation verdicts read back by osqp_multi_solve */
+  int w_uploaded;
   void *stream;
 };
 
@@ -530,10 +530,8 @@ void osqp_multi_free(osqp_multi *mm) {
   if (mm->dW) (void)hipFree(mm->dW);
   if (mm->hW) (void)hipHostFree(mm->hW);
   if (mm->d_dest) (void)hipFree(mm->d_dest);
-  if (mm->dPA) (void)hipFree((void *)mm->dPA);
   if (mm->d_fail) (void)hipFree(mm->d_fail);
   if (mm->h_fail) (void)hipHostFree(mm->h_fail);
-  if (mm->hPA) (void)hipHostFree((void *)mm->hPA);
   free(mm->ws);
   free(mm);
 }
@@ -573,8 +571,6 @@ c_int osqp_multi_create(osqp_multi **mp, osqp_batch **ws, c_int count, const c_i
   if (ok && !HIP_OK(hipMalloc((void **)&mm->dW, sizeof(rldl_dev_admm) * (size_t)count))) ok = 0;
   if (ok && !HIP_OK(hipHostMalloc((void **)&mm->hW, sizeof(rldl_dev_admm) * (size_t)count, hipHostMallocDefault))) { mm->hW = 0; ok = 0; }
   if (ok && !HIP_OK(hipMalloc((void **)&mm->d_dest, sizeof(int) * (size_t)total))) ok = 0;
-  if (ok && !HIP_OK(hipMalloc((void **)&mm->dPA, sizeof(double *) * 4 * (size_t)count))) ok = 0;
-  if (ok && !HIP_OK(hipHostMalloc((void **)&mm->hPA, sizeof(double *) * 4 * (size_t)count, hipHostMallocDefault))) { mm->hPA = 0; ok = 0; }
   if (ok && !HIP_OK(hipMalloc((void **)&mm->d_fail, sizeof(int) * RLDL_MULTI_MAX))) ok = 0;
   if (ok && !HIP_OK(hipHostMalloc((void **)&mm->h_fail, sizeof(int) * RLDL_MULTI_MAX, hipHostMallocDefault))) { mm->h_fail = 0; ok = 0; }
   mm->upd_key = -2;
@@ -610,6 +606,23 @@ c_int osqp_multi_create(osqp_multi **mp, osqp_batch **ws, c_int count, const c_i
   return 0;
 }
 
+/* the device copies of the workspaces' rldl_dev_admm structs follow the host structs: uploaded again only when one of them changed
+ * (settings updates), after the stream has drained -- the pinned staging array is never rewritten under a copy that is still queued */
+static c_int multi_sync_W(osqp_multi *mm) {
+  c_int g;
+  int changed = 0;
+  for (g = 0; g < mm->count; g++) {
+    mm->ws[g]->W.write_delta = 1;
+    if (!mm->w_uploaded || memcmp(&mm->hW[g], &mm->ws[g]->W, sizeof(rldl_dev_admm))) changed = 1;
+  }
+  if (!changed) return 0;
+  if (!HIP_OK(hipStreamSynchronize((hipStream_t)mm->stream))) return 1;
+  for (g = 0; g < mm->count; g++) mm->hW[g] = mm->ws[g]->W;
+  if (!HIP_OK(hipMemcpyAsync(mm->dW, mm->hW, sizeof(rldl_dev_admm) * (size_t)mm->count, hipMemcpyHostToDevice, (hipStream_t)mm->stream))) return 1;
+  mm->w_uploaded = 1;
+  return 0;
+}
+
 /* osqp_solve of every workspace of the set; returns when the results are there (osqp_multi_get reads them in caller order) */
 c_int osqp_multi_solve(osqp_multi *mm) {
   c_int g;
@@ -618,12 +631,9 @@ c_int osqp_multi_solve(osqp_multi *mm) {
   hipStream_t st;
   if (!mm) return 7;
   w0 = mm->ws[0]; st = (hipStream_t)mm->stream;
-  for (g = 0; g < mm->count; g++) {                               /* work still queued on the workspaces' own streams comes first */
+  for (g = 0; g < mm->count; g++)                                 /* work still queued on the workspaces' own streams comes first */
     if (mm->ws[g]->stream != mm->stream && !HIP_OK(hipStreamSynchronize((hipStream_t)mm->ws[g]->stream))) return 1;
-    mm->ws[g]->W.write_delta = 1;
-    mm->hW[g] = mm->ws[g]->W;
-  }
-  if (!HIP_OK(hipMemcpyAsync(mm->dW, mm->hW, sizeof(rldl_dev_admm) * (size_t)mm->count, hipMemcpyHostToDevice, st))) return 1;
+  if (multi_sync_W(mm)) return 1;
   if (rldl_launch_multi_solve_begin(&mm->M, (int)mm->total, (int)mm->n, (int)mm->m, w0->st.warm_start ? 0 : 1, 0, mm->stream)) return 1;
   for (p = 0; p < mm->nparts; p++) {                              /* the fused iterations: one launch per kernel instantiation */
     const int gs = mm->part_first[p], ge = mm->part_first[p + 1];
@@ -663,17 +673,15 @@ c_int osqp_multi_update_P_A(osqp_multi *mm, const c_float *const *d_Px, const c_
   if (!mm || !d_Px || !d_Ax) return 1;
   if (mm->upd_key < 0) return 2;
   C = mm->count;
+  memset(&PA, 0, sizeof(PA));
   for (i = 0; i < C; i++) {
     osqp_batch *w = mm->ws[i];
     if (!d_Px[mm->orig_of[i]] || !d_Ax[mm->orig_of[i]]) return 1;
     if (w->stream != mm->stream && !HIP_OK(hipStreamSynchronize((hipStream_t)w->stream))) return 1;
-    mm->hPA[0 * C + i] = d_Px[mm->orig_of[i]]; mm->hPA[1 * C + i] = d_Ax[mm->orig_of[i]];
-    mm->hPA[2 * C + i] = w->Px; mm->hPA[3 * C + i] = w->Ax;
-    mm->hW[i] = w->W;
+    PA.Px[i] = d_Px[mm->orig_of[i]]; PA.Ax[i] = d_Ax[mm->orig_of[i]];
+    PA.keepP[i] = w->Px; PA.keepA[i] = w->Ax;
   }
-  if (!HIP_OK(hipMemcpyAsync((void *)mm->dPA, (const void *)mm->hPA, sizeof(double *) * 4 * (size_t)C, hipMemcpyHostToDevice, (hipStream_t)mm->stream))) return 1;
-  if (!HIP_OK(hipMemcpyAsync(mm->dW, mm->hW, sizeof(rldl_dev_admm) * (size_t)C, hipMemcpyHostToDevice, (hipStream_t)mm->stream))) return 1;
-  PA.Px = mm->dPA; PA.Ax = mm->dPA + C; PA.keepP = (double *const *)(mm->dPA + 2 * C); PA.keepA = (double *const *)(mm->dPA + 3 * C);
+  if (multi_sync_W(mm)) return 1;
   if (rldl_launch_multi_update(&mm->M, &PA, (int)mm->total, mm->upd_key, mm->upd_flds, mm->upd_ilds, mm->stream)) return 1;
   /* reset_info (auxil.c:628-645) of every workspace in one launch */
   if (rldl_launch_multi_solve_begin(&mm->M, (int)mm->total, (int)mm->n, (int)mm->m, 0, 1, mm->stream)) return 1;

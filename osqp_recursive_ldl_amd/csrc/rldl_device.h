@@ -142,9 +142,9 @@ typedef struct {
   const rldl_dev_num *N;
   const rldl_dev_admm *W;
 } rldl_dev_multi;
-/* per-group value arrays of an update of all groups (device arrays [ngroups] of device pointers): the caller's new P / A values and the
- * workspaces' own copies, which the scatter writes on the way */
-typedef struct { const double *const *Px, *const *Ax; double *const *keepP, *const *keepA; } rldl_dev_multi_pa;
+/* per-group value arrays of an update of all groups: the caller's new P / A values and the workspaces' own copies, which the scatter
+ * writes on the way.  Passed by value (kernel argument): captured at launch time, no staging buffer a later call could overwrite. */
+typedef struct { const double *Px[RLDL_MULTI_MAX], *Ax[RLDL_MULTI_MAX]; double *keepP[RLDL_MULTI_MAX], *keepA[RLDL_MULTI_MAX]; } rldl_dev_multi_pa;
 
 /* shared-memory footprint (bytes) of the LDS-resident variants; the launchers pick the global-memory
  * variant by themselves when this exceeds RLDL_LDS_LIMIT */
