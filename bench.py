@@ -56,6 +56,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-perturb", action="store_true", help="re-upload the same P / A values every step")
     ap.add_argument("--sync-steps", action="store_true", help="blocking update_P_A / solve calls (host round trips inside a step)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the RCCL process group and run the result all-gather even with ONE rank (exercises the "
+                         "collective path on a single GPU; the gather is then inside every timed step)")
     return ap.parse_args(argv)
 
 
@@ -153,13 +156,14 @@ def run_steps(args, shard, n, m, sizes, scaling, world):
     import torch.distributed as dist
     from osqp_recursive_ldl_amd import dist as rdist
     gsz = sizes if scaling == "strong" else None
+    coll = world > 1 or getattr(args, "force_dist", False)    # --force-dist: the collective runs even in a world of one rank
 
     def one():
         res = shard.step()
-        return rdist.gather_results(res, n, m, sizes=gsz) if world > 1 else res   # the path's only collective
+        return rdist.gather_results(res, n, m, sizes=gsz, force=coll) if coll else res   # the path's only collective
 
     def sync():
-        if world > 1:
+        if coll:
             dist.barrier()
         shard.device_sync()
 
@@ -175,17 +179,17 @@ def run_steps(args, shard, n, m, sizes, scaling, world):
     sync()
     mine = time.perf_counter() - t0
     per_rank = [mine]
-    if world > 1:
+    if coll:
         tt = torch.tensor([mine], dtype=torch.float64, device=res["x"].device)
         allt = [torch.zeros_like(tt) for _ in range(world)]
         dist.all_gather(allt, tt)
         per_rank = [float(x.item()) for x in allt]
     gather_ms = None
-    if world > 1:                                            # the collective of one step alone, outside the timed steps
+    if coll:                                                 # the collective of one step alone, outside the timed steps
         sync()
         g0 = time.perf_counter()
         for _ in range(10):
-            rdist.gather_results(shard.results(), n, m, sizes=gsz)
+            rdist.gather_results(shard.results(), n, m, sizes=gsz, force=True)
         sync()
         gather_ms = 1e2 * (time.perf_counter() - g0)
     return max(per_rank), per_rank, res, gather_ms
@@ -228,8 +232,13 @@ def main(argv=None):
         raise SystemExit("bench.py needs a GPU: the backend has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    coll = world > 1 or args.force_dist
+    if coll:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:                                       # --force-dist without a launcher: a world of this one rank
+            os.environ.setdefault("MASTER_PORT", str(free_port()))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=dev)
 
     import osqp_recursive_ldl_amd as R
@@ -274,7 +283,9 @@ def main(argv=None):
                                   " -- OFF (--no-perturb)" if args.no_perturb else "", args.iters),
                    "batch_total": total, "batch_per_gpu": sizes, "n": n, "m": m, "nnzKKT": dims["nnzKKT"], "nnzL": dims["nnzL"],
                    "admm_iters": args.iters, "parallelism": "batch-sharded x%d, one all-gather of the result records per step" % world,
-                   "per_rank_seconds": per_rank, "gather_ms": gather_ms},
+                   "per_rank_seconds": per_rank, "gather_ms": gather_ms,
+                   "collective": ("RCCL all_gather_into_tensor of the result records inside every step (backend %s, world %d%s)"
+                                  % (dist.get_backend(), world, ", --force-dist" if args.force_dist else "")) if coll else None},
         "roofline": {"bound": "hbm", "kernel": "batched permuted tri-solve + z~ epilogue (plugin `solve`: k_tile_solve on arrowhead "
                                                "patterns, else k_arrow_solve / k_plan_solve), rldl_batch_time_solve",
                      "achieved": solve_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": solve_gbs / HBM_PEAK_GBS, "traffic": None,
@@ -314,7 +325,7 @@ def main(argv=None):
     if rank == 0:
         print(json.dumps(out))
     w.cleanup()
-    if world > 1:
+    if coll:
         dist.destroy_process_group()
 
 

@@ -200,7 +200,9 @@ void  osqp_batch_cleanup(osqp_batch *w);                                /* osqp.
  * (solve_begin, the fused iterations once per kernel instantiation the patterns select, the closing check)
  * and osqp_multi_get writes the OSQPSolution / OSQPInfo fields in the caller's instance order: dest[k] = caller row of stacked
  * instance k (workspace 0's instances first).  osqp_multi_create returns 2 when the set does not qualify (other settings, patterns
- * off the tile kernels): solve the workspaces one by one then.  The workspaces stay owned by the caller. */
+ * off the tile kernels): solve the workspaces one by one then; 1 when dest is not a permutation of 0 .. total-1.  osqp_multi_solve
+ * re-checks the settings of every member (they can change through osqp_batch_update_settings) and returns 2 when the set no longer
+ * qualifies.  The workspaces stay owned by the caller. */
 typedef struct osqp_multi osqp_multi;
 c_int osqp_multi_create(osqp_multi **mp, osqp_batch **ws, c_int count, const c_int *dest, void *stream);
 c_int osqp_multi_solve(osqp_multi *mm);

@@ -536,6 +536,19 @@ void osqp_multi_free(osqp_multi *mm) {
   free(mm);
 }
 
+/* the fixed-iteration case the launch chain covers: no termination checks, no rho adaptation, no polish, same n, m, max_iter and
+ * warm_start in every workspace.  Checked at creation AND at every solve (check_termination, max_iter, warm_start can be changed
+ * on a member workspace by osqp_batch_update_settings afterwards). */
+static int multi_qualifies(osqp_batch *const *ws, c_int count) {
+  c_int g;
+  for (g = 0; g < count; g++) {
+    const osqp_batch *w = ws[g];
+    if (!w || w->st.check_termination || w->st.adaptive_rho || w->st.polish || w->n != ws[0]->n || w->m != ws[0]->m ||
+        w->st.max_iter != ws[0]->st.max_iter || w->st.warm_start != ws[0]->st.warm_start) return 0;
+  }
+  return 1;
+}
+
 c_int osqp_multi_create(osqp_multi **mp, osqp_batch **ws, c_int count, const c_int *dest, void *stream) {
   osqp_multi *mm;
   c_int g, total = 0;
@@ -545,14 +558,23 @@ c_int osqp_multi_create(osqp_multi **mp, osqp_batch **ws, c_int count, const c_i
   if (!ws || count <= 0 || !dest) return 1;
   if (count > RLDL_MULTI_MAX) return 2;                            /* more patterns than one descriptor holds: the per-workspace route */
   first_orig[0] = 0;
-  for (g = 0; g < count; g++) {                                   /* the fixed-iteration case on the tile kernels, same n and m */
+  if (!multi_qualifies(ws, count)) return 2;                      /* the fixed-iteration case on the tile kernels, same n and m */
+  for (g = 0; g < count; g++) {
     const osqp_batch *w = ws[g];
-    if (!w || w->st.check_termination || w->st.adaptive_rho || w->st.polish || w->n != ws[0]->n || w->m != ws[0]->m ||
-        w->st.max_iter != ws[0]->st.max_iter || w->st.warm_start != ws[0]->st.warm_start) return 2;
     keys[g] = rldl_multi_key(&w->ls->dsym, &w->ls->num, &w->W);
     if (keys[g] < 0) return 2;
     first_orig[g + 1] = first_orig[g] + (int)w->batch;
     total += w->batch;
+  }
+  {                                                               /* dest must be a permutation of 0 .. total-1: k_multi_gather writes x / y / status rows there */
+    unsigned char *seen = (unsigned char *)calloc((size_t)total, 1);
+    c_int t, bad = 0;
+    if (!seen) return RLDL_MEM_ALLOC_ERROR;
+    for (t = 0; t < total && !bad; t++) {
+      if (dest[t] < 0 || dest[t] >= total || seen[dest[t]]) bad = 1; else seen[dest[t]] = 1;
+    }
+    free(seen);
+    if (bad) return 1;
   }
   for (i = 0; i < count; i++) order[i] = i;                        /* groups by key (insertion sort, stable): one launch of the iterations per key */
   for (i = 1; i < count; i++) {
@@ -630,6 +652,7 @@ c_int osqp_multi_solve(osqp_multi *mm) {
   osqp_batch *w0;
   hipStream_t st;
   if (!mm) return 7;
+  if (!multi_qualifies(mm->ws, mm->count)) return 2;              /* settings of a member changed since creation: the caller solves the workspaces one by one */
   w0 = mm->ws[0]; st = (hipStream_t)mm->stream;
   for (g = 0; g < mm->count; g++)                                 /* work still queued on the workspaces' own streams comes first */
     if (mm->ws[g]->stream != mm->stream && !HIP_OK(hipStreamSynchronize((hipStream_t)mm->ws[g]->stream))) return 1;

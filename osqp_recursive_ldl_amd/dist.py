@@ -4,7 +4,6 @@ One process per GPU (torch.distributed; backend "nccl" is RCCL on ROCm, "gloo" o
 The data path has NO collective; the only exchange is one all-gather of the packed per-instance result
 record  [x(n) | y(m) | obj | pri_res | dua_res | iter | status]  at the end of a solve.
 """
-import numpy as np
 
 
 def shard_range(batch, rank, world):
@@ -35,13 +34,14 @@ def unpack_results(rec, n, m):
                 iter=rec[:, n + m + 3].to(torch.int32), status=rec[:, n + m + 4].to(torch.int32))
 
 
-def gather_results(res, n, m, sizes=None):
+def gather_results(res, n, m, sizes=None, force=False):
     """All-gather the per-rank result shards into the full batch on every rank (the one collective of
-    the path).  `sizes` = per-rank shard sizes when they differ; equal shards use all_gather_into_tensor."""
+    the path).  `sizes` = per-rank shard sizes when they differ; equal shards use all_gather_into_tensor.
+    force=True issues the collective even in a world of one rank (bench.py --force-dist: the RCCL call on a single GPU)."""
     import torch
     import torch.distributed as dist
     rec = pack_results(res, n, m).contiguous()
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force):
         return unpack_results(rec, n, m)
     world = dist.get_world_size()
     if sizes is None:
@@ -72,4 +72,3 @@ def sharded_values(values_fn, batch, rank, world):
 
 
 __all__ = ["shard_range", "shard_sizes", "pack_results", "unpack_results", "gather_results", "sharded_values"]
-_ = np

@@ -84,8 +84,13 @@ class OSQPBatchGroups:
         import torch
         if self._multi is not None:
             L = _lib.lib()
-            if L.osqp_multi_solve(self._multi):
-                raise RuntimeError("osqp_multi_solve failed")
+            rc = L.osqp_multi_solve(self._multi)
+            if rc == 2:                                      # a member's settings left the fixed-iteration case: per-workspace route from now on
+                L.osqp_multi_free(self._multi)
+                self._multi = None
+                return self.solve()
+            if rc:
+                raise RuntimeError("osqp_multi_solve failed (%d)" % rc)
             o = self._out
             p = lambda t: C.c_void_p(t.data_ptr())
             if L.osqp_multi_get(self._multi, p(o["x"]), p(o["y"]), p(o["z"]), p(o["status"]), p(o["iter"]), p(o["obj"]), p(o["pri_res"]), p(o["dua_res"])):
@@ -108,19 +113,29 @@ class OSQPBatchGroups:
         """New P / A values for every group: values[k] = (Px, Ax) device tensors [batch_k, nnz] of group k (the order of self.groups).
         One launch chain over all groups when the set qualifies, else one asynchronous update per workspace; a failed
         refactorisation surfaces at the next solve."""
+        import torch
         if len(values) != len(self.groups):
             raise ValueError("one (Px, Ax) pair per pattern group")
+        # the values were produced on torch's current stream; the chain runs on other streams: order them behind it
+        # (an event on the producer stream) and tell the caching allocator which streams still read the arrays
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(self._dev))
         if self._multi is not None:
+            self._mstream.wait_event(ready)
+            for v in values:
+                v[0].record_stream(self._mstream); v[1].record_stream(self._mstream)
             G = len(values)
             px = (C.c_void_p * G)(*[C.c_void_p(v[0].data_ptr()) for v in values])
             ax = (C.c_void_p * G)(*[C.c_void_p(v[1].data_ptr()) for v in values])
             rc = _lib.lib().osqp_multi_update_P_A(self._multi, px, ax)
             if rc == 0:
-                self._keep = values                       # the arrays must outlive the enqueued chain
                 return
             if rc != 2:
                 raise RuntimeError("osqp_multi_update_P_A failed (%d)" % rc)
         for (_, w), (Px, Ax) in zip(self.groups, values):
+            if w._stream is not None:
+                w._stream.wait_event(ready)
+                Px.record_stream(w._stream); Ax.record_stream(w._stream)
             if w.update_P_A(Px, Ax, wait=False):
                 raise RuntimeError("update_P_A failed")
 

@@ -442,6 +442,45 @@ def test_full_size_batch_4096_properties(R):
     w.cleanup()
 
 
+def test_config4_shard_8192_position_independence_across_rounds(R):
+    """BASELINE config 4's per-GPU shard (65536 / 8 = 8192 instances of the metric shape): the tile kernels hold 2048 waves at a
+    time, so 8192 instances are four resident rounds.  Copies of one instance placed in every round (and at both ends of a
+    round) must give bit-identical factors, solves and iterates; a spread sample agrees with the oracle."""
+    wl = R.workloads.SharedPatternQPs()
+    B = 8192
+    Px, Ax, q, l, u = wl.values(B)
+    spots = [1, 2047, 2048, 4095, 4096, 6143, 6144, 8191]          # first / last wave of every round
+    for arr in (Px, Ax, q, l, u):
+        arr[spots] = arr[0]
+    dPx, dAx = dev(Px), dev(Ax)
+    rho = np.full((B, wl.m), 0.1)
+    ls = R.BatchLinsys(wl.P_pattern, wl.A_pattern, dPx, dAx, 1e-6, dev(rho))
+    assert ls.status == 0 and (ls.factor_status() == wl.n).all()
+    g = torch.Generator(device="cuda:0"); g.manual_seed(1)
+    rhs = torch.randn((B, wl.n + wl.m), dtype=torch.float64, device="cuda:0", generator=g)
+    rhs[spots] = rhs[0].clone()
+    sol = ls.solve(rhs.clone())
+    f0 = ls.export_factor(0)["Lx"]
+    for k in spots:
+        assert np.array_equal(ls.export_factor(k)["Lx"], f0) and torch.equal(sol[k], sol[0]), k
+    sym = ls.export_symbolic()
+    for b in (0, 3000, 5555, 8190):
+        P, qq, A, ll, uu = wl.instance(b) if b not in spots else wl.instance(0)
+        ref = ob.OracleLinsys(P, A, 1e-6, rho[b], perm=sym["perm"]).solve(rhs[b].cpu().numpy())
+        assert relerr(sol[b].cpu().numpy(), ref) < 1e-10
+    ls.free()
+    w = R.OSQPBatch(wl.P_pattern, wl.A_pattern, dPx, dAx, dev(q), dev(l), dev(u), **FIXED)
+    r = w.solve()
+    assert (r["iter"] == 200).all() and bool(torch.isfinite(r["x"]).all())
+    for k in spots:
+        assert torch.equal(r["x"][k], r["x"][0]) and torch.equal(r["y"][k], r["y"][0]), k
+    for b in (4097, 8190):
+        P, qq, A, ll, uu = wl.instance(b)
+        ro = ob.OracleOSQP(P, qq, A, ll, uu, perm=sym["perm"], **FIXED).solve()
+        assert relerr(r["x_iter"][b].cpu().numpy(), ro["x_iter"]) < 1e-8
+    w.cleanup()
+
+
 def test_resident_iterations_equal_single_iteration_launches(R):
     """The fused kernel keeps an instance's factor and iterates on chip for a whole group of iterations; running the
     same number of iterations as separate one-iteration launches (state through HBM every time) must give the same
@@ -571,6 +610,64 @@ def test_pattern_groups_in_one_launch_chain(R):
     g1.update_P_A(values(g1, 1.05, 0.97))
     u2 = g1.solve()
     assert torch.equal(u2["x"], u1["x"])
+    g1.cleanup(); g0.cleanup()
+
+
+def test_pattern_groups_values_from_the_producer_stream_and_changed_settings(R):
+    """(1) update_P_A values that a torch kernel has just produced on torch's current stream: the chain runs on the set's own
+    stream and must be ordered behind the producer (event wait) -- result bit-equal to the per-workspace route fed the same
+    values after a full synchronisation.  (2) a settings change on a member workspace after creation takes the set off the single
+    chain (osqp_multi_solve returns 2) instead of being ignored.  (3) a dest that is no permutation is refused by osqp_multi_create."""
+    import ctypes as C
+    from osqp_recursive_ldl_amd import _lib
+    seeds = (2000, 2001, 2002)
+    wls = [R.workloads.SharedPatternQPs(pattern_seed=s) for s in seeds]
+    problems = [wls[k % 3].instance(k // 3) for k in range(3 * 40)]
+    kw = dict(rho=0.1, sigma=1e-6, alpha=1.6, max_iter=30, check_termination=0, adaptive_rho=0, warm_start=0, scaling=0)
+    g1 = R.OSQPBatchGroups(problems, **kw)
+    g0 = R.OSQPBatchGroups(problems, one_launch=False, **kw)
+    base = []
+    for idx, w in g1.groups:
+        Pu = [sparse.triu(sparse.csc_matrix(problems[i][0]), format="csc") for i in idx.tolist()]
+        Ac = [sparse.csc_matrix(problems[i][2]) for i in idx.tolist()]
+        for M in Pu + Ac:
+            M.sort_indices()
+        base.append((dev(np.stack([M.data for M in Pu])), dev(np.stack([M.data for M in Ac]))))
+    big = torch.ones((64, 1 << 20), dtype=torch.float64, device="cuda:0")
+    torch.cuda.synchronize()
+    for rep in range(3):
+        fp, fa = 1.0 + 0.02 * (rep + 1), 1.0 - 0.01 * (rep + 1)
+        big.mul_(1.0000001)                                         # keeps torch's stream busy in front of the producers
+        vals = [(torch.mul(bp, fp), torch.mul(ba, fa)) for bp, ba in base]   # produced on the current stream, NOT synchronised
+        g1.update_P_A(vals)
+        del vals                                                    # the allocator may recycle the arrays only after the chain has read them
+        junk = [torch.full_like(bp, float("nan")) for bp, _ in base]
+        r1 = {k: v.clone() for k, v in g1.solve().items()}
+        ref_vals = [(torch.mul(bp, fp), torch.mul(ba, fa)) for bp, ba in base]
+        torch.cuda.synchronize()
+        g0.update_P_A(ref_vals)
+        r0 = g0.solve()
+        for key in ("x", "y", "z", "obj", "iter", "status"):
+            assert torch.equal(r1[key], r0[key]), (rep, key)
+        del junk
+    if g1.one_launch:
+        # (2) max_iter changed on ONE member: the set no longer qualifies; the fallback honours every workspace's own settings
+        assert g1.groups[1][1].update_settings(max_iter=10) == 0
+        assert g0.groups[1][1].update_settings(max_iter=10) == 0
+        r1, r0 = g1.solve(), g0.solve()
+        assert not g1.one_launch
+        for key in ("x", "y", "iter"):
+            assert torch.equal(r1[key], r0[key]), key
+        assert set(r1["iter"].tolist()) == {10, 30}
+        # (3) dest validation
+        hs = (C.c_void_p * 3)(*[w.h for _, w in g0.groups])
+        for _, w in g0.groups:
+            w.update_settings(max_iter=30)
+        total = len(problems)
+        for bad in (np.r_[np.arange(total - 1), total], np.r_[0, np.arange(total - 1)], np.r_[-1, np.arange(1, total)]):
+            mh = C.c_void_p()
+            d = np.ascontiguousarray(bad, dtype=np.int64)
+            assert _lib.lib().osqp_multi_create(C.byref(mh), hs, 3, d.ctypes.data_as(_lib.IP), None) == 1 and not mh.value
     g1.cleanup(); g0.cleanup()
 
 
