@@ -211,6 +211,12 @@ def main(argv=None):
     if os.environ.get("WORLD_SIZE") is None and args.gpus > 1:
         sys.exit(launch_ranks(args, argv))
     world, rank, local_rank = check_world(args)
+    # stdout carries exactly ONE line, the JSON record of rank 0: native libraries print there too (RCCL writes its version banner
+    # to stdout when the first communicator is created), so file descriptor 1 points at stderr for the whole run and the record
+    # goes out through the saved descriptor at the end
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     import numpy as np
     import torch
@@ -322,8 +328,10 @@ def main(argv=None):
     if cpu is not None:
         assert np.array_equal(perm0, w.linsys().export_symbolic()["perm"])
         out["cpu_baseline"] = cpu
+    sys.stdout.flush()
     if rank == 0:
-        print(json.dumps(out))
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    os.close(real_stdout)
     w.cleanup()
     if coll:
         dist.destroy_process_group()

@@ -132,6 +132,12 @@ c_int rldl_batch_export_prod(const rldl_batch *h, c_int inst, c_int *meta, int *
 /* average device time (ms) of the last `solve` kernel launch group measured with HIP events on the
  * handle's stream; bench.py's live roofline measurement uses this */
 c_int rldl_batch_time_solve(rldl_batch *h, c_float *d_b, c_int reps, c_float *ms_per_launch);
+/* the same over a rotation of handles that share one stream (launch r solves hs[r % count] on d_b[r % count]): with a combined
+ * working set beyond the 256 MB Infinity Cache every launch streams its factor from HBM */
+c_int rldl_batch_time_solve_rotating(rldl_batch **hs, c_float **d_b, c_int count, c_int reps, c_float *ms_per_launch);
+/* tracing aid: wave timeline of one launch of the solve kernel, host_out[batch][8] int64 ticks of the 100 MHz device clock
+ * (wave start, all loads landed, forward gather / forward product / backward product / scatter done, stores issued, 0); 2 = this handle's solve kernel carries no timeline */
+c_int rldl_batch_trace_solve(rldl_batch *h, c_float *d_b, long long *host_out);
 
 /* =====================================================================================
  * 3. Batched ADMM driver (device-resident mirror of src/osqp.c + src/auxil.c step kernels)

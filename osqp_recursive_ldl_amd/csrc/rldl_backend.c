@@ -154,7 +154,7 @@ static int upload_symbolic(rldl_batch *h) {
   D->arrow_vsteps = s->arrow_vsteps; D->arrow_vrows = s->arrow_vrows;
   D->tile_ok = D->arrow_ok ? s->tile_ok : 0; D->tile_ta = s->tile_ta; D->tile_tq = s->tile_tq; D->tile_lanes = s->tile_lanes;
   D->nTi = s->nTi; D->ldTi = (s->nTi + 1) & ~1;
-  D->po_tlane = s->po_tlane; D->po_tmap = s->po_tmap; D->po_tislot = s->po_tislot;
+  D->po_tlane = s->po_tlane; D->po_tmap = s->po_tmap; D->po_tislot = s->po_tislot; D->po_tmask = s->po_tmask; D->po_pinv = s->po_pinv; D->po_trc = s->po_trc;
   D->tile_admm_ok = D->tile_ok ? s->tile_admm_ok : 0; D->tile_vslots = s->tile_vslots; D->tile_slots = s->tile_slots; D->po_tpos = s->po_tpos;
   D->tile_ck[0] = s->tile_ck[0]; D->tile_ck[1] = s->tile_ck[1]; D->tile_ck[2] = s->tile_ck[2]; D->tile_tk = s->tile_tk; D->tile_sp = s->tile_sp;
   D->po_cmap = s->po_cmap; D->po_crow = s->po_crow;
@@ -498,6 +498,45 @@ c_int rldl_batch_time_solve(rldl_batch *h, c_float *d_b, c_int reps, c_float *ms
   if (!HIP_OK(hipEventElapsedTime(&ms, (hipEvent_t)h->ev0, (hipEvent_t)h->ev1))) return 1;
   if (ms_per_launch) *ms_per_launch = (c_float)ms / (c_float)reps;
   return 0;
+}
+
+/* The same timing over a ROTATION of handles: launch r solves handle r % count on its right-hand side d_b[r % count], all on the
+ * stream of hs[0] (the handles must share it).  With count x (factor + tile bytes per handle) beyond the 256 MB Infinity Cache every
+ * launch streams its factor rows from HBM instead of finding them cached from the previous launch of the same handle. */
+c_int rldl_batch_time_solve_rotating(rldl_batch **hs, c_float **d_b, c_int count, c_int reps, c_float *ms_per_launch) {
+  c_int r;
+  float ms = 0.f;
+  if (!hs || !d_b || count <= 0 || reps <= 0) return 1;
+  for (r = 0; r < count; r++) if (!hs[r] || !d_b[r] || hs[r]->stream != hs[0]->stream) return 1;
+  if (!HIP_OK(hipEventRecord((hipEvent_t)hs[0]->ev0, (hipStream_t)hs[0]->stream))) return 1;
+  for (r = 0; r < reps; r++)
+    if (rldl_launch_solve(&hs[r % count]->dsym, &hs[r % count]->num, d_b[r % count], hs[0]->stream)) return 1;
+  if (!HIP_OK(hipEventRecord((hipEvent_t)hs[0]->ev1, (hipStream_t)hs[0]->stream))) return 1;
+  if (!HIP_OK(hipEventSynchronize((hipEvent_t)hs[0]->ev1))) return 1;
+  if (!HIP_OK(hipEventElapsedTime(&ms, (hipEvent_t)hs[0]->ev0, (hipEvent_t)hs[0]->ev1))) return 1;
+  if (ms_per_launch) *ms_per_launch = (c_float)ms / (c_float)reps;
+  return 0;
+}
+
+/* Wave timeline of ONE launch of the plugin solve: host_out[batch][8] int64 ticks of the 100 MHz device clock per instance (= wave):
+ * wave start, every global load landed, forward gather done, forward tile product done, backward tile product done, scatter done,
+ * result stores issued, 0.  Returns 2 when the handle's solve kernel carries no
+ * timeline (only the tile kernel of arrowhead patterns does).  The solve is applied to d_b like rldl_batch_solve. */
+c_int rldl_batch_trace_solve(rldl_batch *h, c_float *d_b, long long *host_out) {
+  long long *d = 0;
+  size_t bytes;
+  c_int rc = 1;
+  if (!h || !d_b || !host_out) return 1;
+  bytes = sizeof(long long) * 8 * (size_t)h->batch;
+  if (!HIP_OK(hipMalloc((void **)&d, bytes))) return RLDL_MEM_ALLOC_ERROR;
+  if (HIP_OK(hipMemsetAsync(d, 0, bytes, (hipStream_t)h->stream))) {
+    const int lr = rldl_launch_solve_trace(&h->dsym, &h->num, d_b, d, h->stream);
+    rc = lr < 0 ? 2 : (lr ? 1 : 0);
+    if (!rc && !(HIP_OK(hipMemcpyAsync(host_out, d, bytes, hipMemcpyDeviceToHost, (hipStream_t)h->stream)) &&
+                 HIP_OK(hipStreamSynchronize((hipStream_t)h->stream)))) rc = 1;
+  }
+  (void)hipFree(d);
+  return rc;
 }
 
 /* =====================================================================================

@@ -77,7 +77,7 @@ typedef struct {
   int arrow_ok, arrow_group, arrow_steps; /* arrowhead specialisation (see rldl_plan.c) */
   int arrow_vsteps, arrow_vrows;          /* virtual rows: coupling rows cut into pieces of <= vsteps entries, one piece per lane */
   int tile_ok, tile_ta, tile_tq, tile_lanes, nTi, ldTi;   /* tail inverse by register tiles (rldl_symbolic.h); ldTi = nTi rounded up to even */
-  int po_tlane, po_tmap, po_tislot;
+  int po_tlane, po_tmap, po_tislot, po_tmask, po_pinv, po_trc;
   int tile_admm_ok, tile_vslots, tile_slots, po_tpos;   /* ADMM slots of the tile kernels (rldl_symbolic.h) */
   int tile_ck[3], tile_tk, tile_sp, po_cmap, po_crow;            /* backward coupling product gathered by the owner lane */
   int arrow_g0, arrow_g;       /* index range of the tail group */
@@ -170,6 +170,7 @@ int rldl_launch_horizon_adopt(const rldl_dev_sym *So, const rldl_dev_num *No, co
                               int *d_n_reused, void *stream);
 int rldl_launch_factor_from(const rldl_dev_sym *S, const rldl_dev_num *Nn, int c_start, void *stream);
 int rldl_launch_solve(const rldl_dev_sym *S, const rldl_dev_num *Nn, double *d_b, void *stream);
+int rldl_launch_solve_trace(const rldl_dev_sym *S, const rldl_dev_num *Nn, double *d_b, long long *d_trace, void *stream);
 int rldl_launch_admm_iter(const rldl_dev_sym *S, const rldl_dev_num *Nn, const rldl_dev_admm *W, void *stream);
 int rldl_launch_bcast_rows(int batch, int len, double *dst, const double *src, void *stream);
 int rldl_launch_set_range(int batch, int ld, int start, int cnt, double *dst, const double *src, const double *s, void *stream);

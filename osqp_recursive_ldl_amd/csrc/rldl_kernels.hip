@@ -2975,6 +2975,179 @@ __global__ __launch_bounds__(256, 2) void k_tile_solve(rldl_dev_sym S, rldl_dev_
   }
 }
 
+// Round 3 form of the plugin `solve` on tile handles.  k_tile_solve above starts every wave with a chain of DEPENDENT loads
+// (slot tables -> gathered factor values, perm -> b) and holds the coupling values in registers (164 VGPRs: 12 waves per CU, so
+// 4096 instances are 1 1/3 rounds).  Here every global load is issued at wave start from addresses that need no table:
+//   * coupling values: the slots [0, nOp) of the factor row are ONE contiguous piece -> coalesced LDS-DMA (16 bytes per lane),
+//     they stay in LDS and are read where they are used (gather and scatter) through the virtual-row slot table;
+//   * Ti: slot of (register k, lane) = first slot of k + number of set bits below the lane in k's lane mask (po_tmask: scalar
+//     loads + v_mbcnt), i.e. coalesced loads without a per-lane table;
+//   * b, rho_inv in ORIGINAL order and Dinv in permuted order: plain coalesced rows; b enters x through the inverse
+//     permutation as an LDS scatter and leaves through the same addresses, so permute_x / permutet_x cost no dependent load.
+// The tables (L2-resident, shared by all instances) only feed LDS addresses and arrive under the value loads.  128 VGPRs:
+// 16 waves per CU, the whole batch of 4096 is resident at once.  Same products as k_tile_solve; the head's y_c Dinv_c enters as the
+// initial value of the scatter accumulator instead of a closing fma (last-bit differences; RLDL_SOLVE_V2=1 selects the old kernel).  TRACE: wave timeline (rldl_batch_trace_solve).
+template <int TMAX, int TG, int TA, bool TRACE, int WPE>
+__global__ __launch_bounds__(256, WPE) void k_tile_solve3(rldl_dev_sym S, rldl_dev_num Nn, double *__restrict__ b_all, int xdw, int cwp,
+                                                         long long *__restrict__ trace) {
+  typedef __attribute__((address_space(1))) const void *gptr_t;
+  typedef __attribute__((address_space(3))) void *lptr_t;
+  extern __shared__ __attribute__((aligned(16))) double sh[];
+  const int lane = threadIdx.x & (WAVE - 1), wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wpb = blockDim.x >> 6;
+  const int inst = blockIdx.x * wpb + wv;
+  if (inst >= Nn.batch) return;
+  long long *tr = TRACE ? trace + 8 * (size_t)inst : nullptr;
+  if (TRACE && lane == 0) tr[0] = wall_clock64();
+  char *shb = reinterpret_cast<char *>(sh);
+  const unsigned pws = (unsigned)(cwp + xdw + WAVE);              // doubles per wave: coupling values | x | one dummy word per lane
+  const unsigned cb = (unsigned)wv * pws * 8u, xb = cb + 8u * (unsigned)cwp, dmy = xb + 8u * (unsigned)(xdw + lane);
+  const double *Fg = Nn.F + (size_t)inst * S.ldF;
+  const int g0 = S.arrow_g0, g = S.arrow_g;
+  // Every load below is a BUFFER load: 32-bit offsets, and a lane whose offset lies past the end of its array receives 0 (a store is
+  // dropped) -- no range selects, so the compiler has nothing to turn into branches around loads.
+  const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc((void *)S.plan, 0, 4 * S.plan_words, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void *)(b_all + (size_t)inst * S.N), 0, 8 * S.N, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rD = __builtin_amdgcn_make_buffer_rsrc((void *)(Fg + S.nS), 0, 8 * S.N, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc((void *)(Nn.rho_inv + (size_t)inst * S.m), 0, S.polish ? 0 : 8 * S.m, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rTi = __builtin_amdgcn_make_buffer_rsrc((void *)(Nn.Ti + (size_t)inst * S.ldTi), 0, 8 * S.nTi, 0x00020000);
+  const unsigned l4 = 4u * (unsigned)lane, l8 = 8u * (unsigned)lane;
+  // ---- phase A: issue every load of the wave.  Tables first (L2-resident, needed first; vmcnt retires in order), then the rows
+  // of this instance: b, Dinv, the coupling values (LDS-DMA), the lane's tile of Linv. ----
+  unsigned pw[TMAX], cw[(TG + 1) / 2], mw[(TG + 1) / 2], rcw[TA];
+#pragma unroll
+  for (int t = 0; t < TMAX; t++) pw[t] = __builtin_amdgcn_raw_buffer_load_b32(rP, l4 + 4u * (unsigned)(S.po_pinv + 64 * t), 0, 0);
+#pragma unroll
+  for (int t2 = 0; t2 < (TG + 1) / 2; t2++) {
+    cw[t2] = __builtin_amdgcn_raw_buffer_load_b32(rP, l4 + 4u * (unsigned)(S.po_avcol + 64 * t2), 0, 0);
+    mw[t2] = __builtin_amdgcn_raw_buffer_load_b32(rP, l4 + 4u * (unsigned)(S.po_avmap + 64 * t2), 0, 0);
+  }
+#pragma unroll
+  for (int sx = 0; sx < TA; sx++) rcw[sx] = __builtin_amdgcn_raw_buffer_load_b32(rP, l4 + 4u * (unsigned)(S.po_trc + 64 * sx), 0, 0);
+  const unsigned tlw = __builtin_amdgcn_raw_buffer_load_b32(rP, l4 + 4u * (unsigned)S.po_tlane, 0, 0);
+  const unsigned jrw = __builtin_amdgcn_raw_buffer_load_b32(rP, l4 + 4u * (unsigned)S.po_avrow, 0, 0);
+  pv_v2u blr[TMAX], dlr[TMAX], rrr[TMAX];
+#pragma unroll
+  for (int t = 0; t < TMAX; t++) {
+    blr[t] = __builtin_amdgcn_raw_buffer_load_b64(rB, l8 + 512u * (unsigned)t, 0, 0);    // b by original index (0 past N)
+    dlr[t] = __builtin_amdgcn_raw_buffer_load_b64(rD, l8 + 512u * (unsigned)t, 0, 0);    // Dinv by permuted position
+    if (WPE < 4) rrr[t] = __builtin_amdgcn_raw_buffer_load_b64(rR, l8 + 512u * (unsigned)t - 8u * (unsigned)S.n, 0, 0);   // rho_inv of row i - n (0 for variables and when polishing)
+  }
+  const pv_v2u dtr = __builtin_amdgcn_raw_buffer_load_b64(rD, lane < g ? 8u * (unsigned)(g0 + lane) : 0xffffffffu, 0, 0);
+  {                                                               // coupling values: slots [0, nOp) of the factor row -> LDS, one coalesced stream
+    const int n2 = S.nOp >> 1;
+    double *dst = sh + (size_t)wv * pws;
+    for (int base = 0; base < n2; base += WAVE) {
+      const int i = base + lane;
+      if (i < n2) __builtin_amdgcn_global_load_lds((gptr_t)(Fg + 2 * (size_t)i), (lptr_t)(dst + 2 * (size_t)base), 16, 0, 0);
+    }
+  }
+  TileRegs<TA> T;
+  {                                                               // slot of (register k, lane) = entries of the registers before k + set bits of k's lane mask below the lane
+    sv_cptr_t tk = (sv_cptr_t)(unsigned long long)(S.plan + S.po_tmask);   // (scalar loads: the masks are uniform)
+    unsigned long long msk[TA * TA];
+#pragma unroll
+    for (int k = 0; k < TA * TA; k++) msk[k] = (unsigned long long)(unsigned)tk[2 * k] | ((unsigned long long)(unsigned)tk[2 * k + 1] << 32);
+    __builtin_amdgcn_sched_barrier(0);                            // all masks with ONE wait, not one wait per pair of registers
+    unsigned first = 0;
+#pragma unroll
+    for (int k = 0; k < TA * TA; k++) {
+      const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(msk[k] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)msk[k], 0u));
+      const pv_v2u r = __builtin_amdgcn_raw_buffer_load_b64(rTi, pv_select(msk[k], (first + rank) << 3, 0xffffffffu), 0, 0);
+      T.v[k] = __hiloint2double((int)r.y, (int)r.x);
+      first += (unsigned)__builtin_popcountll(msk[k]);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- phase B: LDS addresses from the tables; b into x through the inverse permutation ----
+  for (int j = S.N + lane; j < xdw + WAVE; j += WAVE) lds_st(shb, xb + 8u * (unsigned)j, 0.0);   // padding rows, dummy words
+  wave_sync();
+  unsigned za[TMAX];                                              // x slot of permuted position j = t * 64 + lane when j is a head position, else the dummy word
+#pragma unroll
+  for (int t = 0; t < TMAX; t++) {
+    const int j = t * WAVE + lane;
+    za[t] = j < S.N && (j < g0 || j >= g0 + g) ? xb + l8 + 512u * (unsigned)t : dmy;
+    lds_st(shb, xb + 8u * pw[t], __hiloint2double((int)blr[t].y, (int)blr[t].x));       // permute_x  qdldl_interface.c:538-541 (indices past N: 0.0 to the dummy word)
+  }
+  TileCols<TG> C, V;                                              // C: byte address of x[column] per step; V: of the step's coupling value
+#pragma unroll
+  for (int t2 = 0; t2 < (TG + 1) / 2; t2++) {
+    const bool l0 = (mw[t2] & 0xffffu) != 0xffffu, h0 = (mw[t2] >> 16) != 0xffffu;
+    C.a[t2] = (l0 ? xb + 8u * (cw[t2] & 0xffffu) : dmy) | ((h0 ? xb + 8u * (cw[t2] >> 16) : dmy) << 16);
+    V.a[t2] = (l0 ? cb + 8u * (mw[t2] & 0xffffu) : dmy) | ((h0 ? cb + 8u * (mw[t2] >> 16) : dmy) << 16);
+  }
+  TileAddr<TA> A;
+  A.act = tlw != 0xffffffffu;
+  {
+    const unsigned xt2 = (xb + 8u * (unsigned)g0) * 0x10001u;    // both halves: byte address of the tail's first entry
+#pragma unroll
+    for (int sx = 0; sx < TA; sx++) A.rc[sx] = xt2 + (rcw[sx] << 3);
+  }
+  const unsigned jra = xb + 8u * jrw;                             // (lanes without a virtual row: the table holds their dummy word)
+  const unsigned dta = lane < g ? xb + 8u * (unsigned)(g0 + lane) : dmy;
+  const double dtail = __hiloint2double((int)dtr.y, (int)dtr.x);
+  wave_sync();
+  double hd[TMAX];                                                // head entries are final after the (empty) forward pass of the head: y_c Dinv_c
+#pragma unroll
+  for (int t = 0; t < TMAX; t++) hd[t] = lds_ld(shb, za[t]) * __hiloint2double((int)dlr[t].y, (int)dlr[t].x);   // (no head position: dummy word, 0)
+  wait_dma();                                                     // the coupling values have landed
+  wave_sync();
+  if (TRACE && lane == 0) tr[1] = wall_clock64();
+  {
+    double ga[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int t = 0; t < TG; t++) {
+      const unsigned xa_ = (t & 1) ? pk_hi(C.a[t >> 1]) : pk_lo(C.a[t >> 1]), va_ = (t & 1) ? pk_hi(V.a[t >> 1]) : pk_lo(V.a[t >> 1]);
+      ga[t % 3] = fma(-lds_ld(shb, va_), lds_ld(shb, xa_), ga[t % 3]);
+      if (t % 6 == 5) __builtin_amdgcn_sched_barrier(0);         // at most 12 reads in flight: their values need registers
+    }
+    wave_sync();                                                  // all reads of the head values are done
+    lds_add(shb, jra, (ga[0] + ga[1]) + ga[2]);
+#pragma unroll
+    for (int t = 0; t < TMAX; t++) lds_st(shb, za[t], za[t] != dmy ? hd[t] : 0.0);   // head slots become the accumulators of x_c = y_c Dinv_c - sum_r L(r, c) x_r
+    wave_sync();
+  }
+  if (TRACE && lane == 0) tr[2] = wall_clock64();
+  tile_fwd<TA>(T, shb, A);
+  if (TRACE && lane == 0) tr[3] = wall_clock64();
+  lds_st(shb, dta, lds_ld(shb, dta) * dtail);                    // D^-1
+  wave_sync();
+  tile_bwd<TA>(T, shb, A);
+  if (TRACE && lane == 0) tr[4] = wall_clock64();
+  // b (again: an L2 hit), rho_inv and the inverse permutation for the epilogue are fetched here, under the scatter, instead of living
+  // in registers across the products (opaque offsets: the compiler must not merge these loads with the ones at wave start)
+  if (WPE >= 4) {                                                 // (with 168 registers they simply stay: rrr below was loaded at wave start)
+    unsigned o4 = l4, o8 = l8;
+    asm volatile("" : "+v"(o4), "+v"(o8));
+#pragma unroll
+    for (int t = 0; t < TMAX; t++) {
+      pw[t] = __builtin_amdgcn_raw_buffer_load_b32(rP, o4 + 4u * (unsigned)(S.po_pinv + 64 * t), 0, 0);
+      blr[t] = __builtin_amdgcn_raw_buffer_load_b64(rB, o8 + 512u * (unsigned)t, 0, 0);
+      rrr[t] = __builtin_amdgcn_raw_buffer_load_b64(rR, o8 + 512u * (unsigned)t - 8u * (unsigned)S.n, 0, 0);   // rho_inv of row i - n (0 for variables and when polishing)
+    }
+  }
+  {
+    const double xr = -lds_ld(shb, jra);
+#pragma unroll
+    for (int t = 0; t < TG; t++) {                               // transposed gather: -L(r, c) x_r into the head columns
+      const unsigned xa_ = (t & 1) ? pk_hi(C.a[t >> 1]) : pk_lo(C.a[t >> 1]), va_ = (t & 1) ? pk_hi(V.a[t >> 1]) : pk_lo(V.a[t >> 1]);
+      lds_add(shb, xa_, lds_ld(shb, va_) * xr);
+    }
+    wave_sync();
+  }
+  if (TRACE && lane == 0) tr[5] = wall_clock64();
+#pragma unroll
+  for (int t = 0; t < TMAX; t++) {                                // permutet_x + the z~ epilogue, coalesced in original order (stores past N are dropped)
+    const int i = t * WAVE + lane;
+    const double xv = lds_ld(shb, xb + 8u * pw[t]);
+    const double bv = __hiloint2double((int)blr[t].y, (int)blr[t].x), rv = __hiloint2double((int)rrr[t].y, (int)rrr[t].x);
+    const double out = (S.polish || i < S.n) ? xv : fma(rv, xv, bv);      // qdldl_interface.c:568-579
+    pv_v2u o;
+    o.x = (unsigned)__double2loint(out); o.y = (unsigned)__double2hiint(out);
+    __builtin_amdgcn_raw_buffer_store_b64(o, rB, l8 + 512u * (unsigned)t, 0, 0);
+  }
+  if (TRACE && lane == 0) tr[6] = wall_clock64();
+}
+
 // `iters` fused ADMM iterations per launch (as k_arrow_admm).  Everything the loop touches is on chip: both copies of the
 // coupling values, the tile of Linv, the packed LDS addresses, x / z / y / q and rho_inv in registers, x~ and the other
 // per-slot constants in LDS -- no global memory access inside the loop and no branch besides the tile lanes' predicate.
@@ -3460,7 +3633,42 @@ static bool tile_admm_usable(const rldl_dev_sym *S, const rldl_dev_num *Nn, cons
     case 7: CALL(7); break;                   \
     default: return -1;                       \
   }
+// round-3 solve kernel (k_tile_solve3): coupling values staged in LDS (cwp doubles per wave, whole 64-lane DMA pieces); every LDS
+// byte address of the workgroup must fit 16 bits
+static int tile_solve3_cwp(const rldl_dev_sym *S) { return ((S->nOp + 127) / 128) * 128; }
+static bool tile_solve3_usable(const rldl_dev_sym *S) {
+  static const int off = getenv("RLDL_SOLVE_V2") ? 1 : 0;
+  return !off && S->po_tmask > 0 && sizeof(double) * (size_t)(tile_solve3_cwp(S) + tile_per_wave(S) + WAVE) * TILE_WPB < 65536;
+}
+static int launch_tile_solve3(const rldl_dev_sym *S, const rldl_dev_num *Nn, double *d_b, long long *d_trace, void *stream) {
+  const int pw = tile_per_wave(S), cwp = tile_solve3_cwp(S), grid = (Nn->batch + TILE_WPB - 1) / TILE_WPB;
+  const size_t lds = sizeof(double) * (size_t)(cwp + pw + WAVE) * TILE_WPB;
+  // waves per SIMD: 4 (128 registers, the whole batch of 4096 resident at once) where the tile and the addresses fit, else 3 / 2
+  static const int wpe_env = getenv("RLDL_SOLVE_WPE") ? atoi(getenv("RLDL_SOLVE_WPE")) : 0;
+#define TS3W(TG, TA, TR, W) hipLaunchKernelGGL((k_tile_solve3<3, TG, TA, TR, W>), dim3(grid), dim3(TILE_WPB * WAVE), lds, (hipStream_t)stream, *S, *Nn, d_b, pw, cwp, d_trace)
+#define TS3(TG, TA) do { const int w0 = (TA <= 5 && TG <= 18) ? 4 : (TA <= 5 ? 3 : 2), w = wpe_env >= 2 && wpe_env < w0 ? wpe_env : w0; \
+    if (w == 4 && w0 == 4) { if (d_trace) TS3W(TG, TA, true, ((TA <= 5 && TG <= 18) ? 4 : 3)); else TS3W(TG, TA, false, ((TA <= 5 && TG <= 18) ? 4 : 3)); } \
+    else if (w == 3 && w0 >= 3) { if (d_trace) TS3W(TG, TA, true, ((TA <= 5) ? 3 : 2)); else TS3W(TG, TA, false, ((TA <= 5) ? 3 : 2)); } \
+    else { if (d_trace) TS3W(TG, TA, true, 2); else TS3W(TG, TA, false, 2); } } while (0)
+  if (S->arrow_vsteps <= 12) {
+#define C(TA) TS3(12, TA)
+    TILE_TA_SWITCH(C)
+#undef C
+  } else if (S->arrow_vsteps <= 18) {
+#define C(TA) TS3(18, TA)
+    TILE_TA_SWITCH(C)
+#undef C
+  } else {
+#define C(TA) TS3(24, TA)
+    TILE_TA_SWITCH(C)
+#undef C
+  }
+#undef TS3
+#undef TS3W
+  return launch_status();
+}
 static int launch_tile_solve(const rldl_dev_sym *S, const rldl_dev_num *Nn, double *d_b, void *stream) {
+  if (tile_solve3_usable(S)) return launch_tile_solve3(S, Nn, d_b, nullptr, stream);
   const int pw = tile_per_wave(S), grid = (Nn->batch + TILE_WPB - 1) / TILE_WPB;
   static const size_t pad = getenv("RLDL_SOLVE_LDS_PAD") ? (size_t)atol(getenv("RLDL_SOLVE_LDS_PAD")) : 0;   // occupancy experiments: LDS bytes per workgroup
   const size_t lds0 = sizeof(double) * (size_t)(pw + WAVE) * TILE_WPB, lds = pad > lds0 ? pad : lds0;
@@ -3678,6 +3886,14 @@ extern "C" int rldl_launch_solve(const rldl_dev_sym *S, const rldl_dev_num *Nn, 
     hipLaunchKernelGGL(k_solve<false>, dim3(Nn->batch), dim3(WAVE), sizeof(double) * (size_t)S->N, (hipStream_t)stream, *S,
                        *Nn, d_b);
   return launch_status();
+}
+
+// wave timeline of one launch of the plugin solve (round-3 tile kernel only): d_trace[batch][8] s_memrealtime ticks (100 MHz):
+// wave start, all loads landed, forward gather done, forward product done, backward product done, scatter done, stores issued, 0.  -1: this handle does not run that kernel.
+extern "C" int rldl_launch_solve_trace(const rldl_dev_sym *S, const rldl_dev_num *Nn, double *d_b, long long *d_trace, void *stream) {
+  if (Nn->batch <= 0 || !d_trace) return -1;
+  if (!(arrow_usable(S) && tile_usable(S, Nn) && tile_solve3_usable(S))) return -1;
+  return launch_tile_solve3(S, Nn, d_b, d_trace, stream);
 }
 
 // `iters` ADMM iterations of every active instance.  The arrowhead kernel runs them inside one launch with the factor

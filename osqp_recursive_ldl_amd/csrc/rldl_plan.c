@@ -187,7 +187,7 @@ int rldl_plan_build(rldl_symbolic *s) {
   s->po_avrow = words; words += s->arrow_ok ? 64 : 0;                                 /* row (permuted index) of the lane's piece */
   /* tail inverse by register tiles (see rldl_symbolic.h): tile size from the set the kernels are compiled for */
   s->tile_ok = 0; s->tile_ta = 0; s->tile_tq = 0; s->tile_lanes = 0; s->nTi = 0;
-  s->po_tlane = s->po_tmap = s->po_tislot = 0;
+  s->po_tlane = s->po_tmap = s->po_tislot = s->po_tmask = s->po_pinv = s->po_trc = 0;
   if (s->arrow_ok && coloff[gstart[arrow_k]] == nOp) {
     static const int tas[4] = {2, 3, 5, 7};
     const int g = gstart[arrow_k + 1] - gstart[arrow_k];
@@ -201,6 +201,10 @@ int rldl_plan_build(rldl_symbolic *s) {
       s->po_tlane = words; words += 64;
       s->po_tmap = words; words += ((a * a + 1) / 2) * 64;
       s->po_tislot = words; words += g * 32;
+      words = (words + 3) & ~3;                                /* (16-byte aligned: the kernel reads a record with one scalar load) */
+      s->po_tmask = words; words += ((a * a * 2 + 3) & ~3);
+      s->po_pinv = words; words += 3 * 64;
+      s->po_trc = words; words += a * 64;
       s->tile_vslots = (s->n + 63) / 64; s->tile_slots = s->tile_vslots + (s->m + 63) / 64;
       s->tile_admm_ok = s->tile_slots <= 3 && !s->polish;
       s->po_tpos = words; words += 3 * 64;
@@ -403,6 +407,37 @@ int rldl_plan_build(rldl_symbolic *s) {
       }
     }
     if (slot != s->nTi) { rc = -2; goto out; }                /* cannot happen: every strictly lower entry lies in exactly one tile */
+    {                                                         /* the same map without a per-lane table: the 64-bit lane mask of every register k (lo, hi words);
+                                                               * slot(k, lane) = (entries of the registers before k) + (set mask bits below the lane) -- Ti is in (k, lane) order */
+      unsigned *tk = (unsigned *)(blob + s->po_tmask);
+      int first = 0;
+      for (kk = 0; kk < a * a; kk++) {
+        unsigned long long msk = 0;
+        int cnt = 0;
+        for (l = 0; l < nl; l++) {
+          const unsigned w = tm[(kk >> 1) * 64 + l], sl = (kk & 1) ? w >> 16 : w & 0xffffu;
+          if (sl == 0xffffu) continue;
+          if ((int)sl != first + cnt) { rc = -2; goto out; }  /* cannot happen: slots were handed out in (k, lane) order */
+          msk |= 1ull << l; cnt++;
+        }
+        tk[2 * kk] = (unsigned)msk; tk[2 * kk + 1] = (unsigned)(msk >> 32);
+        first += cnt;
+      }
+      {                                                       /* x slot (in doubles from the wave's x[0]) of original index i = its permuted position; indices
+                                                               * past N point at the lane's dummy word (xdw + lane, xdw as in launch geometry: tile_per_wave) */
+        const int need = gstart[arrow_k] + a * tq, xdw = ((need > N ? need : N) + 1) & ~1;
+        for (i = 0; i < 3 * 64; i++) blob[s->po_pinv + i] = xdw + (i & 63);
+        if (N <= 3 * 64) for (i = 0; i < N; i++) blob[s->po_pinv + s->perm[i]] = i;
+        if (s->arrow_ok) for (l = s->arrow_vrows; l < 64; l++) blob[s->po_avrow + l] = xdw + l;   /* lanes without a virtual row: their dummy word */
+      }
+      {                                                       /* tile addresses without arithmetic: word s of the lane = (rotated row s | rotated column s << 16), local to the tail */
+        unsigned *rc = (unsigned *)(blob + s->po_trc);
+        int sidx;
+        for (sidx = 0; sidx < a; sidx++)
+          for (l = 0; l < 64; l++)
+            rc[sidx * 64 + l] = l < nl ? (unsigned)(a * tI[l] + (sidx + tJ[l]) % a) | ((unsigned)(a * tJ[l] + (sidx + tI[l]) % a) << 16) : 0u;
+      }
+    }
     {                                                         /* ADMM slots: variables first, then constraints; inside a kind by decreasing
                                                                * number of coupling entries in the position's column (ties: ascending position) */
       int *tp = blob + s->po_tpos;

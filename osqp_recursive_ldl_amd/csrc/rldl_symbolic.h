@@ -66,9 +66,14 @@ typedef struct {
    * order, structural zeros (diagonal tiles, rows >= g) are not stored.
    *   po_tlane  [64]                 I | J << 8, 0xffffffff for lanes without a tile
    *   po_tmap   [ceil(ta^2 / 2)][64] slot(k even) | slot(k odd) << 16, 0xffff = structural zero
-   *   po_tislot [g][32]              u16 [g][64]: slot of Linv(i, c) for lane c, 0xffff where c >= i (inverse kernel) */
+   *   po_tislot [g][32]              u16 [g][64]: slot of Linv(i, c) for lane c, 0xffff where c >= i (inverse kernel)
+   *   po_tmask  [ta^2][2]            po_tmap without a per-lane table: the 64-bit lane mask of register k (lo, hi); the slot of (k, lane) is
+   *                                  (entries of the registers before k) + (mask bits below the lane); 16-byte aligned
+   *   po_pinv   [3][64]              permuted position of every original index (inverse of perm); entries past N = xdw + lane, the
+   *                                  lane's dummy word in the tile kernels' LDS geometry (po_avrow is padded the same way)
+   *   po_trc    [ta][64]             word s of the lane = rotated row s | rotated column s << 16 of its tile, local to the tail group */
   int tile_ok, tile_ta, tile_tq, tile_lanes, nTi;
-  int po_tlane, po_tmap, po_tislot;
+  int po_tlane, po_tmap, po_tislot, po_tmask, po_pinv, po_trc;
   /* ADMM slots of the tile kernels: the permuted positions are dealt to (slot, lane) so that a slot holds variables only or
    * constraints only (uniform code per slot, no per-lane role test): po_tpos [3][64] = permuted position or -1;
    * tile_vslots = number of leading variable slots, tile_slots = slots in use (<= 3; more -> tile_admm_ok = 0) */

@@ -235,6 +235,28 @@ class BatchLinsys:
             raise RuntimeError("time_solve failed")
         return ms.value
 
+    @staticmethod
+    def time_solve_rotating(handles, bs, reps=200):
+        """ms per launch of the solve kernel over a rotation of handles (same stream) and right-hand sides: with a combined working
+        set beyond the Infinity Cache every launch streams its factor rows from HBM."""
+        ms = _lib.c_float(0)
+        hs = (C.c_void_p * len(handles))(*[h.h for h in handles])
+        ps = (C.c_void_p * len(bs))(*[C.c_void_p(b.data_ptr()) for b in bs])
+        if _lib.lib().rldl_batch_time_solve_rotating(hs, ps, len(handles), int(reps), C.byref(ms)):
+            raise RuntimeError("time_solve_rotating failed")
+        return ms.value
+
+    def trace_solve(self, b):
+        """Wave timeline of one launch of the solve kernel: int64 [batch, 8] ticks of the 100 MHz device clock (wave start, loads
+        landed, forward gather / forward product / backward product / scatter done, stores issued, 0); None when the handle's kernel carries no timeline.  Solves b in place."""
+        out = np.zeros((self.batch, 8), np.int64)
+        rc = _lib.lib().rldl_batch_trace_solve(self.h, _dptr(b), out.ctypes.data_as(C.c_void_p))
+        if rc == 2:
+            return None
+        if rc:
+            raise RuntimeError("trace_solve failed")
+        return out
+
     def free(self):
         if getattr(self, "h", None) and self._owned:
             _lib.lib().rldl_batch_free(self.h)
