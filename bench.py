@@ -21,7 +21,8 @@ max-over-ranks time.
 
 Rank 0 prints ONE JSON line with
   roofline        the kernel the north-star names: the batched permuted tri-solve (plugin `solve`), HBM-bound, timed live with
-                  HIP events on its own stream (rldl_batch_time_solve) -- outside the timed steps;
+                  HIP events on its own stream over a rotation of handles (every launch streams from HBM) -- outside the timed
+                  steps; roofline_resident = the same handle back to back (rows served by the Infinity Cache);
   roofline_fused  the kernel that dominates a step: the resident fused ADMM-iteration kernel, bound by the CU's LDS array;
   cpu_baseline    (N = 1) the CPU oracle = scalar port of the reference path, -O2 and -Ofast builds, one core and all usable
                   host cores, on a bounded sample of the same workload.
@@ -271,11 +272,29 @@ def main(argv=None):
     iters_per_launch = n_iters / n_launches
 
     # ---- roofline of the north-star kernel: the plugin `solve` (batched permuted tri-solve) on this rank's batch ----
+    # Two live timings (HIP events on the kernel's stream, 200 launches each, best of three):
+    #   hbm      a ROTATION of ROT handles with their own factor / tile arrays and right-hand sides (ROT x working set > the 256 MB
+    #            Infinity Cache, cyclic order): every launch streams its rows from HBM -- the figure `roofline` reports;
+    #   resident the same handle back to back (what an ADMM loop through the plugin API does: one factorisation, one solve per
+    #            iteration): the 82 MB working set stays in the Infinity Cache between launches -- `roofline_resident`.
     ls = w.linsys()
     rhs = torch.randn((B, N), dtype=torch.float64, device=dev)
     ls.time_solve(rhs, reps=20)                              # warm-up
-    solve_ms = min(ls.time_solve(rhs, reps=200) for _ in range(3))   # HIP events on the kernel's stream, 200 launches each
+    solve_ms = min(ls.time_solve(rhs, reps=200) for _ in range(3))
     solve_gbs = tri_bytes * B / (solve_ms * 1e-3) / 1e9
+    ROT = max(2, int(np.ceil(3 * 256e6 / (tri_bytes * B)))) if tri_bytes * B < 512e6 else 1
+    hbm_ms = solve_ms
+    if ROT > 1:
+        rho0 = torch.full((B, m), settings["rho"], dtype=torch.float64, device=dev)
+        extra = [R.BatchLinsys(wl.P_pattern, wl.A_pattern, shard.dPx * shard.fP[k % len(shard.fP)] if shard.fP else shard.dPx,
+                               shard.dAx * shard.fA[k % len(shard.fA)] if shard.fA else shard.dAx, settings["sigma"], rho0)
+                 for k in range(ROT - 1)]
+        hs, bs = [ls] + extra, [rhs] + [torch.randn_like(rhs) for _ in extra]
+        R.BatchLinsys.time_solve_rotating(hs, bs, reps=4 * ROT)
+        hbm_ms = min(R.BatchLinsys.time_solve_rotating(hs, bs, reps=40 * ROT) for _ in range(3))
+        for h in extra:
+            h.free()
+    hbm_gbs = tri_bytes * B / (hbm_ms * 1e-3) / 1e9
     out = {
         "metric": "QP solves/sec (batch) + ADMM iters/sec, n=50 m=100 fp64 batch=4096",
         "value": value, "unit": "QP solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -292,14 +311,20 @@ def main(argv=None):
                    "per_rank_seconds": per_rank, "gather_ms": gather_ms,
                    "collective": ("RCCL all_gather_into_tensor of the result records inside every step (backend %s, world %d%s)"
                                   % (dist.get_backend(), world, ", --force-dist" if args.force_dist else "")) if coll else None},
-        "roofline": {"bound": "hbm", "kernel": "batched permuted tri-solve + z~ epilogue (plugin `solve`: k_tile_solve on arrowhead "
-                                               "patterns, else k_arrow_solve / k_plan_solve), rldl_batch_time_solve",
-                     "achieved": solve_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": solve_gbs / HBM_PEAK_GBS, "traffic": None,
-                     "bytes_per_instance": tri_bytes, "instances_per_launch": B, "kernel_us": 1e3 * solve_ms,
-                     "note": "achieved = SURVEY 8d algorithmic bytes 8 (nnzL + 3 N + m) x instances / launch duration (HIP events, "
-                             "200 back-to-back launches on the handle's stream); every launch re-reads every factor row "
-                             "(working set %d MB: it can stay in the 256 MB Infinity Cache between launches)"
-                             % (tri_bytes * B // 1000000)},
+        "roofline": {"bound": "hbm", "kernel": "batched permuted tri-solve + z~ epilogue (plugin `solve`: k_tile_solve3 on arrowhead "
+                                               "patterns, else k_arrow_solve / k_plan_solve), rldl_batch_time_solve_rotating",
+                     "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_gbs / HBM_PEAK_GBS, "traffic": None,
+                     "bytes_per_instance": tri_bytes, "instances_per_launch": B, "kernel_us": 1e3 * hbm_ms,
+                     "rotation": ROT, "rotation_working_set_MB": ROT * tri_bytes * B / 1e6,
+                     "note": "achieved = SURVEY 8d algorithmic bytes 8 (nnzL + 3 N + m) x instances / launch duration (HIP events over "
+                             "%d launches on the handles' stream); the launches cycle through %d handles with their own factor / tile / "
+                             "right-hand-side arrays, %d MB together, so no launch finds its rows in the 256 MB Infinity Cache: the rows come "
+                             "from HBM" % (40 * ROT, ROT, ROT * tri_bytes * B // 1000000)},
+        "roofline_resident": {"bound": "hbm peak as yardstick; the rows are served by the Infinity Cache",
+                              "kernel": "the same kernel, the same handle 200 times back to back (an ADMM loop through the plugin API: one "
+                                        "factorisation, one solve per iteration), rldl_batch_time_solve",
+                              "achieved": solve_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": solve_gbs / HBM_PEAK_GBS,
+                              "kernel_us": 1e3 * solve_ms, "working_set_MB": tri_bytes * B / 1e6},
     }
     # the kernel that dominates a step: the resident fused iteration kernel.  Its roof is the CU's LDS array (x~ travels
     # between lanes through LDS; the factor stays in registers): LDS-array cycles per wave-iteration come from the committed
@@ -318,10 +343,10 @@ def main(argv=None):
                      note="frac = LDS-array busy cycles / (256 CUs x 2.4 GHz x launch duration): a lower bound of the busy fraction "
                           "(the chip clocks below 2.4 GHz under load)")
     out["roofline_fused"] = fused
-    tr = load_profile("r2_pmc_traffic_solve.json")
-    if tr and B == tr.get("batch") and tr.get("algorithmic_bytes_per_launch") == tri_bytes * B:
+    tr = load_profile("r3_pmc_traffic_solve.json")
+    if tr and B == tr.get("batch") and tr.get("algorithmic_bytes_per_launch") == tri_bytes * B and "tile_solve3" in tr.get("kernel", ""):
         out["roofline"]["traffic"] = tr["traffic_bytes_per_launch"]
-        out["roofline"]["traffic_source"] = "from_file: profiles/r2_pmc_traffic_solve.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+        out["roofline"]["traffic_source"] = "from_file: profiles/r3_pmc_traffic_solve.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
     status = res["status"]
     out["config"]["status_counts"] = {str(int(k)): int((status == k).sum()) for k in torch.unique(status)}
 

@@ -521,7 +521,8 @@ c_int rldl_batch_time_solve_rotating(rldl_batch **hs, c_float **d_b, c_int count
 /* Wave timeline of ONE launch of the plugin solve: host_out[batch][8] int64 ticks of the 100 MHz device clock per instance (= wave):
  * wave start, every global load landed, forward gather done, forward tile product done, backward tile product done, scatter done,
  * result stores issued, 0.  Returns 2 when the handle's solve kernel carries no
- * timeline (only the tile kernel of arrowhead patterns does).  The solve is applied to d_b like rldl_batch_solve. */
+ * timeline (only the tile kernel of arrowhead patterns does).  The traced launch is the second of two
+ * back-to-back launches (warm instruction cache), so d_b is solved in place TWICE: pass a scratch right-hand side. */
 c_int rldl_batch_trace_solve(rldl_batch *h, c_float *d_b, long long *host_out) {
   long long *d = 0;
   size_t bytes;
@@ -530,7 +531,8 @@ c_int rldl_batch_trace_solve(rldl_batch *h, c_float *d_b, long long *host_out) {
   bytes = sizeof(long long) * 8 * (size_t)h->batch;
   if (!HIP_OK(hipMalloc((void **)&d, bytes))) return RLDL_MEM_ALLOC_ERROR;
   if (HIP_OK(hipMemsetAsync(d, 0, bytes, (hipStream_t)h->stream))) {
-    const int lr = rldl_launch_solve_trace(&h->dsym, &h->num, d_b, d, h->stream);
+    int lr = rldl_launch_solve_trace(&h->dsym, &h->num, d_b, d, h->stream);   /* (first launch: instruction cache warm-up; the stamps of the second stay) */
+    if (lr == 0) lr = rldl_launch_solve_trace(&h->dsym, &h->num, d_b, d, h->stream);
     rc = lr < 0 ? 2 : (lr ? 1 : 0);
     if (!rc && !(HIP_OK(hipMemcpyAsync(host_out, d, bytes, hipMemcpyDeviceToHost, (hipStream_t)h->stream)) &&
                  HIP_OK(hipStreamSynchronize((hipStream_t)h->stream)))) rc = 1;

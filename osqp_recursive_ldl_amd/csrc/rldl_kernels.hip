@@ -2984,13 +2984,13 @@ __global__ __launch_bounds__(256, 2) void k_tile_solve(rldl_dev_sym S, rldl_dev_
 //     loads + v_mbcnt), i.e. coalesced loads without a per-lane table;
 //   * b, rho_inv in ORIGINAL order and Dinv in permuted order: plain coalesced rows; b enters x through the inverse
 //     permutation as an LDS scatter and leaves through the same addresses, so permute_x / permutet_x cost no dependent load.
-// The tables (L2-resident, shared by all instances) only feed LDS addresses and arrive under the value loads.  128 VGPRs:
-// 16 waves per CU, the whole batch of 4096 is resident at once.  Same products as k_tile_solve; the head's y_c Dinv_c enters as the
+// The tables (L2-resident, shared by all instances) only feed LDS addresses and arrive under the value loads.  The coupling values
+// move from LDS to registers once they have landed (a variant that left them in LDS to fit 128 registers / 16 waves per CU spent
+// 0.9 us per wave in each of the gather and the scatter on dependent LDS round trips and was no faster: DESIGN 7.1).  Same products as k_tile_solve; the head's y_c Dinv_c enters as the
 // initial value of the scatter accumulator instead of a closing fma (last-bit differences; RLDL_SOLVE_V2=1 selects the old kernel).  TRACE: wave timeline (rldl_batch_trace_solve).
-template <int TMAX, int TG, int TA, bool TRACE, int WPE>
-__global__ __launch_bounds__(256, WPE) void k_tile_solve3(rldl_dev_sym S, rldl_dev_num Nn, double *__restrict__ b_all, int xdw, int cwp,
+template <int TMAX, int TG, int TA, bool TRACE>
+__global__ __launch_bounds__(256, (TA <= 5 && TG <= 18) ? 3 : 2) void k_tile_solve3(rldl_dev_sym S, rldl_dev_num Nn, double *__restrict__ b_all, int xdw, int cwp,
                                                          long long *__restrict__ trace) {
-  typedef __attribute__((address_space(1))) const void *gptr_t;
   typedef __attribute__((address_space(3))) void *lptr_t;
   extern __shared__ __attribute__((aligned(16))) double sh[];
   const int lane = threadIdx.x & (WAVE - 1), wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wpb = blockDim.x >> 6;
@@ -3030,16 +3030,15 @@ __global__ __launch_bounds__(256, WPE) void k_tile_solve3(rldl_dev_sym S, rldl_d
   for (int t = 0; t < TMAX; t++) {
     blr[t] = __builtin_amdgcn_raw_buffer_load_b64(rB, l8 + 512u * (unsigned)t, 0, 0);    // b by original index (0 past N)
     dlr[t] = __builtin_amdgcn_raw_buffer_load_b64(rD, l8 + 512u * (unsigned)t, 0, 0);    // Dinv by permuted position
-    if (WPE < 4) rrr[t] = __builtin_amdgcn_raw_buffer_load_b64(rR, l8 + 512u * (unsigned)t - 8u * (unsigned)S.n, 0, 0);   // rho_inv of row i - n (0 for variables and when polishing)
+    rrr[t] = __builtin_amdgcn_raw_buffer_load_b64(rR, l8 + 512u * (unsigned)t - 8u * (unsigned)S.n, 0, 0);   // rho_inv of row i - n (0 for variables and when polishing)
   }
   const pv_v2u dtr = __builtin_amdgcn_raw_buffer_load_b64(rD, lane < g ? 8u * (unsigned)(g0 + lane) : 0xffffffffu, 0, 0);
-  {                                                               // coupling values: slots [0, nOp) of the factor row -> LDS, one coalesced stream
-    const int n2 = S.nOp >> 1;
-    double *dst = sh + (size_t)wv * pws;
-    for (int base = 0; base < n2; base += WAVE) {
-      const int i = base + lane;
-      if (i < n2) __builtin_amdgcn_global_load_lds((gptr_t)(Fg + 2 * (size_t)i), (lptr_t)(dst + 2 * (size_t)base), 16, 0, 0);
-    }
+  {                                                               // coupling values: slots [0, nOp) of the factor row -> LDS, one coalesced stream of
+    const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc((void *)Fg, 0, 8 * S.nOp, 0x00020000);   // 1 KB pieces (lanes past the end write 0.0 into the padding)
+    lptr_t dst = (lptr_t)(sh + (size_t)wv * pws);
+    const unsigned l16 = 16u * (unsigned)lane;
+    for (int pc = 0; pc < cwp; pc += 128)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rC, (lptr_t)((__attribute__((address_space(3))) double *)dst + pc), 16, l16, 8 * pc, 0, 0);
   }
   TileRegs<TA> T;
   {                                                               // slot of (register k, lane) = entries of the registers before k + set bits of k's lane mask below the lane
@@ -3058,6 +3057,7 @@ __global__ __launch_bounds__(256, WPE) void k_tile_solve3(rldl_dev_sym S, rldl_d
     }
   }
   __builtin_amdgcn_sched_barrier(0);
+  if (TRACE && lane == 0) tr[7] = wall_clock64();                 // every load is issued
   // ---- phase B: LDS addresses from the tables; b into x through the inverse permutation ----
   for (int j = S.N + lane; j < xdw + WAVE; j += WAVE) lds_st(shb, xb + 8u * (unsigned)j, 0.0);   // padding rows, dummy words
   wave_sync();
@@ -3092,13 +3092,15 @@ __global__ __launch_bounds__(256, WPE) void k_tile_solve3(rldl_dev_sym S, rldl_d
   wait_dma();                                                     // the coupling values have landed
   wave_sync();
   if (TRACE && lane == 0) tr[1] = wall_clock64();
+  ArrowRegs<TG> R;                                                // the coupling values of the lane's virtual row: LDS -> registers, all reads in flight at once
+#pragma unroll
+  for (int t = 0; t < TG; t++) R.v[t] = lds_ld(shb, (t & 1) ? pk_hi(V.a[t >> 1]) : pk_lo(V.a[t >> 1]));
   {
     double ga[3] = {0.0, 0.0, 0.0};
 #pragma unroll
     for (int t = 0; t < TG; t++) {
-      const unsigned xa_ = (t & 1) ? pk_hi(C.a[t >> 1]) : pk_lo(C.a[t >> 1]), va_ = (t & 1) ? pk_hi(V.a[t >> 1]) : pk_lo(V.a[t >> 1]);
-      ga[t % 3] = fma(-lds_ld(shb, va_), lds_ld(shb, xa_), ga[t % 3]);
-      if (t % 6 == 5) __builtin_amdgcn_sched_barrier(0);         // at most 12 reads in flight: their values need registers
+      ga[t % 3] = fma(-R.v[t], lds_ld(shb, (t & 1) ? pk_hi(C.a[t >> 1]) : pk_lo(C.a[t >> 1])), ga[t % 3]);
+      if (t % 9 == 8) __builtin_amdgcn_sched_barrier(0);         // at most 9 reads in flight: their values need registers
     }
     wave_sync();                                                  // all reads of the head values are done
     lds_add(shb, jra, (ga[0] + ga[1]) + ga[2]);
@@ -3113,25 +3115,11 @@ __global__ __launch_bounds__(256, WPE) void k_tile_solve3(rldl_dev_sym S, rldl_d
   wave_sync();
   tile_bwd<TA>(T, shb, A);
   if (TRACE && lane == 0) tr[4] = wall_clock64();
-  // b (again: an L2 hit), rho_inv and the inverse permutation for the epilogue are fetched here, under the scatter, instead of living
-  // in registers across the products (opaque offsets: the compiler must not merge these loads with the ones at wave start)
-  if (WPE >= 4) {                                                 // (with 168 registers they simply stay: rrr below was loaded at wave start)
-    unsigned o4 = l4, o8 = l8;
-    asm volatile("" : "+v"(o4), "+v"(o8));
-#pragma unroll
-    for (int t = 0; t < TMAX; t++) {
-      pw[t] = __builtin_amdgcn_raw_buffer_load_b32(rP, o4 + 4u * (unsigned)(S.po_pinv + 64 * t), 0, 0);
-      blr[t] = __builtin_amdgcn_raw_buffer_load_b64(rB, o8 + 512u * (unsigned)t, 0, 0);
-      rrr[t] = __builtin_amdgcn_raw_buffer_load_b64(rR, o8 + 512u * (unsigned)t - 8u * (unsigned)S.n, 0, 0);   // rho_inv of row i - n (0 for variables and when polishing)
-    }
-  }
   {
     const double xr = -lds_ld(shb, jra);
 #pragma unroll
-    for (int t = 0; t < TG; t++) {                               // transposed gather: -L(r, c) x_r into the head columns
-      const unsigned xa_ = (t & 1) ? pk_hi(C.a[t >> 1]) : pk_lo(C.a[t >> 1]), va_ = (t & 1) ? pk_hi(V.a[t >> 1]) : pk_lo(V.a[t >> 1]);
-      lds_add(shb, xa_, lds_ld(shb, va_) * xr);
-    }
+    for (int t = 0; t < TG; t++)                                 // transposed gather: -L(r, c) x_r into the head columns
+      lds_add(shb, (t & 1) ? pk_hi(C.a[t >> 1]) : pk_lo(C.a[t >> 1]), R.v[t] * xr);
     wave_sync();
   }
   if (TRACE && lane == 0) tr[5] = wall_clock64();
@@ -3643,13 +3631,8 @@ static bool tile_solve3_usable(const rldl_dev_sym *S) {
 static int launch_tile_solve3(const rldl_dev_sym *S, const rldl_dev_num *Nn, double *d_b, long long *d_trace, void *stream) {
   const int pw = tile_per_wave(S), cwp = tile_solve3_cwp(S), grid = (Nn->batch + TILE_WPB - 1) / TILE_WPB;
   const size_t lds = sizeof(double) * (size_t)(cwp + pw + WAVE) * TILE_WPB;
-  // waves per SIMD: 4 (128 registers, the whole batch of 4096 resident at once) where the tile and the addresses fit, else 3 / 2
-  static const int wpe_env = getenv("RLDL_SOLVE_WPE") ? atoi(getenv("RLDL_SOLVE_WPE")) : 0;
-#define TS3W(TG, TA, TR, W) hipLaunchKernelGGL((k_tile_solve3<3, TG, TA, TR, W>), dim3(grid), dim3(TILE_WPB * WAVE), lds, (hipStream_t)stream, *S, *Nn, d_b, pw, cwp, d_trace)
-#define TS3(TG, TA) do { const int w0 = (TA <= 5 && TG <= 18) ? 4 : (TA <= 5 ? 3 : 2), w = wpe_env >= 2 && wpe_env < w0 ? wpe_env : w0; \
-    if (w == 4 && w0 == 4) { if (d_trace) TS3W(TG, TA, true, ((TA <= 5 && TG <= 18) ? 4 : 3)); else TS3W(TG, TA, false, ((TA <= 5 && TG <= 18) ? 4 : 3)); } \
-    else if (w == 3 && w0 >= 3) { if (d_trace) TS3W(TG, TA, true, ((TA <= 5) ? 3 : 2)); else TS3W(TG, TA, false, ((TA <= 5) ? 3 : 2)); } \
-    else { if (d_trace) TS3W(TG, TA, true, 2); else TS3W(TG, TA, false, 2); } } while (0)
+#define TS3(TG, TA) do { if (d_trace) hipLaunchKernelGGL((k_tile_solve3<3, TG, TA, true>), dim3(grid), dim3(TILE_WPB * WAVE), lds, (hipStream_t)stream, *S, *Nn, d_b, pw, cwp, d_trace); \
+    else hipLaunchKernelGGL((k_tile_solve3<3, TG, TA, false>), dim3(grid), dim3(TILE_WPB * WAVE), lds, (hipStream_t)stream, *S, *Nn, d_b, pw, cwp, d_trace); } while (0)
   if (S->arrow_vsteps <= 12) {
 #define C(TA) TS3(12, TA)
     TILE_TA_SWITCH(C)
@@ -3664,7 +3647,6 @@ static int launch_tile_solve3(const rldl_dev_sym *S, const rldl_dev_num *Nn, dou
 #undef C
   }
 #undef TS3
-#undef TS3W
   return launch_status();
 }
 static int launch_tile_solve(const rldl_dev_sym *S, const rldl_dev_num *Nn, double *d_b, void *stream) {

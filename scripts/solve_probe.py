@@ -54,6 +54,7 @@ for B in [int(x) for x in a.batches.split(",")]:
         q = lambda v: [round(float(x), 2) for x in np.percentile(v, [0, 10, 50, 90, 100])]
         rec["timeline_us"] = {"span_first_start_to_last_end": round(float(tr[:, 6].max() - t00), 2),
                               "wave_start_after_first [min,p10,p50,p90,max]": q(tr[:, 0] - t00),
+                              "loads_issued_after_start": q(tr[:, 7] - tr[:, 0]),
                               "loads_landed_after_start": q(tr[:, 1] - tr[:, 0]),
                               "forward_gather": q(tr[:, 2] - tr[:, 1]), "forward_product": q(tr[:, 3] - tr[:, 2]),
                               "backward_product": q(tr[:, 4] - tr[:, 3]), "scatter": q(tr[:, 5] - tr[:, 4]),

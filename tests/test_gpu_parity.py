@@ -481,6 +481,30 @@ def test_config4_shard_8192_position_independence_across_rounds(R):
     w.cleanup()
 
 
+def test_solve_wave_timeline_and_rotating_timing(R):
+    """Tracing aids of the plugin solve (rldl_batch_trace_solve, rldl_batch_time_solve_rotating): the timeline of a launch is ordered
+    per wave, and the traced / rotated launches are ordinary solves (same result as rldl_batch_solve)."""
+    wl = R.workloads.SharedPatternQPs()
+    B = 64
+    Px, Ax, q, l, u = wl.values(B)
+    rho = np.full((B, wl.m), 0.1)
+    hs = [R.BatchLinsys(wl.P_pattern, wl.A_pattern, dev(Px * (1.0 + 0.01 * k)), dev(Ax), 1e-6, dev(rho)) for k in range(3)]
+    g = torch.Generator(device="cuda:0"); g.manual_seed(3)
+    rhs = torch.randn((B, wl.n + wl.m), dtype=torch.float64, device="cuda:0", generator=g)
+    ref = hs[0].solve(rhs.clone())
+    tr = hs[0].trace_solve(rhs.clone())
+    if tr is not None:                                              # (None: a kernel-selection switch took the handle off the tile kernel)
+        assert tr.shape == (B, 8) and (tr[:, :7] > 0).all()
+        assert (np.diff(tr[:, [0, 7, 1, 2, 3, 4, 5, 6]], axis=1) >= 0).all()      # start, loads issued, landed, gather, forward, backward, scatter, stores
+    bs = [rhs.clone() for _ in hs]
+    assert R.BatchLinsys.time_solve_rotating(hs, bs, reps=3) > 0.0                  # one launch per handle: bs[k] = solve of handle k
+    assert torch.equal(bs[0], ref)
+    for k in (1, 2):
+        assert torch.equal(bs[k], hs[k].solve(rhs.clone()))
+    for h in hs:
+        h.free()
+
+
 def test_resident_iterations_equal_single_iteration_launches(R):
     """The fused kernel keeps an instance's factor and iterates on chip for a whole group of iterations; running the
     same number of iterations as separate one-iteration launches (state through HBM every time) must give the same
