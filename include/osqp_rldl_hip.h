@@ -295,6 +295,18 @@ c_int osqp_horizon_N(const osqp_horizon *h);
 /* what the last osqp_horizon_update did: the first stage that was refactorised, how many instances restarted there (the others
  * were factorised from the first block), and whether the workspace of that horizon had to be created (first visit) */
 c_int osqp_horizon_last_update(const osqp_horizon *h, c_int *pivot_stage, c_int *instances_reused, c_int *workspace_created);
+/* Single store (the reference's "combined" X / Z / Y variant, src/recursive_ldl.c:2359-2856: everything sized for Nmax once, a
+ * horizon change rebuilds the trailing part and its border only).  With scaling = 0 on a pattern the product tri-solve covers,
+ * osqp_horizon_setup builds ONE workspace at Nmax dimensions: horizon N lives on the leading entries of its arrays (row strides
+ * osqp_horizon_ld: n and m of Nmax), the stages behind N are decoupled dummies that are neither factorised nor solved, and
+ * osqp_horizon_update restarts the recursion inside the same factor store -- no second workspace, no copy of shared columns.
+ * Values and iterates of the CURRENT horizon go through the two calls below (packed arrays in that horizon's own P / A value
+ * order and sizes); results are read from osqp_horizon_workspace with the row strides of osqp_horizon_ld. */
+c_int osqp_horizon_is_single(const osqp_horizon *h);
+c_int osqp_horizon_workspaces(const osqp_horizon *h);                     /* resident numeric workspaces: 1 with the single store */
+c_int osqp_horizon_ld(const osqp_horizon *h, c_int *ld_n, c_int *ld_m);
+c_int osqp_horizon_update_P_A(osqp_horizon *h, const c_float *d_Px, const c_float *d_Ax);   /* osqp_update_P_A at the current horizon */
+c_int osqp_horizon_warm_start(osqp_horizon *h, const c_float *d_x, const c_float *d_y);      /* osqp_warm_start at the current horizon */
 void osqp_horizon_free(osqp_horizon *h);
 
 const char *rldl_version(void);

@@ -211,5 +211,8 @@ orc_int orc_rldl_xeven_stride(const orc_stage_dims *d);
 orc_int orc_rldl_factor(const orc_stage_dims *d, const orc_csc *P, const orc_csc *A, orc_float sigma, const orc_float *rho_inv,
                         orc_int Nmax, orc_int mirror_drops, orc_int terminal_rho_own, orc_int iter_start, orc_float *xeven,
                         orc_int *Lp, orc_int *Li, orc_float *Lx, orc_int Lcap, orc_float *Dinv, orc_int *perm);
+/* border algebra of the reference's combined X / Z / Y variant (compute_Vhat, recursive_ldl.c:253-327): V^ = V L^-T D^-1, Y^ = Y - V^ D V^' */
+void orc_rldl_border(orc_int nf, const orc_int *Lp, const orc_int *Li, const orc_float *Lx, const orc_float *Dinv, orc_int nrows,
+                     const orc_float *V, const orc_float *Y, orc_float *Vhat, orc_float *Yhat);
 
 #endif

@@ -14,6 +14,8 @@
  *   A_times_B_plus_I         cs_addon.c:274-339         L21 = scale Ybar' (L + I): diagonal term first, then the column of L ascending
  *   A_minus_B                cs_addon.c:342-411         E_next = Q + sigma I - (columns ny.. of Ybar')' on the leading nx x nx upper part
  *   copy_csc_plus_sigma      cs_addon.c:58-74           sigma only where a diagonal entry is stored
+ *   compute_Vhat             recursive_ldl.c:253-327    the border algebra of the "combined" X / Z / Y variant (:2359-2856):
+ *                                                       V^ = V L^-T D^-1 against a finished factor, Y^ = Y - V^ D V^' (orc_rldl_border)
  *
  * The reference keeps every block as a sparse CSC matrix; here the blocks are small dense arrays and every loop runs in the
  * reference's order, so structural zeros contribute exact zeros and the floating-point results are the same.  The small LDL'
@@ -343,4 +345,37 @@ orc_int orc_rldl_factor(const orc_stage_dims *d, const orc_csc *P, const orc_csc
   if (rc) return rc;
   if (o.overflow) return -2;
   return o.nnz;
+}
+
+
+/* The border algebra of the reference's "combined" variant (osqp_setup_combine_recursive :2603-2661, osqp_update_Z_horizon :2814-2816),
+ * as compute_Vhat (:253-327) carries it out: a block whose rows V couple it to an ALREADY FACTORISED part (L, Dinv of that part, nf x nf,
+ * in the part's own order) is bordered by
+ *     W    = L^-1 V'            forward substitution, column by column of L, every right-hand side (row of V) alongside (:270-278)
+ *     V^   = (D^-1 W)'          (:280-292; the reference stores only the entries with W != 0)
+ *     Y^   = Y - V^ W           (:294-303), i.e. Y - V^ D V^'
+ * and Y^ is what gets factorised next.  V: nrows x nf dense, row major (V[r * nf + c]), columns in the factored part's order;
+ * Y: nrows x nrows dense row major, symmetric.  Outputs Vhat (same layout as V) and Yhat (same layout as Y).
+ * compute_Uhat (:329-389) is the same algebra for the other border of the combined layout. */
+void orc_rldl_border(orc_int nf, const orc_int *Lp, const orc_int *Li, const orc_float *Lx, const orc_float *Dinv, orc_int nrows,
+                     const orc_float *V, const orc_float *Y, orc_float *Vhat, orc_float *Yhat) {
+  orc_float *W = (orc_float *)malloc(sizeof(orc_float) * (size_t)(nf * nrows > 0 ? nf * nrows : 1));
+  orc_int i, p, k, r, c;
+  for (k = 0; k < nrows; k++)
+    for (i = 0; i < nf; i++) W[i + k * nf] = V[k * nf + i];      /* Vtemp: column i of the factored part, right-hand side k (:262-266) */
+  for (i = 0; i < nf; i++)                                         /* "Invert by L" (:269-278) */
+    for (p = Lp[i]; p < Lp[i + 1]; p++)
+      for (k = 0; k < nrows; k++)
+        if (W[i + k * nf] != 0.0) W[Li[p] + k * nf] -= Lx[p] * W[i + k * nf];
+  for (i = 0; i < nf; i++)                                         /* "Invert by D" (:280-292) */
+    for (k = 0; k < nrows; k++) Vhat[k * nf + i] = W[i + k * nf] != 0.0 ? W[i + k * nf] * Dinv[i] : 0.0;
+  for (r = 0; r < nrows; r++)
+    for (c = 0; c < nrows; c++) Yhat[r * nrows + c] = Y[r * nrows + c];
+  for (i = 0; i < nf; i++)                                         /* Yhat -= Vhat(:, i) W(i, :) (:294-303) */
+    for (r = 0; r < nrows; r++) {
+      const orc_float v = Vhat[r * nf + i];
+      if (v == 0.0) continue;
+      for (c = 0; c < nrows; c++) Yhat[c + r * nrows] -= v * W[i + c * nf];
+    }
+  free(W);
 }

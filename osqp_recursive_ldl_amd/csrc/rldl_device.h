@@ -18,6 +18,10 @@ extern "C" {
 #define RLDL_PV_RING 4   /* groups of the product tri-solve whose loads are in flight + 1 (stage_prod_solve); pv_prog is padded to multiples of it */
 typedef struct {
   int nb, ld, smax;
+  /* single-store horizon handles (rldl_horizon.c): only the first nb_act blocks are live (0 = all nb); the blocks behind them
+   * belong to stages beyond the current horizon, are decoupled (zero coupling values) and are neither factorised nor solved;
+   * npos_skip = their variable positions, which count as positive pivots in the inertia verdict */
+  int nb_act, npos_skip;
   const int *bs;                          /* [nb+1] first permuted index of each block */
   const int *kd_ptr, *kd_src, *kd_pos;    /* KKT values of the diagonal block: Kx index -> tile position (lower part) */
   const int *kc_ptr, *kc_src, *kc_pos;    /* KKT values of the coupling block (b+1, b) */
@@ -174,6 +178,15 @@ int rldl_launch_solve_trace(const rldl_dev_sym *S, const rldl_dev_num *Nn, doubl
 int rldl_launch_admm_iter(const rldl_dev_sym *S, const rldl_dev_num *Nn, const rldl_dev_admm *W, void *stream);
 int rldl_launch_bcast_rows(int batch, int len, double *dst, const double *src, void *stream);
 int rldl_launch_set_range(int batch, int ld, int start, int cnt, double *dst, const double *src, const double *s, void *stream);
+/* single-store horizon change (rldl_horizon.c) */
+int rldl_launch_bcast_range(int batch, int ld, int start, int cnt, double *dst, const double *src_row, void *stream);
+int rldl_launch_scatter_rows(int batch, int cnt, int ld, const int *map, const double *src, double *dst, void *stream);
+int rldl_launch_horizon_vectors(int batch, int n_act, int n_max, int m_act, int m_max, const double *q_src, const double *l_src,
+                                const double *u_src, double *q, double *l, double *u, void *stream);
+int rldl_launch_horizon_rho(const rldl_dev_sym *S, const rldl_dev_admm *W, const int *d_status, int m_keep, int b_pivot, int *d_b0v,
+                            int *d_n_reused, void *stream);
+int rldl_launch_horizon_state_single(const rldl_dev_admm *W, int n_max, int m_max, int n_keep, int m_keep, int term_old, int term_new,
+                                     int nt, void *stream);
 int rldl_launch_polish_prep(const rldl_dev_sym *S, const rldl_dev_admm *W, void *stream);
 int rldl_launch_polish_resid(const rldl_dev_sym *S, const rldl_dev_admm *W, int add_first, void *stream);
 int rldl_launch_polish_finish(const rldl_dev_sym *S, const rldl_dev_admm *W, int add_last, void *stream);

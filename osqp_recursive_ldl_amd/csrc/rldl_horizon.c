@@ -28,6 +28,21 @@
  *   iterates x keeps its first min(n, n') entries, y the rows of the shared row blocks, the terminal multipliers move to
  *            the new terminal rows, new entries start at zero, z = A x (osqp_warm_start, osqp.c:907-950).  This is a
  *            design decision: the reference reads whatever the Nmax-sized vectors held.
+ *
+ * SINGLE STORE (round 3; the reference's "combined" X / Z / Y variant, osqp_setup_combine_recursive :2359-2756 and
+ * osqp_update_Z_horizon :2761-2856: everything is sized for Nmax once, a horizon change rebuilds only the trailing part Z, its
+ * border V^ = V L^-T D^-1 and the Schur block Y^ = Y - V^ D V^T, and changes n and m).  In the stage-interleaved order the
+ * border IS the coupling block L(2p, 2p-1) and Y^ the Schur complement the recursion forms at block 2p, so the restart at a
+ * block is the Z / V^ / Y^ rebuild.  What the single store adds: ONE workspace at Nmax dimensions serves every horizon.
+ * Variables and rows of horizon N are prefixes of those of Nmax (x_N sits where stage N's state sits, the nt terminal rows are
+ * the first nt rows of row block N), so a horizon is a set of VALUES on the Nmax patterns: stages < N nominal or the instance's
+ * own, stage N with QN on its state part and AN in its first nt rows (the patterns of the store are the unions Qi + QN,
+ * Ai + AN), everything behind it zero -- decoupled dummy variables (pivot sigma) and free rows (l = -inf, u = +inf), whose
+ * iterates stay exactly 0.  The factorisation, the tile inverses and the tri-solve stop at the last live block
+ * (rldl_dev_stage.nb_act; the solve runs a per-horizon step program over the same tile store), so the cost follows N, not
+ * Nmax.  A change N -> N' writes the nominal values of stages >= p = min(N, N'), q / l / u, rebuilds rho_vec and restarts the
+ * recursion at block 2p of the SAME factor store: no second workspace, no adoption copy.  Used when scaling = 0 and the
+ * product tri-solve is available; otherwise the per-horizon workspaces above.
  */
 #include <hip/hip_runtime_api.h>
 #include <stdlib.h>
@@ -53,6 +68,13 @@ struct osqp_horizon {
   int *b0v, *n_reused;           /* [batch] first block of the restart per instance; [RLDL_NACT_SLOTS] counters */
   int *h_reused;                 /* pinned */
   c_int last_pivot, last_reused, last_created;
+  /* single store: one workspace at Nmax dimensions (ws[Nmax]) whatever the horizon */
+  int single;
+  csc *Pmax, *Amax;              /* host patterns of the store (union blocks) */
+  int **mapP, **mapA;            /* [Nmax + 1] device: entry i of horizon N's P / A (rldl_setup_AP_matrices order) -> entry of Pmax / Amax */
+  c_int *nnzPh, *nnzAh;          /* [Nmax + 1] entries of horizon N's P / A */
+  int **progN, *nstepsN;         /* [Nmax + 1] device step programs of the product tri-solve over the live blocks, their step counts */
+  const int *prog0; int nsteps0; /* the store's own program (all blocks), restored before the workspace is freed */
 };
 
 static csc *csc_clone(const csc *M) {
@@ -75,8 +97,19 @@ static csc *csc_clone(const csc *M) {
 void osqp_horizon_free(osqp_horizon *h) {
   c_int k;
   if (!h) return;
+  if (h->single && h->ws && h->ws[h->Nmax]) {                   /* the store's own tables go back before it is freed */
+    rldl_dev_stage *G = &h->ws[h->Nmax]->ls->dsym.stage;
+    G->pv_prog = h->prog0; G->pv_nsteps = h->nsteps0; G->nb_act = 0; G->npos_skip = 0;
+  }
   if (h->ws)
     for (k = 0; k <= h->Nmax; k++) osqp_batch_cleanup(h->ws[k]);
+  for (k = 0; k <= h->Nmax; k++) {
+    if (h->mapP && h->mapP[k]) (void)hipFree(h->mapP[k]);
+    if (h->mapA && h->mapA[k]) (void)hipFree(h->mapA[k]);
+    if (h->progN && h->progN[k]) (void)hipFree(h->progN[k]);
+  }
+  free(h->mapP); free(h->mapA); free(h->nnzPh); free(h->nnzAh); free(h->progN); free(h->nstepsN);
+  rldl_csc_free(h->Pmax); rldl_csc_free(h->Amax);
   if (h->nomP)
     for (k = 0; k <= h->Nmax; k++) if (h->nomP[k]) (void)hipFree(h->nomP[k]);
   if (h->nomA)
@@ -108,6 +141,245 @@ static c_int create_workspace(osqp_horizon *h, c_int N, const c_float *d_q, cons
   rldl_csc_free(P); rldl_csc_free(A);
   if (rc) { osqp_batch_cleanup(h->ws[N]); h->ws[N] = 0; }
   return rc;
+}
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * Single store
+ * --------------------------------------------------------------------------------------------------------------------- */
+/* union of two CSC blocks with the second one placed at the top-left corner of the first (rows / columns [0, small->m) x [0, small->n));
+ * values: the big block's, 0.0 where only the small one has an entry */
+static csc *csc_union_corner(const csc *big, const csc *small) {
+  c_int j, nz = 0, cap = big->p[big->n] + small->p[small->n];
+  csc *U = (csc *)calloc(1, sizeof(csc));
+  if (!U) return 0;
+  U->m = big->m; U->n = big->n; U->nzmax = cap > 0 ? cap : 1; U->nz = -1;
+  U->p = (c_int *)calloc((size_t)big->n + 1, sizeof(c_int));
+  U->i = (c_int *)malloc(sizeof(c_int) * (size_t)U->nzmax);
+  U->x = (c_float *)malloc(sizeof(c_float) * (size_t)U->nzmax);
+  if (!U->p || !U->i || !U->x) { rldl_csc_free(U); return 0; }
+  for (j = 0; j < big->n; j++) {
+    c_int a = big->p[j], ae = big->p[j + 1], b = j < small->n ? small->p[j] : 0, be = j < small->n ? small->p[j + 1] : 0;
+    U->p[j] = nz;
+    while (a < ae || b < be) {                                   /* merge by row index (both sorted) */
+      if (b >= be || (a < ae && big->i[a] <= small->i[b])) {
+        if (b < be && big->i[a] == small->i[b]) b++;
+        U->i[nz] = big->i[a]; U->x[nz] = big->x[a]; a++;
+      } else { U->i[nz] = small->i[b]; U->x[nz] = 0.0; b++; }
+      nz++;
+    }
+  }
+  U->p[big->n] = nz;
+  return U;
+}
+
+static int csc_rows_sorted(const csc *M) {
+  c_int j, p;
+  for (j = 0; j < M->n; j++)
+    for (p = M->p[j] + 1; p < M->p[j + 1]; p++) if (M->i[p] <= M->i[p - 1]) return 0;
+  return 1;
+}
+
+/* entry (r, j) of M, or -1 */
+static c_int csc_find(const csc *M, c_int r, c_int j) {
+  c_int p;
+  for (p = M->p[j]; p < M->p[j + 1]; p++) if (M->i[p] == r) return p;
+  return -1;
+}
+
+/* tables of horizon N on the store's patterns: value maps, the nominal value rows (zeros outside the horizon's entries), the step
+ * program over the live blocks */
+static c_int single_tables(osqp_horizon *h, c_int N) {
+  rldl_stage_dims d = h->dims;
+  csc *P = 0, *A = 0;
+  int *mp = 0, *ma = 0;
+  double *rowP = 0, *rowA = 0;
+  c_int rc = 0, j, p, nzP, nzA, nzPm = h->Pmax->p[h->Pmax->n], nzAm = h->Amax->p[h->Amax->n];
+  if (h->mapP[N]) return 0;
+  d.N = N;
+  rc = rldl_setup_AP_matrices(&d, h->blk[0], h->blk[1], h->blk[2], h->blk[3], h->blk[4], h->blk[5], h->blk[6], &P, &A, 0, 0, 0, 0, 0, 0);
+  if (rc) return rc;
+  nzP = P->p[P->n]; nzA = A->p[A->n];
+  mp = (int *)malloc(sizeof(int) * (size_t)(nzP + 1)); ma = (int *)malloc(sizeof(int) * (size_t)(nzA + 1));
+  rowP = (double *)calloc((size_t)nzPm + 1, sizeof(double)); rowA = (double *)calloc((size_t)nzAm + 1, sizeof(double));
+  if (!mp || !ma || !rowP || !rowA) rc = RLDL_MEM_ALLOC_ERROR;
+  for (j = 0; !rc && j < P->n; j++)
+    for (p = P->p[j]; p < P->p[j + 1]; p++) {
+      const c_int q = csc_find(h->Pmax, P->i[p], j);
+      if (q < 0) { rc = 1; break; }
+      mp[p] = (int)q; rowP[q] = P->x[p];
+    }
+  for (j = 0; !rc && j < A->n; j++)
+    for (p = A->p[j]; p < A->p[j + 1]; p++) {
+      const c_int q = csc_find(h->Amax, A->i[p], j);
+      if (q < 0) { rc = 1; break; }
+      ma[p] = (int)q; rowA[q] = A->x[p];
+    }
+  if (!rc) {
+    if (!HIP_OK(hipMalloc((void **)&h->mapP[N], sizeof(int) * (size_t)(nzP + 1))) || !HIP_OK(hipMalloc((void **)&h->mapA[N], sizeof(int) * (size_t)(nzA + 1))) ||
+        !HIP_OK(hipMalloc((void **)&h->nomP[N], sizeof(double) * (size_t)nzPm + 8)) || !HIP_OK(hipMalloc((void **)&h->nomA[N], sizeof(double) * (size_t)nzAm + 8)) ||
+        !HIP_OK(hipMemcpy(h->mapP[N], mp, sizeof(int) * (size_t)nzP, hipMemcpyHostToDevice)) ||
+        !HIP_OK(hipMemcpy(h->mapA[N], ma, sizeof(int) * (size_t)nzA, hipMemcpyHostToDevice)) ||
+        !HIP_OK(hipMemcpy(h->nomP[N], rowP, sizeof(double) * (size_t)nzPm, hipMemcpyHostToDevice)) ||
+        !HIP_OK(hipMemcpy(h->nomA[N], rowA, sizeof(double) * (size_t)nzAm, hipMemcpyHostToDevice)))
+      rc = RLDL_MEM_ALLOC_ERROR;
+    h->nnzPh[N] = nzP; h->nnzAh[N] = nzA;
+  }
+  if (!rc && N < h->Nmax && rldl_stage_prog_prefix(h->ws[h->Nmax]->ls, (int)(2 * N + 2), &h->progN[N], &h->nstepsN[N])) rc = 1;
+  if (rc) {
+    if (h->mapP[N]) { (void)hipFree(h->mapP[N]); h->mapP[N] = 0; }
+    if (h->mapA[N]) { (void)hipFree(h->mapA[N]); h->mapA[N] = 0; }
+    if (h->nomP[N]) { (void)hipFree(h->nomP[N]); h->nomP[N] = 0; }
+    if (h->nomA[N]) { (void)hipFree(h->nomA[N]); h->nomA[N] = 0; }
+  }
+  free(mp); free(ma); free(rowP); free(rowA);
+  rldl_csc_free(P); rldl_csc_free(A);
+  return rc;
+}
+
+/* move the store to horizon Nnew; p = first stage whose values change (0: everything, the first activation) */
+static c_int single_activate(osqp_horizon *h, c_int Nnew, c_int p, const c_float *d_q, const c_float *d_l, const c_float *d_u) {
+  osqp_batch *w = h->ws[h->Nmax];
+  const rldl_stage_dims *d = &h->dims;
+  rldl_dev_stage *G = &w->ls->dsym.stage;
+  hipStream_t st = (hipStream_t)h->stream;
+  const c_int nN = Nnew * (d->nx + d->nu), mN = Nnew * (d->nx + d->ny) + d->nt;
+  const c_int n_keep = p * (d->nx + d->nu), m_keep = p * (d->nx + d->ny);
+  const c_int col_keep = p > 0 ? d->nu + (p - 1) * (d->nx + d->nu) : 0;      /* columns of P and A before stage p */
+  const c_int cP = h->Pmax->p[col_keep], cA = h->Amax->p[col_keep];
+  const c_int term_old = h->N * (d->nx + d->ny), term_new = Nnew * (d->nx + d->ny);
+  c_int rc;
+  int k;
+  rc = single_tables(h, Nnew);
+  if (rc) return rc;
+  if (w->loop_pending && osqp_batch_wait(w)) return 1;
+  h->last_created = 0; h->last_pivot = p; h->last_reused = 0;
+  /* values of the stages >= p: the nominal row of the new horizon (zeros behind its terminal stage) */
+  if (rldl_launch_bcast_range((int)h->batch, (int)w->nnzP, (int)cP, (int)(w->nnzP - cP), w->Px, h->nomP[Nnew], w->stream) ||
+      rldl_launch_bcast_range((int)h->batch, (int)w->nnzA, (int)cA, (int)(w->nnzA - cA), w->Ax, h->nomA[Nnew], w->stream))
+    return 1;
+  if (rldl_launch_horizon_vectors((int)h->batch, (int)nN, (int)w->n, (int)mN, (int)w->m, d_q, d_l, d_u, w->q, w->l, w->u, w->stream)) return 1;
+  (void)hipMemsetAsync(h->n_reused, 0, sizeof(int) * RLDL_NACT_SLOTS, st);
+  if (rldl_launch_horizon_rho(&w->ls->dsym, &w->W, w->ls->num.status, (int)m_keep, (int)(2 * p), h->b0v, h->n_reused, w->stream)) return 1;
+  /* the live blocks of the new horizon and the step program over their tiles */
+  if (Nnew < h->Nmax) {
+    G->nb_act = (int)(2 * Nnew + 2);
+    G->npos_skip = (int)(w->n - d->nu - Nnew * (d->nx + d->nu));           /* variable positions of the blocks behind block 2 Nnew + 1 */
+    G->pv_prog = h->progN[Nnew]; G->pv_nsteps = h->nstepsN[Nnew];
+  } else { G->nb_act = 0; G->npos_skip = 0; G->pv_prog = h->prog0; G->pv_nsteps = h->nsteps0; }
+  if (rldl_launch_kkt_assemble(&w->ls->dsym, &w->ls->num, w->Px, w->Ax, w->W.rho_vec, 0, 0, w->stream)) return 1;
+  if (rldl_launch_stage_factor_each(&w->ls->dsym, &w->ls->num, h->b0v, 1, w->stream)) return 1;
+  if (!HIP_OK(hipMemcpyAsync(h->h_reused, h->n_reused, sizeof(int) * RLDL_NACT_SLOTS, hipMemcpyDeviceToHost, st))) return 1;
+  if (rldl_batch_check_status(w->ls)) return RLDL_NONCVX_ERROR;   /* synchronises the stream */
+  if (p > 0) for (k = 0; k < RLDL_NACT_SLOTS; k++) h->last_reused += h->h_reused[k];
+  if (p > 0 && w->st.warm_start) {
+    if (rldl_launch_horizon_state_single(&w->W, (int)w->n, (int)w->m, (int)n_keep, (int)m_keep, (int)term_old, (int)term_new, (int)d->nt, w->stream)) return 1;
+    if (rldl_launch_matvec_A(&w->ls->dsym, &w->W, w->W.x, w->W.z, w->stream)) return 1;   /* z = A x, osqp.c:945 */
+  }
+  osqp_batch_reset_info(w);
+  h->N = Nnew; h->dims.N = Nnew;
+  return 0;
+}
+
+/* 0: the store is up at horizon dims->N; 2: the problem does not qualify (the caller takes the per-horizon workspaces); else an error */
+static c_int single_setup(osqp_horizon *h, const c_float *d_q, const c_float *d_l, const c_float *d_u) {
+  rldl_stage_dims d = h->dims;
+  csc *Qi_u = 0, *Ai_u = 0;
+  double *qp = 0, *lp = 0, *up = 0;
+  osqp_batch *w = 0;
+  const c_int N0 = h->dims.N;
+  const c_int nmax = h->Nmax * (d.nx + d.nu), mmax = h->Nmax * (d.nx + d.ny) + d.nt;
+  c_int rc = 2;
+  if (h->st.scaling || getenv("RLDL_HORIZON_MULTI") || getenv("RLDL_NO_STAGE_PROD") || getenv("RLDL_NO_STAGE_FACTOR") || getenv("RLDL_NO_STAGE_SOLVE") ||
+      getenv("RLDL_HORIZON_FULL") || getenv("RLDL_STAGE_LDS"))
+    return 2;
+  if (d.nt > d.nx + d.ny || d.nt > 64 || h->blk[2]->n > h->blk[1]->n) return 2;
+  for (rc = 0; rc < 7; rc++) if (!csc_rows_sorted(h->blk[rc])) return 2;
+  rc = 2;
+  Qi_u = csc_union_corner(h->blk[1], h->blk[2]);                  /* Qi + QN on the state part */
+  Ai_u = csc_union_corner(h->blk[4], h->blk[6]);                  /* Ai + AN in the first nt rows of the state columns */
+  if (!Qi_u || !Ai_u) { rc = RLDL_MEM_ALLOC_ERROR; goto out; }
+  h->mapP = (int **)calloc((size_t)h->Nmax + 1, sizeof(int *)); h->mapA = (int **)calloc((size_t)h->Nmax + 1, sizeof(int *));
+  h->progN = (int **)calloc((size_t)h->Nmax + 1, sizeof(int *)); h->nstepsN = (int *)calloc((size_t)h->Nmax + 1, sizeof(int));
+  h->nnzPh = (c_int *)calloc((size_t)h->Nmax + 1, sizeof(c_int)); h->nnzAh = (c_int *)calloc((size_t)h->Nmax + 1, sizeof(c_int));
+  if (!h->mapP || !h->mapA || !h->progN || !h->nstepsN || !h->nnzPh || !h->nnzAh) { rc = RLDL_MEM_ALLOC_ERROR; goto out; }
+  if (!HIP_OK(hipMalloc((void **)&qp, sizeof(double) * (size_t)h->batch * (size_t)nmax + 8)) ||
+      !HIP_OK(hipMalloc((void **)&lp, sizeof(double) * (size_t)h->batch * (size_t)mmax + 8)) ||
+      !HIP_OK(hipMalloc((void **)&up, sizeof(double) * (size_t)h->batch * (size_t)mmax + 8))) { rc = RLDL_MEM_ALLOC_ERROR; goto out; }
+  if (rldl_launch_horizon_vectors((int)h->batch, (int)(N0 * (d.nx + d.nu)), (int)nmax, (int)(N0 * (d.nx + d.ny) + d.nt), (int)mmax, d_q, d_l, d_u,
+                                  qp, lp, up, h->stream) || !HIP_OK(hipStreamSynchronize((hipStream_t)h->stream))) { rc = 1; goto out; }
+  d.N = h->Nmax;
+  rc = osqp_batch_setup_recursive(&w, h->batch, &d, h->blk[0], Qi_u, h->blk[2], h->blk[3], Ai_u, h->blk[5], h->blk[6], qp, lp, up, &h->st,
+                                  &h->Pmax, &h->Amax, h->stream);
+  if (rc) goto out;
+  h->ws[h->Nmax] = w;
+  if (!w->ls->dsym.stage.pv_ok || w->ls->dsym.stage.nb != 2 * h->Nmax + 2 || !w->ls->num.Ti) {   /* no product tri-solve on this pattern */
+    osqp_batch_cleanup(w); h->ws[h->Nmax] = 0; rldl_csc_free(h->Pmax); rldl_csc_free(h->Amax); h->Pmax = h->Amax = 0;
+    rc = 2; goto out;
+  }
+  h->prog0 = w->ls->dsym.stage.pv_prog; h->nsteps0 = w->ls->dsym.stage.pv_nsteps;
+  h->single = 1;
+  h->N = h->Nmax;                                                 /* (what the store holds right now: the nominal problem at Nmax) */
+  rc = single_activate(h, N0, 0, d_q, d_l, d_u);
+out:
+  if (qp) (void)hipFree(qp);
+  if (lp) (void)hipFree(lp);
+  if (up) (void)hipFree(up);
+  rldl_csc_free(Qi_u); rldl_csc_free(Ai_u);
+  return rc;
+}
+
+c_int osqp_horizon_is_single(const osqp_horizon *h) { return h ? h->single : 0; }
+
+/* resident numeric workspaces (factor, tiles, iterates, problem data): 1 with the single store, one per visited horizon otherwise */
+c_int osqp_horizon_workspaces(const osqp_horizon *h) {
+  c_int k, cnt = 0;
+  if (!h) return 0;
+  for (k = 0; k <= h->Nmax; k++) cnt += h->ws[k] ? 1 : 0;
+  return cnt;
+}
+
+/* row strides of the workspace's per-instance arrays: n and m of Nmax with the single store, of the current horizon otherwise */
+c_int osqp_horizon_ld(const osqp_horizon *h, c_int *ld_n, c_int *ld_m) {
+  const osqp_batch *w;
+  if (!h) return 1;
+  w = h->single ? h->ws[h->Nmax] : h->ws[h->N];
+  if (ld_n) *ld_n = w->n;
+  if (ld_m) *ld_m = w->m;
+  return 0;
+}
+
+/* osqp_update_P_A for the current horizon: values in the order of ITS assembled P / A (rldl_setup_AP_matrices at N), device arrays
+ * [batch][nnz]; either may be null */
+c_int osqp_horizon_update_P_A(osqp_horizon *h, const c_float *d_Px, const c_float *d_Ax) {
+  osqp_batch *w;
+  c_int rc;
+  if (!h) return 7;
+  if (!h->single) return osqp_batch_update_P_A(h->ws[h->N], d_Px, d_Ax);
+  w = h->ws[h->Nmax];
+  if (w->loop_pending && osqp_batch_wait(w)) return 1;
+  if (d_Px && rldl_launch_scatter_rows((int)h->batch, (int)h->nnzPh[h->N], (int)w->nnzP, h->mapP[h->N], d_Px, w->Px, w->stream)) return 1;
+  if (d_Ax && rldl_launch_scatter_rows((int)h->batch, (int)h->nnzAh[h->N], (int)w->nnzA, h->mapA[h->N], d_Ax, w->Ax, w->stream)) return 1;
+  rc = rldl_batch_update_matrices(w->ls, d_Px ? w->Px : 0, d_Ax ? w->Ax : 0);
+  osqp_batch_reset_info(w);
+  return rc;
+}
+
+/* osqp_warm_start for the current horizon: packed [batch][n_N], [batch][m_N] */
+c_int osqp_horizon_warm_start(osqp_horizon *h, const c_float *d_x, const c_float *d_y) {
+  osqp_batch *w;
+  const rldl_stage_dims *d;
+  if (!h || !d_x || !d_y) return 1;
+  if (!h->single) return osqp_batch_warm_start(h->ws[h->N], d_x, d_y);
+  w = h->ws[h->Nmax]; d = &h->dims;
+  if (!w->st.warm_start) w->st.warm_start = 1;
+  if (!HIP_OK(hipMemsetAsync(w->W.x, 0, sizeof(double) * (size_t)h->batch * (size_t)w->n, (hipStream_t)w->stream)) ||
+      !HIP_OK(hipMemsetAsync(w->W.y, 0, sizeof(double) * (size_t)h->batch * (size_t)w->m, (hipStream_t)w->stream)) ||
+      !HIP_OK(hipMemcpy2DAsync(w->W.x, sizeof(double) * (size_t)w->n, d_x, sizeof(double) * (size_t)(h->N * (d->nx + d->nu)),
+                               sizeof(double) * (size_t)(h->N * (d->nx + d->nu)), (size_t)h->batch, hipMemcpyDeviceToDevice, (hipStream_t)w->stream)) ||
+      !HIP_OK(hipMemcpy2DAsync(w->W.y, sizeof(double) * (size_t)w->m, d_y, sizeof(double) * (size_t)(h->N * (d->nx + d->ny) + d->nt),
+                               sizeof(double) * (size_t)(h->N * (d->nx + d->ny) + d->nt), (size_t)h->batch, hipMemcpyDeviceToDevice, (hipStream_t)w->stream)))
+    return 1;
+  return rldl_launch_matvec_A(&w->ls->dsym, &w->W, w->W.x, w->W.z, w->stream) ? 1 : 0;
 }
 
 c_int osqp_horizon_setup(osqp_horizon **hp, c_int batch, const rldl_stage_dims *dims, c_int Nmax, const csc *Q0, const csc *Qi,
@@ -143,13 +415,14 @@ c_int osqp_horizon_setup(osqp_horizon **hp, c_int batch, const rldl_stage_dims *
     osqp_horizon_free(h);
     return RLDL_MEM_ALLOC_ERROR;
   }
-  rc = create_workspace(h, h->N, d_q, d_l, d_u);
+  rc = single_setup(h, d_q, d_l, d_u);                            /* one store for every horizon when the problem qualifies ... */
+  if (rc == 2) { h->single = 0; h->N = dims->N; h->dims.N = dims->N; rc = create_workspace(h, h->N, d_q, d_l, d_u); }   /* ... else a workspace per visited horizon */
   if (rc) { osqp_horizon_free(h); return rc; }
   *hp = h;
   return 0;
 }
 
-osqp_batch *osqp_horizon_workspace(osqp_horizon *h) { return h ? h->ws[h->N] : 0; }
+osqp_batch *osqp_horizon_workspace(osqp_horizon *h) { return h ? h->ws[h->single ? h->Nmax : h->N] : 0; }
 c_int osqp_horizon_N(const osqp_horizon *h) { return h ? h->N : -1; }
 
 c_int osqp_horizon_last_update(const osqp_horizon *h, c_int *pivot_stage, c_int *instances_reused, c_int *workspace_created) {
@@ -186,6 +459,7 @@ c_int osqp_horizon_update(osqp_horizon *h, c_int Nnew, const c_float *d_q, const
   if (Nnew > h->Nmax || Nnew < 1) return -1;                      /* :1978-1989 */
   if (Nnew == h->N) return 0;                                     /* :1982-1985 */
   if (!d_q || !d_l || !d_u) return 1;
+  if (h->single) return single_activate(h, Nnew, h->N < Nnew ? h->N : Nnew, d_q, d_l, d_u);
   d = &h->dims; st = (hipStream_t)h->stream; B = (size_t)h->batch;
   o = h->ws[h->N];
   if (o->loop_pending && osqp_batch_wait(o)) return 1;

@@ -20,6 +20,9 @@ struct rldl_batch {
   int recursive;
   void *rec;               /* rldl_rec_state* */
   int *pv_tiD;             /* host, stage handles with product tiles: first Ti entry of every diagonal block's tile [nb + 1] */
+  /* host copies of the product tri-solve's tables, for step programs over a prefix of the blocks (single-store horizon handles):
+   * group descriptors in tile order [pv_ngrp][12], tile info [4 per tile], tile id of (block, kind) [2 nb] */
+  int *pv_grp, pv_ngrp, *pv_tinfo_h, *pv_blk_h;
 };
 
 /* batched ADMM workspace (rldl_admm.c) */
@@ -46,6 +49,10 @@ struct osqp_batch {
 int rldl_device_available(void);
 void rldl_batch_enable_stage(rldl_batch *h, const rldl_stage_dims *dims);   /* rldl_recursive.c */
 void rldl_stage_maps_free(rldl_batch *h);
+/* step program of the product tri-solve over the first nb_act blocks only (device array in *d_prog, owned by the caller; its
+ * step count in *nsteps): forward over the tiles of those blocks, backward over the same tiles in reverse; the coupling tile
+ * from the last live block to the first dead one is left out.  0 ok, 1 not available. */
+int rldl_stage_prog_prefix(const rldl_batch *h, int nb_act, int **d_prog, int *nsteps);
 void osqp_batch_reset_info(osqp_batch *w);                                    /* rldl_admm.c: auxil.c:628-645 */
 c_int osqp_batch_bounds_ok(osqp_batch *w, c_int count, const c_float *d_l, const c_float *d_u);   /* rldl_admm.c: 1 when l <= u everywhere */
 c_int rldl_batch_update_matrices_async(rldl_batch *h, const c_float *d_Px, const c_float *d_Ax, c_float *keep_Px,

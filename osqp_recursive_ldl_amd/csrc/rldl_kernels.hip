@@ -1602,7 +1602,7 @@ __global__ __launch_bounds__(WAVE, 4) void k_stage_invert(rldl_dev_sym S, rldl_d
   if (mask && !mask[inst]) return;
   if (b0v) b0 = __builtin_amdgcn_readfirstlane(b0v[inst]);
   const rldl_dev_stage &G = S.stage;
-  const int nb = G.nb;
+  const int nb = G.nb_act > 0 ? G.nb_act : G.nb;                  // (single-store horizon handles: the live blocks)
   constexpr int ldT = SM + 2;                                     // even (= G.pv_ldT)
   constexpr int PR = (SM * (SM - 1) / 2 + WAVE - 1) / WAVE;       // rounds of 64 entries that cover a diagonal block
   extern __shared__ __attribute__((aligned(16))) double sh[];
@@ -1627,7 +1627,7 @@ __global__ __launch_bounds__(WAVE, 4) void k_stage_invert(rldl_dev_sym S, rldl_d
   load_idx(b0);
   {                                                              // coupling tiles L(b + 1, b), b >= b0: factor slot -> Ti, one flat list, eight rounds of loads in flight
     sv_cptr_t cpt = (sv_cptr_t)(unsigned long long)G.pv_cptr;
-    const int k1 = cpt[nb];
+    const int k1 = cpt[b0 < nb - 1 ? nb - 1 : b0];               // C_b for b0 <= b < nb - 1 (the last live block couples to nothing live)
     for (int k0 = cpt[b0]; k0 < k1; k0 += 8 * WAVE) {
       int ti[8], sl[8];
       double v[8];
@@ -1965,7 +1965,7 @@ __global__ __launch_bounds__(WAVE) void k_stage_factor(rldl_dev_sym S, rldl_dev_
   if (mask && !mask[inst]) return;
   if (b0v) b0 = b0v[inst];                                       // per-instance restart block (horizon change)
   const rldl_dev_stage &G = S.stage;
-  const int ld = G.ld, nb = G.nb;
+  const int ld = G.ld, nb = G.nb_act > 0 ? G.nb_act : G.nb;     // (single-store horizon handles: the live blocks)
   extern __shared__ double sh[];
   // Wp: panel [S_b ; C_b] (rows of block b, then rows of block b+1), 2*smax rows x ld;  Lc: L(b, b-1), smax rows x ld
   double *Wp = sh, *Lc = Wp + 2 * G.smax * ld, *dg = Lc + G.smax * ld, *dc = dg + ld;
@@ -2042,6 +2042,7 @@ __global__ __launch_bounds__(WAVE) void k_stage_factor(rldl_dev_sym S, rldl_dev_
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) npos += __shfl_xor(npos, o);
+  npos += G.nb_act > 0 ? G.npos_skip : 0;                       // variable positions of the blocks beyond the live ones
   if (lane == 0) { Nn.status[inst] = zero ? -1 : npos; if (Nn.fail && (zero || npos < S.n)) atomicOr(Nn.fail, 1); }
 }
 
@@ -2076,7 +2077,7 @@ __global__ __launch_bounds__(WAVE) void k_stage_factor_r(rldl_dev_sym S, rldl_de
   if (mask && !mask[inst]) return;
   if (b0v) b0 = __builtin_amdgcn_readfirstlane(b0v[inst]);      // per-instance restart block (horizon change)
   const rldl_dev_stage &G = S.stage;
-  const int ld = G.ld, nb = G.nb;
+  const int ld = G.ld, nb = G.nb_act > 0 ? G.nb_act : G.nb;     // (single-store horizon handles: the live blocks)
   constexpr int NT = (SM + 15) / 16, SO_LD = 16 * NT + 1;
   extern __shared__ double sh[];
   // T: staging tile of the panel (2 smax rows; MFMA: also the 16 NT x SO_LD result tiles); Lt: L(b, b-1) as broadcast source /
@@ -2197,6 +2198,7 @@ __global__ __launch_bounds__(WAVE) void k_stage_factor_r(rldl_dev_sym S, rldl_de
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) npos += __shfl_xor(npos, o);
+  npos += G.nb_act > 0 ? G.npos_skip : 0;                       // variable positions of the blocks beyond the live ones
   if (lane == 0) { Nn.status[inst] = zero ? -1 : npos; if (Nn.fail && (zero || npos < S.n)) atomicOr(Nn.fail, 1); }
 }
 
@@ -3334,6 +3336,70 @@ __global__ __launch_bounds__(WAVE) void k_horizon_adopt(rldl_dev_sym So, rldl_de
 
 }  // namespace
 
+// ---- single-store horizon change (rldl_horizon.c): ONE workspace at Nmax dimensions for every horizon; the stages beyond the
+// current horizon are decoupled dummies (zero values, free rows), so only VALUES change and nothing is copied between workspaces ----
+// dst[b][start + i] = src_row[start + i], i < cnt: a column range of one nominal row to every instance
+__global__ __launch_bounds__(256) void k_bcast_range(int ld, int start, int cnt, double *dst, const double *__restrict__ src_row) {
+  const int inst = blockIdx.x;
+  for (int i = threadIdx.x; i < cnt; i += blockDim.x) dst[(size_t)inst * ld + start + i] = src_row[start + i];
+}
+// dst[b][map[i]] = src[b][i], i < cnt: values given in one horizon's pattern order into the Nmax (union) pattern
+__global__ __launch_bounds__(256) void k_scatter_rows(int cnt, int ld, const int *__restrict__ map, const double *__restrict__ src, double *dst) {
+  const int inst = blockIdx.x;
+  for (int i = threadIdx.x; i < cnt; i += blockDim.x) dst[(size_t)inst * ld + map[i]] = src[(size_t)inst * cnt + i];
+}
+// q, l, u of a horizon (packed [n_act] / [m_act] rows) into the Nmax-sized rows: linear cost 0 and free rows behind them
+__global__ __launch_bounds__(256) void k_horizon_vectors(int n_act, int n_max, int m_act, int m_max, const double *__restrict__ qs,
+                                                         const double *__restrict__ ls, const double *__restrict__ us, double *q, double *l, double *u) {
+  const int inst = blockIdx.x;
+  for (int i = threadIdx.x; i < n_max; i += blockDim.x) q[(size_t)inst * n_max + i] = i < n_act ? qs[(size_t)inst * n_act + i] : 0.0;
+  for (int i = threadIdx.x; i < m_max; i += blockDim.x) {
+    l[(size_t)inst * m_max + i] = i < m_act ? ls[(size_t)inst * m_act + i] : -OSQP_INFTY;
+    u[(size_t)inst * m_max + i] = i < m_act ? us[(size_t)inst * m_act + i] : OSQP_INFTY;
+  }
+}
+// set_rho_vec (auxil.c:79-101) for the new bounds + the verdict of the horizon change per instance: rho_vec of the rows the two
+// horizons share is part of the shared factor columns, so an instance whose rho_vec changes there (a row changed its type) or
+// whose old factor has a zero pivot restarts at block 0, the others at the pivot block
+__global__ __launch_bounds__(WAVE) void k_horizon_rho(rldl_dev_sym S, rldl_dev_admm W, const int *__restrict__ fstatus, int m_keep, int b_pivot,
+                                                      int *__restrict__ b0v, int *__restrict__ n_reused) {
+  const int inst = blockIdx.x, lane = threadIdx.x, m = S.m;
+  const double *l = W.l + (size_t)inst * m, *u = W.u + (size_t)inst * m;
+  double *rv = W.rho_vec + (size_t)inst * m;
+  int *ct = W.constr_type + (size_t)inst * m;
+  const double rho = W.rho_cur[inst];
+  int differ = fstatus[inst] < 0 ? 1 : 0;
+  for (int i = lane; i < m; i += WAVE) {
+    int t;
+    double r;
+    if (l[i] < -OSQP_INFTY * MIN_SCALING && u[i] > OSQP_INFTY * MIN_SCALING) { t = -1; r = RHO_MIN; }
+    else if (u[i] - l[i] < RHO_TOL) { t = 1; r = RHO_EQ_OVER_RHO_INEQ * rho; }
+    else { t = 0; r = rho; }
+    if (i < m_keep && rv[i] != r) differ = 1;
+    ct[i] = t; rv[i] = r;
+  }
+  differ = wave_any(differ);
+  if (lane == 0) {
+    W.refactor[inst] = 0;
+    b0v[inst] = differ ? 0 : b_pivot;
+    if (!differ) atomicAdd(&n_reused[inst & (RLDL_NACT_SLOTS - 1)], 1);
+  }
+}
+// the iterates across a horizon change, in place: x keeps its first n_keep entries, y the rows of the shared row blocks, the
+// terminal multipliers move from the old terminal rows to the new ones, everything else starts at zero (z = A x follows)
+__global__ __launch_bounds__(WAVE) void k_horizon_state_single(rldl_dev_admm W, int n_max, int m_max, int n_keep, int m_keep, int term_old,
+                                                               int term_new, int nt) {
+  const int inst = blockIdx.x, lane = threadIdx.x;
+  double *x = W.x + (size_t)inst * n_max, *y = W.y + (size_t)inst * m_max;
+  double tv = 0.0;
+  if (lane < nt) tv = y[term_old + lane];                         // (nt <= 64: checked by the host)
+  wave_sync();
+  for (int i = n_keep + lane; i < n_max; i += WAVE) x[i] = 0.0;
+  for (int i = m_keep + lane; i < m_max; i += WAVE) y[i] = 0.0;
+  wave_sync();
+  if (lane < nt) y[term_new + lane] = tv;
+}
+
 // ================================================================================================
 // extern "C" launchers (enqueue only)
 // ================================================================================================
@@ -4001,6 +4067,34 @@ extern "C" int rldl_launch_ew_scale(int batch, int len, double *dst, const doubl
 extern "C" int rldl_launch_bcast_rows(int batch, int len, double *dst, const double *src, void *stream) {
   if (batch <= 0 || len <= 0) return 0;
   hipLaunchKernelGGL(k_bcast_rows, dim3(batch), dim3(256), 0, (hipStream_t)stream, len, dst, src);
+  return launch_status();
+}
+extern "C" int rldl_launch_bcast_range(int batch, int ld, int start, int cnt, double *dst, const double *src_row, void *stream) {
+  if (batch <= 0 || cnt <= 0) return 0;
+  hipLaunchKernelGGL(k_bcast_range, dim3(batch), dim3(256), 0, (hipStream_t)stream, ld, start, cnt, dst, src_row);
+  return launch_status();
+}
+extern "C" int rldl_launch_scatter_rows(int batch, int cnt, int ld, const int *map, const double *src, double *dst, void *stream) {
+  if (batch <= 0 || cnt <= 0) return 0;
+  hipLaunchKernelGGL(k_scatter_rows, dim3(batch), dim3(256), 0, (hipStream_t)stream, cnt, ld, map, src, dst);
+  return launch_status();
+}
+extern "C" int rldl_launch_horizon_vectors(int batch, int n_act, int n_max, int m_act, int m_max, const double *q_src, const double *l_src,
+                                           const double *u_src, double *q, double *l, double *u, void *stream) {
+  if (batch <= 0) return 0;
+  hipLaunchKernelGGL(k_horizon_vectors, dim3(batch), dim3(256), 0, (hipStream_t)stream, n_act, n_max, m_act, m_max, q_src, l_src, u_src, q, l, u);
+  return launch_status();
+}
+extern "C" int rldl_launch_horizon_rho(const rldl_dev_sym *S, const rldl_dev_admm *W, const int *d_status, int m_keep, int b_pivot, int *d_b0v,
+                                       int *d_n_reused, void *stream) {
+  if (W->batch <= 0) return 0;
+  hipLaunchKernelGGL(k_horizon_rho, dim3(W->batch), dim3(WAVE), 0, (hipStream_t)stream, *S, *W, d_status, m_keep, b_pivot, d_b0v, d_n_reused);
+  return launch_status();
+}
+extern "C" int rldl_launch_horizon_state_single(const rldl_dev_admm *W, int n_max, int m_max, int n_keep, int m_keep, int term_old, int term_new,
+                                                int nt, void *stream) {
+  if (W->batch <= 0) return 0;
+  hipLaunchKernelGGL(k_horizon_state_single, dim3(W->batch), dim3(WAVE), 0, (hipStream_t)stream, *W, n_max, m_max, n_keep, m_keep, term_old, term_new, nt);
   return launch_status();
 }
 extern "C" int rldl_launch_set_range(int batch, int ld, int start, int cnt, double *dst, const double *src, const double *s, void *stream) {

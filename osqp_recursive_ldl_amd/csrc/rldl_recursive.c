@@ -51,6 +51,8 @@ void rldl_stage_maps_free(rldl_batch *h) {
   memset(G, 0, sizeof(*G));
   free(h->rec); h->rec = 0;
   free(h->pv_tiD); h->pv_tiD = 0;
+  free(h->pv_grp); free(h->pv_tinfo_h); free(h->pv_blk_h);
+  h->pv_grp = h->pv_tinfo_h = h->pv_blk_h = 0; h->pv_ngrp = 0;
 }
 
 /* Tables of the block tri-solve (k_plan_solve<.., true> and friends): per stage block the L entries of the diagonal block
@@ -312,8 +314,43 @@ static void build_prod_tiles(rldl_batch *h, const int *bs, int nb, int ld, const
     G->pv_ldTi = (T.nTi + 1) & ~1;
     free(h->pv_tiD); h->pv_tiD = T.tiD; T.tiD = 0;
     G->pv_ok = 1;
+    /* host copies for step programs over a prefix of the blocks (the first T.ngroups entries of seq are the groups in tile order) */
+    free(h->pv_grp); free(h->pv_tinfo_h); free(h->pv_blk_h);
+    h->pv_grp = (int *)malloc(sizeof(int) * (size_t)PV_DW * (size_t)(T.ngroups + 1));
+    h->pv_tinfo_h = (int *)malloc(sizeof(int) * 4 * (size_t)(T.ntiles + 1));
+    h->pv_blk_h = (int *)malloc(sizeof(int) * 2 * (size_t)nb);
+    if (h->pv_grp && h->pv_tinfo_h && h->pv_blk_h) {
+      memcpy(h->pv_grp, T.seq, sizeof(int) * (size_t)PV_DW * (size_t)T.ngroups);
+      memcpy(h->pv_tinfo_h, T.tinfo, sizeof(int) * 4 * (size_t)T.ntiles);
+      memcpy(h->pv_blk_h, T.blk, sizeof(int) * 2 * (size_t)nb);
+      h->pv_ngrp = T.ngroups;
+    } else { free(h->pv_grp); free(h->pv_tinfo_h); free(h->pv_blk_h); h->pv_grp = h->pv_tinfo_h = h->pv_blk_h = 0; h->pv_ngrp = 0; }
   }
   prod_tiles_free(&T);
+}
+
+int rldl_stage_prog_prefix(const rldl_batch *h, int nb_act, int **d_prog, int *nsteps) {
+  const rldl_dev_stage *G;
+  int nb, g_act, NGp, i, b, kind, *seq;
+  if (!h || !d_prog || !nsteps) return 1;
+  G = &h->dsym.stage; nb = G->nb;
+  if (!G->pv_ok || !h->pv_grp || nb_act < 1 || nb_act > nb) return 1;
+  g_act = h->pv_ngrp;                                            /* groups of the tiles D_0, C_0, ..., D_{nb_act - 1}: everything before the first tile left out */
+  for (b = nb_act - 1; b < nb && g_act == h->pv_ngrp; b++)
+    for (kind = (b == nb_act - 1 ? 1 : 0); kind < 2; kind++) {
+      const int t = h->pv_blk_h[2 * b + kind];
+      if (t >= 0) { g_act = h->pv_tinfo_h[4 * t + 3]; break; }
+    }
+  NGp = ((g_act + RLDL_PV_RING - 1) / RLDL_PV_RING) * RLDL_PV_RING;
+  seq = (int *)calloc((size_t)PV_DW * (size_t)(2 * NGp + 2 * RLDL_PV_RING), sizeof(int));
+  if (!seq) return 1;
+  for (i = 0; i < g_act; i++) memcpy(seq + PV_DW * i, h->pv_grp + PV_DW * i, sizeof(int) * PV_DW);
+  for (i = 0; i < g_act; i++) memcpy(seq + PV_DW * (NGp + i), h->pv_grp + PV_DW * (g_act - 1 - i), sizeof(int) * PV_DW);
+  *d_prog = upload_ints(seq, (size_t)PV_DW * (size_t)(2 * NGp + 2 * RLDL_PV_RING));
+  free(seq);
+  if (!*d_prog) return 1;
+  *nsteps = 2 * NGp;
+  return 0;
 }
 
 /* Host part of the stage-block view: block starts and, per block, the entries of the permuted KKT matrix and of L that fall into

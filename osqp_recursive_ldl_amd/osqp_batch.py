@@ -107,8 +107,9 @@ class OSQPBatch:
             raise RuntimeError("osqp_batch_wait failed (%d)" % rc)
         return self.results(clone=clone)
 
-    def _view(self, ptr, shape, dtype):
-        """Zero-copy torch view of a workspace-owned device array (valid until cleanup)."""
+    def _view(self, ptr, shape, dtype, ld=None):
+        """Zero-copy torch view of a workspace-owned device array (valid until cleanup).  ld: row stride in elements when the rows
+        of the array are longer than shape[1] (single-store horizon handles)."""
         import torch
         count = int(np.prod(shape))
         if count == 0:
@@ -119,9 +120,9 @@ class OSQPBatch:
             pass
         a = _Arr()
         typestr = {torch.float64: "<f8", torch.int32: "<i4"}[dtype]
+        strides = None if ld is None or len(shape) != 2 or ld == shape[1] else (int(ld) * itemsize, itemsize)
         a.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2,
-                                      "strides": None}
-        del itemsize
+                                      "strides": strides}
         return torch.as_tensor(a, device=self._device)
 
     def results(self, clone=True):
@@ -129,14 +130,15 @@ class OSQPBatch:
         p = [C.c_void_p() for _ in range(8)]
         _lib.lib().osqp_batch_get(self.h, *[C.byref(t) for t in p])
         B, n, m = self.batch, self.n, self.m
-        out = dict(x=self._view(p[0].value, (B, n), torch.float64), y=self._view(p[1].value, (B, m), torch.float64),
-                   z=self._view(p[2].value, (B, m), torch.float64), status=self._view(p[3].value, (B,), torch.int32),
+        ldn, ldm = getattr(self, "_ldn", None), getattr(self, "_ldm", None)
+        out = dict(x=self._view(p[0].value, (B, n), torch.float64, ldn), y=self._view(p[1].value, (B, m), torch.float64, ldm),
+                   z=self._view(p[2].value, (B, m), torch.float64, ldm), status=self._view(p[3].value, (B,), torch.int32),
                    iter=self._view(p[4].value, (B,), torch.int32), obj=self._view(p[5].value, (B,), torch.float64),
                    pri_res=self._view(p[6].value, (B,), torch.float64), dua_res=self._view(p[7].value, (B,), torch.float64))
         it = [C.c_void_p() for _ in range(5)]
         _lib.lib().osqp_batch_get_iterates(self.h, *[C.byref(t) for t in it])
-        out.update(x_iter=self._view(it[0].value, (B, n), torch.float64), y_iter=self._view(it[1].value, (B, m), torch.float64),
-                   delta_x=self._view(it[3].value, (B, n), torch.float64), delta_y=self._view(it[4].value, (B, m), torch.float64))
+        out.update(x_iter=self._view(it[0].value, (B, n), torch.float64, ldn), y_iter=self._view(it[1].value, (B, m), torch.float64, ldm),
+                   delta_x=self._view(it[3].value, (B, n), torch.float64, ldn), delta_y=self._view(it[4].value, (B, m), torch.float64, ldm))
         ps = C.c_void_p()
         _lib.lib().osqp_batch_get_polish_status(self.h, C.byref(ps))
         out["status_polish"] = self._view(ps.value, (B,), torch.int32)
@@ -234,6 +236,36 @@ def _csc_to_scipy(M):
     return sparse.csc_matrix((x, i, p), shape=(m, n))
 
 
+def _pad(M, shape):
+    """M in the top-left corner of a zero matrix of the given shape"""
+    from scipy import sparse
+    M = sparse.coo_matrix(M)
+    return sparse.csc_matrix((M.data, (M.row, M.col)), shape=shape)
+
+
+class _HorizonStoreView(OSQPBatch):
+    """The current horizon of a single-store OSQPHorizon seen as an OSQPBatch: n, m, P, A are the horizon's own; values and iterates
+    go in through the horizon handle (packed arrays in the horizon's value order and sizes), results come out as strided views of
+    the store's Nmax-sized rows."""
+
+    def update_P_A(self, Px=None, Ax=None, wait=True):
+        _dev_f64(Px, (self.batch, self.P.nnz), "Px"); _dev_f64(Ax, (self.batch, self.A.nnz), "Ax")
+        return int(_lib.lib().osqp_horizon_update_P_A(self._hz.h, _dptr(Px), _dptr(Ax)))
+
+    def warm_start(self, x, y):
+        _dev_f64(x, (self.batch, self.n), "x"); _dev_f64(y, (self.batch, self.m), "y")
+        return int(_lib.lib().osqp_horizon_warm_start(self._hz.h, _dptr(x), _dptr(y)))
+
+    def linsys(self):
+        P, A = self._hz.store_patterns()
+        return BatchLinsys(CscPattern(P), CscPattern(A), None, None, 0, None, _handle=_lib.lib().osqp_batch_linsys(self.h), _owned=False)
+
+    def update_lin_cost(self, q):
+        raise NotImplementedError("single-store horizon: q, l, u are set by OSQPHorizon.update")
+
+    update_bounds = update_lin_cost
+
+
 class OSQPHorizon:
     """Variable-horizon MPC (osqp_setup_recursive with Nmax + osqp_update_recursive, src/recursive_ldl.c:2018-2230,
     :1973-2016): the batch is set up at horizon dims[0] and moves anywhere in 1..Nmax with `update`.  `workspace` is the
@@ -277,10 +309,43 @@ class OSQPHorizon:
         return P, A
 
     @property
+    def single_store(self):
+        """True when ONE workspace at Nmax dimensions serves every horizon (scaling = 0, product tri-solve available)."""
+        return bool(_lib.lib().osqp_horizon_is_single(self.h))
+
+    @property
+    def n_workspaces(self):
+        """Resident numeric workspaces: 1 with the single store, one per visited horizon otherwise."""
+        return int(_lib.lib().osqp_horizon_workspaces(self.h))
+
+    def store_patterns(self):
+        """Single store: the assembled P / A patterns of the one workspace (Nmax stages, interior blocks = the unions Qi + QN on
+        the state part and Ai + AN in the first nt rows)."""
+        from scipy import sparse
+        L = _lib.lib()
+        _, nx, nu, ny, nt = self.dims
+        Q0, Qi, QN, A0, Ai, Aij, AN = [sparse.csc_matrix((np.ones(b.nnz), b.i, b.p), shape=b.shape) for b in self._blocks]
+
+        def struct(M):
+            M = sparse.csc_matrix(M).copy(); M.data[:] = 1.0; return M
+        Qi_u = sparse.triu(sparse.csc_matrix(struct(Qi) + _pad(struct(QN), Qi.shape)), format="csc")
+        Ai_u = sparse.csc_matrix(struct(Ai) + _pad(struct(AN), Ai.shape))
+        blocks = [CscPattern(sparse.triu(struct(Q0), format="csc")), CscPattern(Qi_u), CscPattern(sparse.triu(struct(QN), format="csc")),
+                  CscPattern(struct(A0)), CscPattern(Ai_u), CscPattern(struct(Aij)), CscPattern(struct(AN))]
+        sd = _lib.StageDims(self.Nmax, nx, nu, ny, nt)
+        Pp, Ap = C.POINTER(_lib.Csc)(), C.POINTER(_lib.Csc)()
+        _lib.check(L.rldl_setup_AP_matrices(C.byref(sd), *[b.ref for b in blocks], C.byref(Pp), C.byref(Ap),
+                                            None, None, None, None, None, None), "rldl_setup_AP_matrices")
+        P, A = _csc_to_scipy(Pp.contents), _csc_to_scipy(Ap.contents)
+        L.rldl_csc_free(Pp); L.rldl_csc_free(Ap)
+        return P, A
+
+    @property
     def workspace(self):
         N = self.N
         if N not in self._views:
-            w = OSQPBatch.__new__(OSQPBatch)
+            single = self.single_store
+            w = (_HorizonStoreView if single else OSQPBatch).__new__(_HorizonStoreView if single else OSQPBatch)
             w._owned = False
             w._stream = None
             w.h = C.c_void_p(_lib.lib().osqp_horizon_workspace(self.h))
@@ -291,6 +356,10 @@ class OSQPHorizon:
             w.settings = default_settings()
             C.memmove(C.byref(w.settings), C.byref(self.settings), C.sizeof(self.settings))
             w.status = 0
+            if single:
+                a, b = _lib.c_int(0), _lib.c_int(0)
+                _lib.lib().osqp_horizon_ld(self.h, C.byref(a), C.byref(b))
+                w._ldn, w._ldm, w._hz = int(a.value), int(b.value), self
             self._views[N] = w
         return self._views[N]
 

@@ -187,30 +187,50 @@ def horizon_change():
     torch.cuda.synchronize()
     emit(name="horizon_setup_from_scratch_N20", batch=B, wall_ms=1e3 * (time.perf_counter() - t0))
     fresh.cleanup()
-    hz = R.OSQPHorizon(wl[19].dims, Nmax, *blocks(wl[19]), *data[19], **kw)
-    hz.workspace.update_P_A(t(np.tile(Px, (B // 8, 1))), t(np.tile(Ax, (B // 8, 1))))
-    hz.workspace.solve(clone=False)
+    for store in ("single", "multi"):                            # one workspace at Nmax dimensions / a workspace per visited horizon
+        os.environ.pop("RLDL_HORIZON_MULTI", None)
+        if store == "multi":
+            os.environ["RLDL_HORIZON_MULTI"] = "1"
+        torch.cuda.synchronize()
+        free0 = torch.cuda.mem_get_info()[0]
+        hz = R.OSQPHorizon(wl[19].dims, Nmax, *blocks(wl[19]), *data[19], **kw)
+        hz.workspace.update_P_A(t(np.tile(Px, (B // 8, 1))), t(np.tile(Ax, (B // 8, 1))))
+        hz.workspace.solve(clone=False)
 
-    def change(N):
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        rc = hz.update(N, *data[N])
-        torch.cuda.synchronize()
-        assert rc == 0
-        return 1e3 * (time.perf_counter() - t0)
-    first = change(20)
-    emit(name="horizon_change_first_visit", frm=19, to=20, batch=B, wall_ms=first, **hz.last_update())
-    for mode in ("adopt", "full"):
-        if mode == "full":
-            os.environ["RLDL_HORIZON_FULL"] = "1"
-        ts = {19: [], 20: []}
-        for _ in range(5):
-            ts[19].append(change(19)); info19 = hz.last_update()
-            ts[20].append(change(20)); info20 = hz.last_update()
-        emit(name="horizon_change_cached", mode=mode, batch=B, wall_ms_20_to_19=min(ts[19]), wall_ms_19_to_20=min(ts[20]),
-             reused_19=info19["instances_reused"], reused_20=info20["instances_reused"])
-    os.environ.pop("RLDL_HORIZON_FULL", None)
-    hz.free()
+        def change(N):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            rc = hz.update(N, *data[N])
+            torch.cuda.synchronize()
+            assert rc == 0
+            return 1e3 * (time.perf_counter() - t0)
+        first = change(20)
+        emit(name="horizon_change_first_visit", store=store, single_store=hz.single_store, frm=19, to=20, batch=B, wall_ms=first, **hz.last_update())
+        for mode in ("adopt", "full") if store == "multi" else ("restart",):
+            if mode == "full":
+                os.environ["RLDL_HORIZON_FULL"] = "1"
+            ts = {19: [], 20: []}
+            for _ in range(5):
+                ts[19].append(change(19)); info19 = hz.last_update()
+                ts[20].append(change(20)); info20 = hz.last_update()
+            torch.cuda.synchronize()
+            emit(name="horizon_change_cached", store=store, mode=mode, batch=B, wall_ms_20_to_19=min(ts[19]), wall_ms_19_to_20=min(ts[20]),
+                 reused_19=info19["instances_reused"], reused_20=info20["instances_reused"], workspaces=hz.n_workspaces,
+                 device_MB_held=(free0 - torch.cuda.mem_get_info()[0]) / 1e6)
+        os.environ.pop("RLDL_HORIZON_FULL", None)
+        if store == "single":                                    # a far move on the same store: 20 -> 5 -> 20 (cost follows the live blocks)
+            _, _, q5, l5, u5 = R.workloads.MPCStageQPs(N=5).values(8)
+            d5 = [t(np.tile(a, (B // 8, 1))) for a in (q5, l5, u5)]
+            torch.cuda.synchronize(); t0 = time.perf_counter(); assert hz.update(5, *d5) == 0; torch.cuda.synchronize()
+            down = 1e3 * (time.perf_counter() - t0)
+            ms5 = timed(lambda: hz.workspace.solve(clone=False), reps=3)
+            torch.cuda.synchronize(); t0 = time.perf_counter(); assert hz.update(20, *data[20]) == 0; torch.cuda.synchronize()
+            up = 1e3 * (time.perf_counter() - t0)
+            ms20 = timed(lambda: hz.workspace.solve(clone=False), reps=3)
+            emit(name="horizon_single_store_far_move", batch=B, wall_ms_20_to_5=down, wall_ms_5_to_20=up, solve_ms_200_iterations_N5=ms5,
+                 solve_ms_200_iterations_N20=ms20, workspaces=hz.n_workspaces)
+        hz.free()
+    os.environ.pop("RLDL_HORIZON_MULTI", None)
 
 
 if __name__ == "__main__":

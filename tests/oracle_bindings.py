@@ -119,6 +119,8 @@ def lib():
         L.orc_rldl_factor.argtypes = [C.POINTER(StageDims), C.POINTER(Csc), C.POINTER(Csc), c_float, FP, c_int, c_int, c_int, c_int, FP,
                                       IP, IP, FP, c_int, FP, IP]
         L.orc_rldl_factor.restype = c_int
+        L.orc_rldl_border.argtypes = [c_int, IP, IP, FP, FP, c_int, FP, FP, FP, FP]
+        L.orc_rldl_border.restype = None
         _lib = L
     return _lib
 
@@ -268,6 +270,18 @@ class OracleRLDL:
         from scipy import sparse
         Nk = self.n + self.m
         return sparse.csc_matrix((self.Lx[:self.nnz].copy(), self.Li[:self.nnz].copy(), self.Lp.copy()), shape=(Nk, Nk))
+
+
+def rldl_border(Lp, Li, Lx, Dinv, V, Y):
+    """compute_Vhat's border algebra (oracle/rldl_oracle.c: orc_rldl_border): (V^ = V L^-T D^-1, Y^ = Y - V^ D V^') for the rows V
+    (dense [nrows, nf]) of a block coupled to a factorised part (strictly lower CSC L, Dinv, nf x nf)."""
+    nf, nrows = len(Dinv), V.shape[0]
+    Lp = np.ascontiguousarray(Lp, np.int64); Li = np.ascontiguousarray(Li, np.int64); Lx = np.ascontiguousarray(Lx, np.float64)
+    Dv = np.ascontiguousarray(Dinv, np.float64)
+    Vc = np.ascontiguousarray(V, np.float64); Yc = np.ascontiguousarray(Y, np.float64)
+    Vh, Yh = np.zeros_like(Vc), np.zeros_like(Yc)
+    lib().orc_rldl_border(nf, ip(Lp), ip(Li), fp(Lx), fp(Dv), nrows, fp(Vc), fp(Yc), fp(Vh), fp(Yh))
+    return Vh, Yh
 
 
 class OracleOSQP:

@@ -30,6 +30,51 @@ def reused(count):
     return 0 if (os.environ.get("RLDL_HORIZON_FULL") or os.environ.get("RLDL_NO_STAGE_FACTOR")) else count
 
 
+@pytest.fixture(params=["single", "multi"])
+def mode(request, monkeypatch):
+    """single: ONE workspace at Nmax dimensions for every horizon (the default when scaling = 0 and the product tri-solve is
+    available); multi: a workspace per visited horizon (RLDL_HORIZON_MULTI=1, also what scaling > 0 gets)."""
+    if request.param == "multi":
+        monkeypatch.setenv("RLDL_HORIZON_MULTI", "1")
+    return request.param
+
+
+def dense_factor(ls, b):
+    """(L strictly lower as a dense matrix in permuted coordinates, D) of instance b"""
+    sym, f = ls.export_symbolic(), ls.export_factor(b)
+    N = len(sym["perm"])
+    L = np.zeros((N, N))
+    Lp, Li = sym["Lp"], sym["Li"]
+    for c in range(N):
+        L[Li[Lp[c]:Lp[c + 1]], c] = f["Lx"][Lp[c]:Lp[c + 1]]
+    return L, f["D"], (Lp, Li)
+
+
+def assert_same_factor(hz, wl, Nnew, store_ls, fresh_ls, B):
+    """The factor of the live blocks of the store equals the factor of a from-scratch workspace at the new horizon BIT FOR BIT.
+    Permuted positions agree up to the state part of the terminal cost block; the nt terminal rows sit nu positions further in the
+    store (behind the dummy inputs of stage Nnew)."""
+    if not hz.single_store:
+        for b in range(B):
+            fa, fb = store_ls.export_factor(b), fresh_ls.export_factor(b)
+            assert np.array_equal(fa["Lx"], fb["Lx"]) and np.array_equal(fa["D"], fb["D"]) and np.array_equal(fa["Dinv"], fb["Dinv"])
+        return
+    nx, nu, ny, nt = wl.nx, wl.nu, wl.ny, wl.nt
+    Nt = Nnew * (nx + nu) + Nnew * (nx + ny) + nt                   # KKT dimension of the true horizon
+    first_term = Nt - nt
+    idx = np.arange(Nt)
+    if Nnew < hz.Nmax:
+        idx[first_term:] += nu
+    for b in range(B):
+        Ls, Ds, _ = dense_factor(store_ls, b)
+        Lf, Df, (Lp, Li) = dense_factor(fresh_ls, b)
+        assert Lf.shape[0] == Nt
+        for c in range(Nt):
+            r = Li[Lp[c]:Lp[c + 1]]
+            assert np.array_equal(Ls[idx[r], idx[c]], Lf[r, c]), (b, c)
+        assert np.array_equal(Ds[idx], Df)
+
+
 def blocks(wl):
     return wl.Q0, wl.Qi, wl.QN, wl.A0, wl.Ai, wl.Aij, wl.AN
 
@@ -62,7 +107,7 @@ def mapped_iterates(wl, Nold, Nnew, x, y):
     return xn, yn
 
 
-def test_grow_horizon_factor_bit_exact_and_solve_matches_fresh_workspace_and_oracle():
+def test_grow_horizon_factor_bit_exact_and_solve_matches_fresh_workspace_and_oracle(mode):
     import osqp_recursive_ldl_amd as R
     B, N0, N1 = 4, 4, 6
     w0, w1 = R.workloads.MPCStageQPs(N=N0), R.workloads.MPCStageQPs(N=N1)
@@ -79,20 +124,24 @@ def test_grow_horizon_factor_bit_exact_and_solve_matches_fresh_workspace_and_ora
     assert hz.update(N0, dev(q0), dev(l0), dev(u0)) == 0 and hz.N == N0
     assert hz.update(N1, dev(q1), dev(l1), dev(u1)) == 0
     info = hz.last_update()
-    assert hz.N == N1 and info["pivot_stage"] == N0 and info["workspace_created"]
+    assert hz.single_store == (mode == "single") or reused(1) == 0
+    single = hz.single_store
+    assert hz.N == N1 and info["pivot_stage"] == N0 and info["workspace_created"] == (not single)
     assert info["instances_reused"] == reused(B)             # every instance restarted at stage N0
+    assert hz.n_workspaces == (1 if single else 2)            # the single store: one numeric workspace whatever the horizon
     wn = hz.workspace
     assert (wn.n, wn.m) == (w1.n, w1.m)
     Pn, An, Pxe, Axe = carried_values(hz, w0, N0, N1, Px0, Ax0)
     fresh = R.OSQPBatch.recursive(w1.dims, *blocks(w1), dev(q1), dev(l1), dev(u1), **kw)
     assert fresh.update_P_A(dev(Pxe), dev(Axe)) == 0
-    for b in range(B):
-        fa, fb = wn.linsys().export_factor(b), fresh.linsys().export_factor(b)
-        assert np.array_equal(fa["Lx"], fb["Lx"]) and np.array_equal(fa["D"], fb["D"]) and np.array_equal(fa["Dinv"], fb["Dinv"])
+    assert_same_factor(hz, w1, N1, wn.linsys(), fresh.linsys(), B)
     x0, y0 = mapped_iterates(w1, N0, N1, r0["x_iter"].cpu().numpy(), r0["y_iter"].cpu().numpy())
     assert fresh.warm_start(dev(x0), dev(y0)) == 0
     ra, rb = wn.solve(), fresh.solve()
-    assert torch.equal(ra["x"], rb["x"]) and torch.equal(ra["y"], rb["y"])
+    if single:                                                 # (the store's tiles carry the union pattern: other summation order inside a row)
+        assert relerr(ra["x"].cpu().numpy(), rb["x"].cpu().numpy()) < 1e-11 and relerr(ra["y"].cpu().numpy(), rb["y"].cpu().numpy()) < 1e-11
+    else:
+        assert torch.equal(ra["x"], rb["x"]) and torch.equal(ra["y"], rb["y"])
     perm = R.workloads.stage_permutation(*w1.dims)
     from scipy import sparse
     for b in range(B):
@@ -106,7 +155,7 @@ def test_grow_horizon_factor_bit_exact_and_solve_matches_fresh_workspace_and_ora
     fresh.cleanup(); hz.free()
 
 
-def test_shrink_then_return_with_adaptive_rho_matches_oracle():
+def test_shrink_then_return_with_adaptive_rho_matches_oracle(mode):
     """Horizon 6 -> 3 -> 6 (the second move lands on the cached workspace): rho is per instance after adapt_rho and
     travels with the instance; status / iteration count / solution equal the oracle set up at the new horizon with
     that rho and the mapped warm start."""
@@ -129,7 +178,8 @@ def test_shrink_then_return_with_adaptive_rho_matches_oracle():
         assert hz.update(Nnew, dev(q), dev(l), dev(u)) == 0
         info = hz.last_update()
         assert info["pivot_stage"] == 3 and info["instances_reused"] == reused(B)
-        assert info["workspace_created"] == (Nnew == 3)
+        assert info["workspace_created"] == (Nnew == 3 and not hz.single_store)
+        assert hz.n_workspaces == (1 if hz.single_store else 2)
         Pn, An, Pxe, Axe = carried_values(hz, wl[6], Nold, Nnew, Px_cur, Ax_cur)
         x0, y0 = mapped_iterates(wl[6], Nold, Nnew, r["x_iter"].cpu().numpy(), r["y_iter"].cpu().numpy())
         r = hz.workspace.solve()
@@ -147,7 +197,7 @@ def test_shrink_then_return_with_adaptive_rho_matches_oracle():
     hz.free()
 
 
-def test_instance_whose_constraint_type_changes_is_refactorised_from_the_first_stage():
+def test_instance_whose_constraint_type_changes_is_refactorised_from_the_first_stage(mode):
     """rho_vec of the shared rows is part of the shared factor: an instance that turns an inequality row of a kept stage
     into an equality (rho_vec 1e3 rho there, auxil.c:88-91) cannot adopt the old columns and is factorised from block 0;
     the others restart at the pivot.  Either way the factor equals the from-scratch one."""
@@ -166,11 +216,12 @@ def test_instance_whose_constraint_type_changes_is_refactorised_from_the_first_s
     _, _, Pxe, Axe = carried_values(hz, w0, N0, N1, Px0, Ax0)
     fresh = R.OSQPBatch.recursive(w1.dims, *blocks(w1), dev(q1), dev(l1), dev(u1), **kw)
     assert fresh.update_P_A(dev(Pxe), dev(Axe)) == 0
-    for b in range(B):
-        fa, fb = hz.workspace.linsys().export_factor(b), fresh.linsys().export_factor(b)
-        assert np.array_equal(fa["Lx"], fb["Lx"]) and np.array_equal(fa["D"], fb["D"])
+    assert_same_factor(hz, w1, N1, hz.workspace.linsys(), fresh.linsys(), B)
     ra, rb = hz.workspace.solve(), fresh.solve()
-    assert torch.equal(ra["x"], rb["x"]) and torch.equal(ra["y"], rb["y"])
+    if hz.single_store:
+        assert relerr(ra["x"].cpu().numpy(), rb["x"].cpu().numpy()) < 1e-11 and relerr(ra["y"].cpu().numpy(), rb["y"].cpu().numpy()) < 1e-11
+    else:
+        assert torch.equal(ra["x"], rb["x"]) and torch.equal(ra["y"], rb["y"])
     fresh.cleanup(); hz.free()
 
 
@@ -208,3 +259,57 @@ def test_horizon_change_with_equilibration_matches_fresh_workspace_and_oracle():
         assert int(ra["status"][b]) == ro["status"] == 1 and int(ra["iter"][b]) == ro["iter"]
         assert relerr(ra["x"][b].cpu().numpy(), ro["x"]) < 1e-7
     fresh.cleanup(); hz.free()
+
+
+def test_single_store_walks_every_horizon_with_one_workspace():
+    """1 .. Nmax and back on ONE workspace: after every move the factor of the live blocks is bit-identical to a from-scratch setup at
+    that horizon with the carried values, the dummy stages behind the horizon stay exactly zero, and the solve agrees with the oracle
+    set up at that horizon (same warm start)."""
+    import osqp_recursive_ldl_amd as R
+    from scipy import sparse
+    B, Nmax = 3, 5
+    wl = {N: R.workloads.MPCStageQPs(N=N) for N in range(1, Nmax + 1)}
+    kw = dict(rho=0.1, sigma=1e-6, alpha=1.6, max_iter=60, check_termination=0, adaptive_rho=0, warm_start=1, scaling=0)
+    N = 2
+    Px, Ax, q, l, u = wl[N].values(B, seed0=5)
+    hz = R.OSQPHorizon(wl[N].dims, Nmax, *blocks(wl[N]), dev(q), dev(l), dev(u), **kw)
+    if not hz.single_store:
+        pytest.skip("a kernel-selection switch keeps the per-horizon workspaces")
+    assert hz.workspace.update_P_A(dev(Px), dev(Ax)) == 0
+    r = hz.workspace.solve()
+    for Nnew in (5, 1, 4, 3, 5, 2):
+        _, _, qn, ln, un = wl[Nnew].values(B, seed0=40 + Nnew)
+        assert hz.update(Nnew, dev(qn), dev(ln), dev(un)) == 0
+        info = hz.last_update()
+        assert hz.n_workspaces == 1 and not info["workspace_created"] and info["pivot_stage"] == min(N, Nnew) and info["instances_reused"] == B
+        Pn, An, Px, Ax = carried_values(hz, wl[N], N, Nnew, Px, Ax)
+        fresh = R.OSQPBatch.recursive(wl[Nnew].dims, *blocks(wl[Nnew]), dev(qn), dev(ln), dev(un), **kw)
+        assert fresh.update_P_A(dev(Px), dev(Ax)) == 0
+        assert_same_factor(hz, wl[Nnew], Nnew, hz.workspace.linsys(), fresh.linsys(), B)
+        fresh.cleanup()
+        x0, y0 = mapped_iterates(wl[Nnew], N, Nnew, r["x_iter"].cpu().numpy(), r["y_iter"].cpu().numpy())
+        w = hz.workspace
+        assert (w.n, w.m) == (wl[Nnew].n, wl[Nnew].m)
+        r = w.solve()
+        full = OSQP_full_rows(w)
+        assert float(full["x"][:, w.n:].abs().max() if full["x"].shape[1] > w.n else 0.0) == 0.0      # dummy variables and multipliers stay exactly 0
+        assert float(full["y"][:, w.m:].abs().max() if full["y"].shape[1] > w.m else 0.0) == 0.0
+        perm = R.workloads.stage_permutation(*wl[Nnew].dims)
+        for b in range(B):
+            P = sparse.csc_matrix((Px[b], Pn.indices, Pn.indptr), shape=Pn.shape)
+            A = sparse.csc_matrix((Ax[b], An.indices, An.indptr), shape=An.shape)
+            o = ob.OracleOSQP(P, qn[b], A, ln[b], un[b], perm=perm, **kw)
+            o.warm_start(x0[b], y0[b])
+            ro = o.solve()
+            assert relerr(r["x"][b].cpu().numpy(), ro["x_iter"]) < 1e-8 and relerr(r["y"][b].cpu().numpy(), ro["y_iter"]) < 1e-8
+        N = Nnew
+    hz.free()
+
+
+def OSQP_full_rows(w):
+    """x_iter / y_iter rows of a single-store view at their full (Nmax) length"""
+    import ctypes as C
+    from osqp_recursive_ldl_amd import _lib
+    it = [C.c_void_p() for _ in range(5)]
+    _lib.lib().osqp_batch_get_iterates(w.h, *[C.byref(t) for t in it])
+    return dict(x=w._view(it[0].value, (w.batch, w._ldn), torch.float64), y=w._view(it[1].value, (w.batch, w._ldm), torch.float64))

@@ -111,3 +111,37 @@ def test_coupling_other_than_minus_identity_is_refused():
     A2[ny, nu] = -2.0
     A2 = A2.tocsc()
     assert ob.OracleRLDL(wl.dims).factor(P, A2, SIGMA, ri) == -3
+
+
+@pytest.mark.parametrize("N,Nx", [(2, 1), (7, 3), (7, 6), (12, 5)])
+def test_border_algebra_of_the_combined_variant_is_the_restart_block_of_the_recursion(N, Nx):
+    """The reference's "combined" X / Z / Y variant (osqp_setup_combine_recursive :2359-2756, osqp_update_Z_horizon :2761-2856) keeps a
+    finished factor and borders it: V^ = V L^-T D^-1 (compute_Vhat :253-292), Y^ = Y - V^ D V^' (:294-303), then factorises Y^.
+    With the stage-interleaved order the bordered block is the cost block of stage Nx (block 2 Nx of Q0, C0, Q1, ...): its border
+    rows V couple it to the factorised blocks 0 .. 2 Nx - 1 (only to the constraint block of stage Nx - 1).  The restatement of that
+    algebra (orc_rldl_border) must give (1) V^ = the coupling rows L(2 Nx, :) of the full stage recursion and (2) Y^ = L_bb D_b L_bb',
+    the Schur block the recursion forms and factorises when it reaches block 2 Nx -- which is why restarting the recursion at a block
+    IS the Z / V^ / Y^ rebuild of a horizon change (what rldl_horizon.c's single store does)."""
+    wl, P, A, ri = problem(N)
+    o = ob.OracleRLDL(wl.dims)
+    assert o.factor(P, A, SIGMA, ri) > 0
+    Kp = kkt(P, A, ri)[np.ix_(o.perm, o.perm)]
+    nx, nu, ny = wl.nx, wl.nu, wl.ny
+    c0 = nu + (nx + ny) + (Nx - 1) * (2 * nx + nu + ny)                 # first permuted index of block 2 Nx (cost block of stage Nx)
+    s = nx if Nx == N else nx + nu
+    L = o.L().tocsc()
+    Lf = L[:c0, :c0].tocsc()                                            # the finished factor: blocks before the bordered one
+    Lf.sort_indices()
+    V, Y = Kp[c0:c0 + s, :c0], Kp[c0:c0 + s, c0:c0 + s]
+    Vh, Yh = ob.rldl_border(Lf.indptr, Lf.indices, Lf.data, o.Dinv[:c0], V, Y)
+    Lrow = L[c0:c0 + s, :c0].toarray()
+    assert np.max(np.abs(Vh - Lrow)) <= 1e-12 * max(1.0, np.max(np.abs(Lrow)))
+    prev = c0 - (nx + ny)
+    assert np.count_nonzero(Vh[:, :prev]) == 0 and np.count_nonzero(Vh[:, prev:]) > 0   # the border reaches the previous constraint block only
+    Lbb = L[c0:c0 + s, c0:c0 + s].toarray() + np.eye(s)
+    Sb = Lbb @ np.diag(1.0 / o.Dinv[c0:c0 + s]) @ Lbb.T
+    assert np.max(np.abs(Yh - Sb)) <= 1e-12 * np.max(np.abs(Sb))
+    # and the algebra is the Schur complement it claims to be: Y^ = Y - V D_f^-1... against numpy
+    Ld = Lf.toarray() + np.eye(c0)
+    W = np.linalg.solve(Ld, V.T)
+    assert np.max(np.abs(Yh - (Y - W.T @ np.diag(o.Dinv[:c0]) @ W))) <= 1e-11 * np.max(np.abs(Sb))
