@@ -466,8 +466,8 @@ c_int rldl_batch_export_prod(const rldl_batch *h, c_int inst, c_int *meta, int *
   memset(meta, 0, sizeof(c_int) * 8);
   if (!G->pv_ok || !h->num.Ti) return 1;
   if (!HIP_OK(hipStreamSynchronize((hipStream_t)h->stream))) return 1;
-  meta[0] = 1; meta[1] = G->pv_ntiles; meta[2] = G->pv_ntab; meta[3] = G->pv_nTi; meta[4] = G->nb; meta[5] = G->pv_ldT; meta[6] = G->pv_kmax;
-  meta[7] = G->pv_nsteps;
+  meta[0] = G->pv_mode == 2 ? 2 : 1; meta[1] = G->pv_ntiles; meta[2] = G->pv_ntab; meta[3] = G->pv_nTi; meta[4] = G->nb; meta[5] = G->pv_ldT; meta[6] = G->pv_kmax;
+  meta[7] = G->pv_nsteps;                                        /* meta[0]: 1 = mode-1 tables (L(b+1, b) in the coupling tiles), 2 = mode 2 (K(b+1, b)) */
   if (prog && !HIP_OK(hipMemcpy(prog, G->pv_prog, sizeof(int) * 12 * (size_t)G->pv_nsteps, hipMemcpyDeviceToHost))) return 1;
   if (tinfo && !HIP_OK(hipMemcpy(tinfo, G->pv_tinfo, sizeof(int) * 4 * (size_t)(G->pv_ntiles + 1), hipMemcpyDeviceToHost))) return 1;
   if (tab && !HIP_OK(hipMemcpy(tab, G->pv_tab, sizeof(unsigned) * (size_t)G->pv_ntab, hipMemcpyDeviceToHost))) return 1;

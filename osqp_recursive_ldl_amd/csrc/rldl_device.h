@@ -52,6 +52,10 @@ typedef struct {
   const int *pv_prog, *pv_tinfo, *pv_blk, *pv_dpos, *pv_cptr, *pv_cidx;
   const unsigned short *pv_src;
   int pv_ok, pv_ntiles, pv_ngroups, pv_nsteps, pv_kmax, pv_nTi, pv_ldTi, pv_ntab, pv_ldT;
+  /* pv_mode 2: the coupling tiles hold the ORIGINAL coupling blocks K(b+1, b) of the permuted KKT matrix (pv_src = Kx index) instead of
+   * L(b+1, b) = K(b+1, b) L_bb^-T D_b^-1; every diagonal tile is then used twice per pass while it sits in its ring slot, with an
+   * auxiliary block vector at byte offset pv_aux behind x in the wave's LDS (step kinds: rldl_recursive.c, pv_sequence) */
+  int pv_mode, pv_aux;
 } rldl_dev_stage;
 
 typedef struct {

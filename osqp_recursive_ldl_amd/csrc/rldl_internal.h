@@ -22,7 +22,7 @@ struct rldl_batch {
   int *pv_tiD;             /* host, stage handles with product tiles: first Ti entry of every diagonal block's tile [nb + 1] */
   /* host copies of the product tri-solve's tables, for step programs over a prefix of the blocks (single-store horizon handles):
    * group descriptors in tile order [pv_ngrp][12], tile info [4 per tile], tile id of (block, kind) [2 nb] */
-  int *pv_grp, pv_ngrp, *pv_tinfo_h, *pv_blk_h;
+  int *pv_grp, pv_ngrp, pv_ntiles_h, *pv_tinfo_h, *pv_blk_h;
 };
 
 /* batched ADMM workspace (rldl_admm.c) */

@@ -1567,6 +1567,147 @@ __device__ __forceinline__ void stage_prod_solve(const rldl_dev_sym &S, const do
   wave_sync();
 }
 
+// ------------------------------------------------------------------------------------------------
+// stage_prod_solve2 (round 3, rldl_dev_stage.pv_mode == 2) -- the same chain of tile products on HALF the bytes.  The coupling block
+// of the factor is L(b+1, b) = K(b+1, b) L_bb^-T D_b^-1 with K(b+1, b) the ORIGINAL coupling block of the permuted KKT matrix (block
+// tridiagonal: no elimination touches it) -- a few dozen entries (a stage's A_k, the -I of the dynamics) against the dense
+// L(b+1, b).  So the coupling tiles hold K(b+1, b) and every diagonal tile is applied twice per pass while it sits in its ring slot:
+//   forward,  b ascending    [K-fwd: x_b -= K(b, b-1) a]    D-fwd: x_b <- L_bb^-1 x_b (= y_b);  a <- L_bb^-T D_b^-1 y_b
+//   backward, b descending   [K-bwd: a <- -K(b+1, b)' x_{b+1}]  D-bwd: a <- L_bb^-1 a;  x_b <- L_bb^-T D_b^-1 (x_b + a)
+// with a an auxiliary block vector (<= 32 doubles) behind x in the wave's LDS (y_b = L_bb^-1 (r_b - L(b, b-1) y_{b-1}) and its
+// transpose, regrouped).  Per solve a wave streams the D tiles and the sparse K tiles twice -- on the MPC shape of BASELINE config 3
+// about 57 KB per pass instead of 84.5 KB.  Same load pipeline as stage_prod_solve (groups of four steps, register ring, lane masks +
+// v_mbcnt, buffer loads, descriptors as a sequential program: rldl_recursive.c, pv_sequence); a ring slot carries one more value, the
+// lane's Dinv of the block (lanes < block size, D steps only).  A D tile of one group does both of its products from its one ring
+// slot; a tile of several groups is walked twice (pv_sequence).
+// ------------------------------------------------------------------------------------------------
+typedef unsigned pv_v4u __attribute__((ext_vector_type(4)));
+struct PvGrp2 { double v[4], d; unsigned w; };
+struct PvGI2 { int ti0, wo, rb, s; unsigned long long m[4]; };   // rb: byte offset of the block's first entry in x / Dinv (D steps), s: its size (0 for K steps)
+struct PvGC2 { int base, fl; unsigned long long m[4]; };
+__device__ __forceinline__ PvGI2 pv_gdesc_i2(sv_cptr_t q) {
+  PvGI2 d;
+  const int fl = q[3];
+  d.ti0 = q[0]; d.wo = q[1]; d.rb = (int)((unsigned)q[2] >> 16); d.s = (fl & 4) ? (fl >> 8) & 63 : 0;   // (kinds 1 and 3: bit 2)
+#pragma unroll
+  for (int j = 0; j < 4; j++) d.m[j] = pv_u64(q[4 + 2 * j], q[5 + 2 * j]);
+  return d;
+}
+__device__ __forceinline__ PvGC2 pv_gdesc_c2(sv_cptr_t q) {
+  PvGC2 d;
+  d.base = q[2]; d.fl = q[3];
+#pragma unroll
+  for (int j = 0; j < 4; j++) d.m[j] = pv_u64(q[4 + 2 * j], q[5 + 2 * j]);
+  return d;
+}
+__device__ __forceinline__ void pv_issue2(__amdgpu_buffer_rsrc_t rTi, __amdgpu_buffer_rsrc_t rTab, __amdgpu_buffer_rsrc_t rD, const PvGI2 &d,
+                                          unsigned lane4, PvGrp2 &P) {
+  unsigned sb = 8u * (unsigned)d.ti0;
+#pragma unroll
+  for (int pp = 0; pp < 2; pp++) {                                 // pair layout (rldl_recursive.c): the lane's entries of steps 2 pp, 2 pp + 1 side by side
+    const unsigned long long mk = d.m[2 * pp];
+    const unsigned mb = __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
+    const pv_v4u r = __builtin_amdgcn_raw_buffer_load_b128(rTi, pv_select(mk, (mb << 4) + sb, 0xffffffffu), 0, 0);
+    P.v[2 * pp] = __hiloint2double((int)r.y, (int)r.x);
+    P.v[2 * pp + 1] = __hiloint2double((int)r.w, (int)r.z);
+    sb += 16u * (unsigned)__builtin_popcountll(mk);
+  }
+  P.w = __builtin_amdgcn_raw_buffer_load_b32(rTab, lane4 + 4u * (unsigned)d.wo, 0, 0);
+  const pv_v2u rd = __builtin_amdgcn_raw_buffer_load_b64(rD, lane4 < 4u * (unsigned)d.s ? (unsigned)d.rb + 2u * lane4 : 0xffffffffu, 0, 0);
+  P.d = __hiloint2double((int)rd.y, (int)rd.x);
+}
+// one tile product: FWD  dst[rb + row] -= sum_j v_j src[cb + col_j]  (lanes of a row meet in one LDS atomic at the tile's last group),
+// else the transposed one  dst[cb + col_j] -= v_j src[rb + row]
+template <bool FWD>
+__device__ __forceinline__ void pv_prod2(char *xb, unsigned xb32, unsigned cb, unsigned rb, int fl, const unsigned long long (&m)[4], const PvGrp2 &P,
+                                         double &acc, double &own) {
+  const unsigned ra = rb + (__builtin_amdgcn_ubfe(P.w, 24, 5) << 3);
+  if (FWD) {
+    if (fl & 1) acc = 0.0;
+    double g[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) g[j] = lds_ld(xb, (__builtin_amdgcn_ubfe(P.w, 5 * j, 5) << 3) + cb);
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc = fma(P.v[j], g[j], acc);
+    if (fl & 2) pv_masked_add(__builtin_amdgcn_ballot_w64((P.w >> 29) & 1u), xb32 + ra, -acc);
+  } else {
+    if (fl & 2) own = lds_ld(xb, ra);
+#pragma unroll
+    for (int j = 0; j < 4; j++) pv_masked_add(m[j], (__builtin_amdgcn_ubfe(P.w, 5 * j, 5) << 3) + (xb32 + cb), -(P.v[j] * own));
+  }
+}
+__device__ __forceinline__ void pv_step2(char *xb, unsigned xb32, unsigned aux, const PvGC2 &d, const PvGrp2 &P, double &acc, double &own, int lane) {
+  const int kind = (d.fl >> 2) & 3, s = (d.fl >> 8) & 63;
+  const unsigned cb = (unsigned)d.base & 0xffffu, rb = (unsigned)d.base >> 16, l8 = 8u * (unsigned)lane;
+  if (kind == 0) {                                               // K-fwd: x_b -= K(b, b-1) a
+    pv_prod2<true>(xb, xb32, cb, rb, d.fl, d.m, P, acc, own);
+  } else if (kind == 2) {                                        // K-bwd: a <- -K(b+1, b)' x_{b+1}
+    if (d.fl & 2) {                                              // (the backward pass meets a tile's last group first)
+      if (lane < s) lds_st(xb, aux + l8, 0.0);
+      asm volatile("" ::: "memory");
+    }
+    pv_prod2<false>(xb, xb32, cb, rb, d.fl, d.m, P, acc, own);
+  } else if (kind == 1) {                                        // D-fwd: x_b <- L_bb^-1 x_b;  a <- L_bb^-T D_b^-1 x_b
+    const int f2 = (d.fl & 96) ? d.fl : 3;                         // (one-group tile: both halves from this slot)
+    if (!(d.fl & 64)) {
+      pv_prod2<true>(xb, xb32, rb, rb, f2, d.m, P, acc, own);
+      if (f2 & 2) {
+        asm volatile("" ::: "memory");
+        if (lane < s) lds_st(xb, aux + l8, P.d * lds_ld(xb, rb + l8));
+        asm volatile("" ::: "memory");
+      }
+    }
+    if (!(d.fl & 32)) pv_prod2<false>(xb, xb32, aux, aux, f2, d.m, P, acc, own);
+  } else {                                                       // D-bwd: a <- L_bb^-1 a;  x_b <- L_bb^-T D_b^-1 (x_b + a)
+    const int f2 = (d.fl & 96) ? d.fl : 3;
+    if (d.fl & 16) {                                             // no coupling tile below this block: a starts at 0
+      if (lane < s) lds_st(xb, aux + l8, 0.0);
+      asm volatile("" ::: "memory");
+    }
+    if (!(d.fl & 64)) {
+      pv_prod2<true>(xb, xb32, aux, aux, f2, d.m, P, acc, own);
+      if (f2 & 2) {
+        asm volatile("" ::: "memory");
+        if (lane < s) lds_st(xb, rb + l8, P.d * (lds_ld(xb, rb + l8) + lds_ld(xb, aux + l8)));
+        asm volatile("" ::: "memory");
+      }
+    }
+    if (!(d.fl & 32)) pv_prod2<false>(xb, xb32, rb, rb, f2, d.m, P, acc, own);
+  }
+}
+__device__ __forceinline__ void stage_prod_solve2(const rldl_dev_sym &S, const double *F, const double *Ti, double *xs, int lane) {
+  const rldl_dev_stage &G = S.stage;
+  const int NS = G.pv_nsteps;                                     // forward steps [0, NS / 2), backward steps [NS / 2, NS), both multiples of the ring
+  sv_cptr_t prog = (sv_cptr_t)(unsigned long long)G.pv_prog;
+  char *xb = reinterpret_cast<char *>(xs);
+  const unsigned xb32 = (unsigned)(unsigned long long)xb, aux = (unsigned)G.pv_aux;
+  const unsigned lane4 = 4u * (unsigned)lane;
+  const __amdgpu_buffer_rsrc_t rTi = __builtin_amdgcn_make_buffer_rsrc((void *)Ti, 0, 8 * G.pv_nTi, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rTab = __builtin_amdgcn_make_buffer_rsrc((void *)G.pv_tab, 0, 4 * G.pv_ntab, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rD = __builtin_amdgcn_make_buffer_rsrc((void *)(F + S.nS), 0, 8 * S.N, 0x00020000);
+  PvGrp2 P0, P1, P2, P3;
+  double acc = 0.0, own = 0.0;
+  {
+    const PvGI2 e0 = pv_gdesc_i2(prog), e1 = pv_gdesc_i2(prog + 12), e2 = pv_gdesc_i2(prog + 24);
+    pv_issue2(rTi, rTab, rD, e0, lane4, P0); pv_issue2(rTi, rTab, rD, e1, lane4, P1); pv_issue2(rTi, rTab, rD, e2, lane4, P2);
+  }
+  sv_cptr_t qI = prog + 12 * (RLDL_PV_RING - 1), qC = prog;
+  PvGI2 dI = pv_gdesc_i2(qI);
+  PvGC2 dC = pv_gdesc_c2(qC);
+#define PV2_STEP(PC, PN)                                                                                                        \
+  {                                                                                                                            \
+    qI += 12; qC += 12;                                                                                                        \
+    const PvGI2 nI = pv_gdesc_i2(qI);                                                                                          \
+    const PvGC2 nC = pv_gdesc_c2(qC);                                                                                          \
+    pv_issue2(rTi, rTab, rD, dI, lane4, PN);                                                                                   \
+    pv_step2(xb, xb32, aux, dC, PC, acc, own, lane);                                                                           \
+    dI = nI; dC = nC;                                                                                                          \
+  }
+  for (int s = 0; s < NS; s += RLDL_PV_RING) { PV2_STEP(P0, P3) PV2_STEP(P1, P0) PV2_STEP(P2, P1) PV2_STEP(P3, P2) }
+#undef PV2_STEP
+  wave_sync();
+}
+
 // k_stage_invert -- behind every stage factorisation of a handle with pv_ok: per diagonal block, L_bb goes from the factor's
 // slots into a dense LDS tile, lane c solves  L_bb X = e_c  by forward substitution with the rows of L_bb as LDS broadcast
 // reads (one address for all lanes, two entries per read), X goes back to LDS and its entries -X(r, c), r > c, to their places
@@ -1627,8 +1768,10 @@ __global__ __launch_bounds__(WAVE, 4) void k_stage_invert(rldl_dev_sym S, rldl_d
   load_idx(b0);
   {                                                              // coupling tiles L(b + 1, b), b >= b0: factor slot -> Ti, one flat list, eight rounds of loads in flight
     sv_cptr_t cpt = (sv_cptr_t)(unsigned long long)G.pv_cptr;
+    const double *Cs = G.pv_mode == 2 ? Nn.Kx + (size_t)inst * S.nnzK : F;   // mode 2: the coupling tiles hold the KKT matrix's own coupling blocks
     const int k1 = cpt[b0 < nb - 1 ? nb - 1 : b0];               // C_b for b0 <= b < nb - 1 (the last live block couples to nothing live)
-    for (int k0 = cpt[b0]; k0 < k1; k0 += 8 * WAVE) {
+    const int bc0 = G.pv_mode == 2 && b0 > 0 ? b0 - 1 : b0;      // (mode 2: K(b0, b0-1) is data of the restart block's own columns)
+    for (int k0 = cpt[bc0]; k0 < k1; k0 += 8 * WAVE) {
       int ti[8], sl[8];
       double v[8];
 #pragma unroll
@@ -1636,7 +1779,7 @@ __global__ __launch_bounds__(WAVE, 4) void k_stage_invert(rldl_dev_sym S, rldl_d
 #pragma unroll
       for (int u = 0; u < 8; u++) sl[u] = G.pv_src[ti[u]];
 #pragma unroll
-      for (int u = 0; u < 8; u++) v[u] = F[sl[u]];
+      for (int u = 0; u < 8; u++) { const double cv = Cs[sl[u] != 0xffff ? sl[u] : 0]; v[u] = sl[u] != 0xffff ? cv : 0.0; }   // (0xffff: padding slot of the pair layout)
 #pragma unroll
       for (int u = 0; u < 8; u++) if (k0 + u * WAVE + lane < k1) To[ti[u]] = v[u];
     }
@@ -1663,7 +1806,11 @@ __global__ __launch_bounds__(WAVE, 4) void k_stage_invert(rldl_dev_sym S, rldl_d
     else invert_block<SM>(T, X, ldT, lane, s);
     wave_sync();
 #pragma unroll
-    for (int r = 0; r < PR; r++) if (src[r] >= 0) To[t0 + r * WAVE + lane] = -X[src[r]];
+    for (int r = 0; r < PR; r++) if (src[r] >= 0) To[t0 + r * WAVE + lane] = src[r] != 0xffff ? -X[src[r]] : 0.0;
+    for (int e = PR * WAVE + lane; e < E; e += WAVE) {             // (the pair layout's padding can push a tile past PR rounds)
+      const int sx = (int)G.pv_src[t0 + e];
+      To[t0 + e] = sx != 0xffff ? -X[sx] : 0.0;
+    }
     wave_sync();
   }
 }
@@ -1729,7 +1876,7 @@ __global__ __launch_bounds__(PROD ? 256 : 1024, PROD ? 4 : 1) void k_plan_solve(
   __syncthreads();
   if (!live) return;
   const int *perm = BLK ? S.plan + S.po_perm : wl + S.po_perm;
-  if constexpr (PROD) stage_prod_solve(S, Sv, Nn.Ti + (size_t)inst * S.stage.pv_ldTi, xs, lane);
+  if constexpr (PROD) { if (S.stage.pv_mode == 2) stage_prod_solve2(S, Sv, Nn.Ti + (size_t)inst * S.stage.pv_ldTi, xs, lane); else stage_prod_solve(S, Sv, Nn.Ti + (size_t)inst * S.stage.pv_ldTi, xs, lane); }
   else if constexpr (BLK > 0) stage_tri_solve<BLK>(S, Sv, xs, xs + ((S.N + 1) & ~1), lane);
   else plan_tri_solve(S, wl, Sv, xs, lane);
   if (S.polish) {
@@ -1898,7 +2045,7 @@ __global__ __launch_bounds__(PROD ? 256 : 1024, PROD ? 4 : 1) void k_plan_admm_l
   // iteration: bit-identical iterates.
   for (int it = 0; it < iters; it++) {
     const bool last = it + 1 == iters;
-    if constexpr (PROD) stage_prod_solve(S, Sv, Nn.Ti + io * S.stage.pv_ldTi, xs, lane);
+    if constexpr (PROD) { if (S.stage.pv_mode == 2) stage_prod_solve2(S, Sv, Nn.Ti + io * S.stage.pv_ldTi, xs, lane); else stage_prod_solve(S, Sv, Nn.Ti + io * S.stage.pv_ldTi, xs, lane); }
     else if constexpr (BLK > 0) stage_tri_solve<BLK>(S, Sv, xs, xs + ((S.N + 1) & ~1), lane);
     else plan_tri_solve(S, wl, Sv, xs, lane);
     for (int j0 = 0; j0 < S.N; j0 += 4 * WAVE) {
@@ -3481,7 +3628,7 @@ static bool prod_usable(const rldl_dev_sym *S, const rldl_dev_num *Nn) {
   return !off && S->stage.pv_ok && Nn->Ti;
 }
 #define PROD_WPB 4
-static int prod_per_wave_doubles(const rldl_dev_sym *S) { return ((S->N + 1) & ~1) + 2; }
+static int prod_per_wave_doubles(const rldl_dev_sym *S) { return ((S->N + 1) & ~1) + 2 + 34; }   // x, its spare words, the auxiliary block vector of mode 2
 // dynamic LDS per workgroup of the product kernels: what the waves need, or RLDL_PROD_LDS bytes when that is more (a diagnostic:
 // fewer resident workgroups per CU)
 static size_t prod_lds_bytes(const rldl_dev_sym *S, const void *kernel) {

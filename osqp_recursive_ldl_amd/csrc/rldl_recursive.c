@@ -130,20 +130,118 @@ out:
 #define PV_GS 4                                                     /* steps per group */
 #define PV_DW 12                                                    /* descriptor words per group */
 typedef struct {                                                     /* host arrays of the product tri-solve (owned; prod_tiles_free) */
-  unsigned *tab; int *seq, *tinfo, *blk, *tiD, *dposT, *cidx, *cptr; unsigned short *src;
-  int ntab, nsteps, ntiles, ngroups, kmax, nTi, ldT;
+  unsigned *tab; int *seq, *grp, *tinfo, *blk, *tiD, *dposT, *cidx, *cptr; unsigned short *src;
+  int ntab, nsteps, ntiles, ngroups, kmax, nTi, ldT, mode;
 } prod_tiles_t;
 static void prod_tiles_free(prod_tiles_t *T) {
-  free(T->tab); free(T->seq); free(T->tinfo); free(T->blk); free(T->tiD); free(T->dposT); free(T->cidx); free(T->cptr); free(T->src);
+  free(T->tab); free(T->seq); free(T->grp); free(T->tinfo); free(T->blk); free(T->tiD); free(T->dposT); free(T->cidx); free(T->cptr); free(T->src);
   memset(T, 0, sizeof(*T));
 }
+
+/* byte offset (from x[0]) of the auxiliary block vector of the mode-2 product tri-solve in a wave's LDS: behind x and its spare words */
+static int pv_aux_offset(int N) { return 8 * (((N + 1) & ~1) + 2); }
+
+/* The sequence of groups the solve kernel walks, padded to whole rings: [forward part | padding | backward part | padding | one ring
+ * of empty closing groups].  grp: the group descriptors in tile order (D_0, C_0, D_1, ...; PV_DW words each), tinfo / blk: tile tables;
+ * only the first nb_act blocks take part (single-store horizon handles; the coupling tile from the last live block onward is left out).
+ *   mode 1   forward = the tiles in order, backward = the same groups in reverse (the kernel multiplies by the transposed tiles);
+ *   mode 2   the coupling tiles hold the ORIGINAL coupling blocks K(b+1, b) of the permuted KKT matrix instead of L(b+1, b) =
+ *            K(b+1, b) L_bb^-T D_b^-1, so every diagonal tile is used twice per pass while it sits in its ring slot and nothing but
+ *            D tiles and the sparse K blocks is streamed.  With t_b = L_bb^-T D_b^-1 y_b in an auxiliary block vector a:
+ *              forward, b ascending    [K-fwd_{b-1}: x_b -= K(b, b-1) a]   D-fwd_b: x_b <- L_bb^-1 x_b (= y_b);  a <- L_bb^-T D_b^-1 y_b
+ *              backward, b descending  [K-bwd_b: a <- -K(b+1, b)' x_{b+1}]  D-bwd_b: a <- L_bb^-1 a;  x_b <- L_bb^-T D_b^-1 (x_b + a)
+ *            flags word: bits 0-1 first / last group of its tile, bits 2-3 kind (0 K-fwd, 1 D-fwd, 2 K-bwd, 3 D-bwd), bit 4 the D-bwd
+ *            step starts from a = 0 (no coupling tile below the block), bits 8-13 size of the block whose vector a holds.  A D step
+ *            applies its tile twice (L_bb^-1 to one vector, then L_bb^-T to the other): a one-group tile does both from its one ring
+ *            slot; a tile of several groups is listed twice, first half (bit 5, groups in order, the scaling behind the last one) and
+ *            second half (bit 6, groups in reverse).  Blocks without a diagonal tile get an empty group that carries the scaling. */
+static int *pv_sequence(int mode, const int *grp, int ngrp, const int *tinfo, int ntiles, const int *blk, const int *bs, int nb, int nb_act,
+                        int N, int *nsteps_out) {
+  int *seq = 0, cnt = 0, NGp = 0, b, i, pass;
+  if (mode != 2) {
+    int g_act = ngrp, kind;
+    for (b = nb_act - 1; b < nb && g_act == ngrp; b++)
+      for (kind = (b == nb_act - 1 ? 1 : 0); kind < 2; kind++) {
+        const int t = blk[2 * b + kind];
+        if (t >= 0) { g_act = tinfo[4 * t + 3]; break; }
+      }
+    NGp = ((g_act + RLDL_PV_RING - 1) / RLDL_PV_RING) * RLDL_PV_RING;
+    seq = (int *)calloc((size_t)PV_DW * (size_t)(2 * NGp + 2 * RLDL_PV_RING), sizeof(int));
+    if (!seq) return 0;
+    for (i = 0; i < g_act; i++) memcpy(seq + PV_DW * i, grp + PV_DW * i, sizeof(int) * PV_DW);
+    for (i = 0; i < g_act; i++) memcpy(seq + PV_DW * (NGp + i), grp + PV_DW * (g_act - 1 - i), sizeof(int) * PV_DW);
+    *nsteps_out = 2 * NGp;
+    return seq;
+  }
+  for (pass = 0; pass < 2; pass++) {                                 /* pass 0 counts, pass 1 fills */
+    int pos = 0, half;
+    for (half = 0; half < 2; half++) {
+      if (pass == 1 && half == 1) pos = NGp;
+      for (i = 0; i < nb_act; i++) {
+        const int bb = half == 0 ? i : nb_act - 1 - i, sz = bs[bb + 1] - bs[bb];
+        const int cb = half == 0 ? bb - 1 : bb;                       /* the block whose vector a holds around the coupling step: the tile's columns */
+        const int tk = half == 0 ? (bb > 0 ? blk[2 * (bb - 1) + 1] : -1) : (bb < nb_act - 1 ? blk[2 * bb + 1] : -1);   /* coupling tile in front of the D step */
+        const int td = blk[2 * bb];
+        if (tk >= 0) {
+          const int g0 = tinfo[4 * tk + 3], gend = tk + 1 < ntiles ? tinfo[4 * (tk + 1) + 3] : ngrp;
+          int gk;
+          for (gk = 0; gk < gend - g0; gk++) {
+            if (pass == 1) {
+              int *q = seq + PV_DW * pos;
+              memcpy(q, grp + PV_DW * (half == 0 ? g0 + gk : gend - 1 - gk), sizeof(int) * PV_DW);   /* (backward: a tile's last group first) */
+              q[2] = pv_aux_offset(N) | ((8 * bs[cb + 1]) << 16);
+              q[3] = (q[3] & 3) | ((half == 0 ? 0 : 2) << 2) | ((bs[cb + 1] - bs[cb]) << 8);
+            }
+            pos++;
+          }
+        }
+        {                                                             /* the D step: one group = both products from one ring slot; more groups = listed twice */
+          const int g0 = td >= 0 ? tinfo[4 * td + 3] : 0, gend = td >= 0 ? (td + 1 < ntiles ? tinfo[4 * (td + 1) + 3] : ngrp) : 1;
+          const int ng = gend - g0, kindbits = ((half == 0 ? 1 : 3) << 2) | (sz << 8);
+          int gk;
+          if (ng == 1) {
+            if (pass == 1) {
+              int *q = seq + PV_DW * pos;
+              if (td >= 0) memcpy(q, grp + PV_DW * g0, sizeof(int) * PV_DW);
+              else { memset(q, 0, sizeof(int) * PV_DW); q[2] = (8 * bs[bb]) | ((8 * bs[bb]) << 16); }
+              q[3] = 3 | kindbits | ((half == 1 && tk < 0) ? 16 : 0);
+            }
+            pos++;
+          } else {
+            for (gk = 0; gk < 2 * ng; gk++) {
+              if (pass == 1) {
+                int *q = seq + PV_DW * pos;
+                const int gsrc = gk < ng ? g0 + gk : gend - 1 - (gk - ng);
+                memcpy(q, grp + PV_DW * gsrc, sizeof(int) * PV_DW);
+                q[3] = (q[3] & 3) | kindbits | (gk < ng ? 32 : 64) | ((half == 1 && tk < 0 && gk == 0) ? 16 : 0);
+              }
+              pos++;
+            }
+          }
+        }
+      }
+      if (half == 0 && pass == 0) cnt = pos;
+    }
+    if (pass == 0) {
+      NGp = ((cnt + RLDL_PV_RING - 1) / RLDL_PV_RING) * RLDL_PV_RING;
+      seq = (int *)calloc((size_t)PV_DW * (size_t)(2 * NGp + 2 * RLDL_PV_RING), sizeof(int));
+      if (!seq) return 0;
+    }
+  }
+  *nsteps_out = 2 * NGp;
+  return seq;
+}
+
 /* 0: built, 1: the pattern does not qualify */
-static int prod_tiles_host(int smax, int ldF, int N, const int *bs, int nb, int ld, const int *dptr, const int *dpos, const int *cptr,
+static int *pv_sequence(int mode, const int *grp, int ngrp, const int *tinfo, int ntiles, const int *blk, const int *bs, int nb, int nb_act,
+                        int N, int *nsteps_out);
+static int prod_tiles_host(int mode, int smax, int ldF, int N, const int *bs, int nb, int ld, const int *dptr, const int *dpos, const int *cptr,
                            const int *cslot, const int *cpos, prod_tiles_t *out) {
   const int ntmax = 2 * nb, ngmax = 2 * nb * (PV_KMAX / PV_GS);
   const int ldT = (smax <= 8 ? 8 : smax <= 16 ? 16 : smax <= 24 ? 24 : 32) + 2;   /* row length of k_stage_invert's tiles (its SM + 2) */
   unsigned char *pat = 0;                       /* [smax][smax] pattern of the tile at hand */
   int *rows_e = 0, *cnt = 0, *used = 0, *prog = 0, *seq = 0, *blk = 0, *tinfo = 0, *ent_src = 0, *colcnt = 0, *order = 0, *tiD = 0;
+  int ssrc[PV_KMAX * 64];                                            /* source of the entry of (step, lane) of the tile at hand, -1 = none */
   unsigned *tab = 0;
   unsigned short *src = 0;
   int b, t = 0, g = 0, nTi = 0, ntab = 0, kmax = 0, r, c, k, e, kind, ok = 0, i, NGp, nsteps = 0;
@@ -152,6 +250,7 @@ static int prod_tiles_host(int smax, int ldF, int N, const int *bs, int nb, int 
   if (ldF >= 65536 || (N + 2) * 8 >= 65536 || smax > 32) return 1;
   for (b = 0; b < nb; b++) srccap += (size_t)smax * (size_t)smax;
   srccap += (size_t)cptr[nb];
+  srccap = 2 * srccap + 256;                                         /* (mode 2 pads its pair slots) */
   pat = (unsigned char *)malloc((size_t)smax * smax);
   rows_e = (int *)malloc(sizeof(int) * (size_t)smax * smax);     /* entries of the tile: column per (row, i) */
   ent_src = (int *)malloc(sizeof(int) * (size_t)smax * smax);    /* ... and where the value comes from */
@@ -221,6 +320,7 @@ static int prod_tiles_host(int smax, int ldF, int N, const int *bs, int nb, int 
        * one bit per step << 20 (the lane has an entry) | row of the lane (relative to the tile's first row) << 24 | 1 << 29 for
        * lanes with entries in this tile */
       memset(used, 0, sizeof(int) * (size_t)smax * smax);
+      for (i = 0; i < PV_KMAX * 64; i++) ssrc[i] = -1;
       e = 0;                                                              /* running Ti offset inside the tile */
       for (k = 0; k < K; k++) {
         const int gi = g + k / PV_GS, j = k % PV_GS;
@@ -248,20 +348,40 @@ static int prod_tiles_host(int smax, int ldF, int N, const int *bs, int nb, int 
           gw[lane] |= ((unsigned)c << (5 * j)) | (1u << (20 + j));
           q[4 + 2 * j + (lane >> 5)] |= (int)(1u << (lane & 31));         /* the step's lane mask */
           src[nTi + e] = (unsigned short)ent_src[rr * smax + best];
+          ssrc[k * 64 + lane] = ent_src[rr * smax + best];
           e++;
         }
       }
       if (e != E) goto out;
+      if (mode == 2) {
+        /* PAIR LAYOUT: the two entries a lane takes in steps (2 p, 2 p + 1) of a group sit side by side, lanes of step 2 p in lane order
+         * (a lane's entries fill its steps from 0 up, so a lane of step 2 p + 1 is a lane of step 2 p; a lane without a second entry
+         * gets a padding slot, source 0xffff, value 0.0): one 16-byte load per lane and pair instead of two 8-byte loads */
+        int gi2, pp, lane, eo = 0;
+        for (gi2 = 0; gi2 < NG; gi2++) {
+          prog[PV_DW * (g + gi2)] = nTi + eo;
+          for (pp = 0; pp < PV_GS / 2; pp++) {
+            const int k0 = gi2 * PV_GS + 2 * pp;
+            for (lane = 0; lane < lanes; lane++) {
+              if (ssrc[k0 * 64 + lane] < 0) { if (ssrc[(k0 + 1) * 64 + lane] >= 0) goto out; continue; }
+              src[nTi + eo++] = (unsigned short)ssrc[k0 * 64 + lane];
+              src[nTi + eo++] = ssrc[(k0 + 1) * 64 + lane] >= 0 ? (unsigned short)ssrc[(k0 + 1) * 64 + lane] : (unsigned short)0xffffu;
+            }
+          }
+        }
+        E = eo;
+        if ((size_t)(nTi + E) >= srccap) goto out;
+      }
       tinfo[4 * t] = nTi; tinfo[4 * t + 1] = E; tinfo[4 * t + 2] = kind; tinfo[4 * t + 3] = g;
       blk[2 * b + kind] = t;
       nTi += E; t++; g += NG;
     }
   }
-  /* the step sequence: forward, padding, backward, padding, one ring of closing groups for the loads issued ahead */
-  NGp = ((g + RLDL_PV_RING - 1) / RLDL_PV_RING) * RLDL_PV_RING;
-  for (i = 0; i < g; i++) memcpy(seq + PV_DW * i, prog + PV_DW * i, sizeof(int) * PV_DW);
-  for (i = 0; i < g; i++) memcpy(seq + PV_DW * (NGp + i), prog + PV_DW * (g - 1 - i), sizeof(int) * PV_DW);
-  nsteps = 2 * NGp;
+  /* the step sequence the kernel walks (pv_sequence), one ring of closing groups behind it for the loads issued ahead */
+  free(seq);
+  seq = pv_sequence(mode, prog, g, tinfo, t, blk, bs, nb, nb, N, &nsteps);
+  if (!seq) goto out;
+  (void)NGp;
   tiD[nb] = nTi;
   out->dposT = (int *)malloc(sizeof(int) * (size_t)(dptr[nb] + 1));    /* ld_pos in the geometry of k_stage_invert's tiles */
   if (!out->dposT) goto out;
@@ -269,7 +389,11 @@ static int prod_tiles_host(int smax, int ldF, int N, const int *bs, int nb, int 
   out->ldT = ldT;
   /* the Ti entries of the coupling tiles, block after block: k_stage_invert copies them from their factor slots in one batched loop */
   out->cptr = (int *)malloc(sizeof(int) * (size_t)(nb + 1));
-  out->cidx = (int *)malloc(sizeof(int) * (size_t)(cptr[nb] + 1));
+  {
+    int tot = 1;
+    for (b = 0; b < nb; b++) if (blk[2 * b + 1] >= 0) tot += tinfo[4 * blk[2 * b + 1] + 1];
+    out->cidx = (int *)malloc(sizeof(int) * (size_t)tot);
+  }
   if (!out->cptr || !out->cidx) { free(out->dposT); free(out->cptr); free(out->cidx); out->dposT = out->cptr = out->cidx = 0; goto out; }
   for (b = 0, k = 0; b < nb; b++) {
     out->cptr[b] = k;
@@ -277,7 +401,10 @@ static int prod_tiles_host(int smax, int ldF, int N, const int *bs, int nb, int 
   }
   out->cptr[nb] = k;
   out->tab = tab; out->seq = seq; out->tinfo = tinfo; out->blk = blk; out->tiD = tiD; out->src = src;
-  out->ntab = ntab; out->nsteps = nsteps; out->ntiles = t; out->ngroups = g; out->kmax = kmax; out->nTi = nTi;
+  out->grp = (int *)malloc(sizeof(int) * (size_t)PV_DW * (size_t)(g + 1));
+  if (!out->grp) { free(out->dposT); free(out->cptr); free(out->cidx); out->dposT = out->cptr = out->cidx = 0; goto out; }
+  memcpy(out->grp, prog, sizeof(int) * (size_t)PV_DW * (size_t)g);
+  out->ntab = ntab; out->nsteps = nsteps; out->ntiles = t; out->ngroups = g; out->kmax = kmax; out->nTi = nTi; out->mode = mode;
   tab = 0; seq = 0; tinfo = 0; blk = 0; tiD = 0; src = 0;
   ok = 1;
 out:
@@ -288,12 +415,15 @@ out:
 
 /* the same tables on the device (optional: pv_ok stays 0 on failure) */
 static void build_prod_tiles(rldl_batch *h, const int *bs, int nb, int ld, const int *dptr, const int *dpos, const int *cptr,
-                             const int *cslot, const int *cpos) {
+                             const int *cslot, const int *cpos, const int *kptr, const int *ksrc, const int *kpos) {
   rldl_dev_stage *G = &h->dsym.stage;
   prod_tiles_t T;
-  G->pv_ok = 0;
+  G->pv_ok = 0; G->pv_mode = 0;
   if (getenv("RLDL_NO_STAGE_PROD")) return;
-  if (prod_tiles_host(G->smax, h->dsym.ldF, h->sym->N, bs, nb, ld, dptr, dpos, cptr, cslot, cpos, &T)) return;
+  /* mode 2 (coupling tiles = the original coupling blocks of the KKT matrix, every diagonal tile used twice per pass: about half the
+   * bytes per solve) when every diagonal tile fits one group and the KKT value indices fit the 16-bit source table; else mode 1 */
+  if (getenv("RLDL_PROD_V1") || h->sym->nnzK >= 65535 || prod_tiles_host(2, G->smax, h->dsym.ldF, h->sym->N, bs, nb, ld, dptr, dpos, kptr, ksrc, kpos, &T))
+    if (prod_tiles_host(1, G->smax, h->dsym.ldF, h->sym->N, bs, nb, ld, dptr, dpos, cptr, cslot, cpos, &T)) return;
   G->pv_tab = (const unsigned *)upload_ints((const int *)T.tab, (size_t)T.ntab);
   G->pv_prog = upload_ints(T.seq, (size_t)PV_DW * (size_t)(T.nsteps + 2 * RLDL_PV_RING));
   G->pv_tinfo = upload_ints(T.tinfo, (size_t)4 * (size_t)(T.ntiles + 1));
@@ -313,17 +443,17 @@ static void build_prod_tiles(rldl_batch *h, const int *bs, int nb, int ld, const
     G->pv_ntiles = T.ntiles; G->pv_ngroups = T.ngroups; G->pv_nsteps = T.nsteps; G->pv_kmax = T.kmax; G->pv_nTi = T.nTi; G->pv_ntab = T.ntab;
     G->pv_ldTi = (T.nTi + 1) & ~1;
     free(h->pv_tiD); h->pv_tiD = T.tiD; T.tiD = 0;
-    G->pv_ok = 1;
+    G->pv_ok = 1; G->pv_mode = T.mode; G->pv_aux = pv_aux_offset(h->sym->N);
     /* host copies for step programs over a prefix of the blocks (the first T.ngroups entries of seq are the groups in tile order) */
     free(h->pv_grp); free(h->pv_tinfo_h); free(h->pv_blk_h);
     h->pv_grp = (int *)malloc(sizeof(int) * (size_t)PV_DW * (size_t)(T.ngroups + 1));
     h->pv_tinfo_h = (int *)malloc(sizeof(int) * 4 * (size_t)(T.ntiles + 1));
     h->pv_blk_h = (int *)malloc(sizeof(int) * 2 * (size_t)nb);
     if (h->pv_grp && h->pv_tinfo_h && h->pv_blk_h) {
-      memcpy(h->pv_grp, T.seq, sizeof(int) * (size_t)PV_DW * (size_t)T.ngroups);
+      memcpy(h->pv_grp, T.grp, sizeof(int) * (size_t)PV_DW * (size_t)T.ngroups);
       memcpy(h->pv_tinfo_h, T.tinfo, sizeof(int) * 4 * (size_t)T.ntiles);
       memcpy(h->pv_blk_h, T.blk, sizeof(int) * 2 * (size_t)nb);
-      h->pv_ngrp = T.ngroups;
+      h->pv_ngrp = T.ngroups; h->pv_ntiles_h = T.ntiles;
     } else { free(h->pv_grp); free(h->pv_tinfo_h); free(h->pv_blk_h); h->pv_grp = h->pv_tinfo_h = h->pv_blk_h = 0; h->pv_ngrp = 0; }
   }
   prod_tiles_free(&T);
@@ -331,26 +461,16 @@ static void build_prod_tiles(rldl_batch *h, const int *bs, int nb, int ld, const
 
 int rldl_stage_prog_prefix(const rldl_batch *h, int nb_act, int **d_prog, int *nsteps) {
   const rldl_dev_stage *G;
-  int nb, g_act, NGp, i, b, kind, *seq;
-  if (!h || !d_prog || !nsteps) return 1;
-  G = &h->dsym.stage; nb = G->nb;
-  if (!G->pv_ok || !h->pv_grp || nb_act < 1 || nb_act > nb) return 1;
-  g_act = h->pv_ngrp;                                            /* groups of the tiles D_0, C_0, ..., D_{nb_act - 1}: everything before the first tile left out */
-  for (b = nb_act - 1; b < nb && g_act == h->pv_ngrp; b++)
-    for (kind = (b == nb_act - 1 ? 1 : 0); kind < 2; kind++) {
-      const int t = h->pv_blk_h[2 * b + kind];
-      if (t >= 0) { g_act = h->pv_tinfo_h[4 * t + 3]; break; }
-    }
-  NGp = ((g_act + RLDL_PV_RING - 1) / RLDL_PV_RING) * RLDL_PV_RING;
-  seq = (int *)calloc((size_t)PV_DW * (size_t)(2 * NGp + 2 * RLDL_PV_RING), sizeof(int));
+  int *seq;
+  if (!h || !d_prog || !nsteps || !h->rec) return 1;
+  G = &h->dsym.stage;
+  if (!G->pv_ok || !h->pv_grp || nb_act < 1 || nb_act > G->nb) return 1;
+  seq = pv_sequence(G->pv_mode, h->pv_grp, h->pv_ngrp, h->pv_tinfo_h, h->pv_ntiles_h, h->pv_blk_h, (const int *)h->rec + 1, G->nb, nb_act,
+                    h->sym->N, nsteps);
   if (!seq) return 1;
-  for (i = 0; i < g_act; i++) memcpy(seq + PV_DW * i, h->pv_grp + PV_DW * i, sizeof(int) * PV_DW);
-  for (i = 0; i < g_act; i++) memcpy(seq + PV_DW * (NGp + i), h->pv_grp + PV_DW * (g_act - 1 - i), sizeof(int) * PV_DW);
-  *d_prog = upload_ints(seq, (size_t)PV_DW * (size_t)(2 * NGp + 2 * RLDL_PV_RING));
+  *d_prog = upload_ints(seq, (size_t)PV_DW * (size_t)(*nsteps + 2 * RLDL_PV_RING));
   free(seq);
-  if (!*d_prog) return 1;
-  *nsteps = 2 * NGp;
-  return 0;
+  return *d_prog ? 0 : 1;
 }
 
 /* Host part of the stage-block view: block starts and, per block, the entries of the permuted KKT matrix and of L that fall into
@@ -463,7 +583,7 @@ static int build_stage_maps(rldl_batch *h) {
   if (!G.bs || !G.kd_ptr || !G.kd_src || !G.kd_pos || !G.kc_ptr || !G.kc_src || !G.kc_pos || !G.ld_ptr || !G.ld_slot || !G.ld_pos ||
       !G.lc_ptr || !G.lc_slot || !G.lc_pos) { rldl_stage_maps_free(h); goto out; }
   build_solve_tiles(h, L.bs, nb, L.ld, ptr[2], a[2], b[2], tot[2], ptr[3], a[3], b[3], tot[3]);   /* optional: sv_ok stays 0 on failure */
-  if (h->dsym.stage.sv_ok) build_prod_tiles(h, L.bs, nb, L.ld, ptr[2], b[2], ptr[3], a[3], b[3]);   /* optional as well */
+  if (h->dsym.stage.sv_ok) build_prod_tiles(h, L.bs, nb, L.ld, ptr[2], b[2], ptr[3], a[3], b[3], ptr[1], a[1], b[1]);   /* optional as well */
   h->rec = malloc(sizeof(int) * (size_t)(nb + 2));
   if (!h->rec) { rldl_stage_maps_free(h); goto out; }
   ((int *)h->rec)[0] = nb;
@@ -492,7 +612,7 @@ c_int rldl_stage_prod_export(const csc *P, const csc *A, const rldl_stage_dims *
   if (rldl_symbolic_create(&s, P->n, A->m, P->p, P->i, A->p, A->i, 0, perm)) { free(perm); return RLDL_LINSYS_SOLVER_INIT_ERROR; }
   free(perm);
   if (stage_lists(s, dims, &L)) { rldl_symbolic_free(s); return 2; }
-  if (!prod_tiles_host(L.smax, (s->nS + s->N + 1) & ~1, s->N, L.bs, L.nb, L.ld, L.ptr[2], L.b[2], L.ptr[3], L.a[3], L.b[3], &T)) {
+  if (!prod_tiles_host(1, L.smax, (s->nS + s->N + 1) & ~1, s->N, L.bs, L.nb, L.ld, L.ptr[2], L.b[2], L.ptr[3], L.a[3], L.b[3], &T)) {   /* (the mode-1 tables: L(b+1, b) in the coupling tiles) */
     meta[0] = 1; meta[1] = T.ntiles; meta[2] = T.ntab; meta[3] = T.nTi; meta[4] = L.nb; meta[5] = T.ldT; meta[6] = T.kmax; meta[7] = T.nsteps;
     if (prog) memcpy(prog, T.seq, sizeof(int) * PV_DW * (size_t)T.nsteps);
     if (tinfo) memcpy(tinfo, T.tinfo, sizeof(int) * 4 * (size_t)(T.ntiles + 1));

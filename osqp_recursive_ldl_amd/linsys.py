@@ -222,7 +222,7 @@ class BatchLinsys:
         if L.rldl_batch_export_prod(self.h, int(inst), _ip(meta), vp(prog), vp(tinfo), vp(tab), vp(src), vp(blk), _fp(Ti)):
             raise RuntimeError("export_prod failed")
         return dict(tiles=nt, steps=ng, nb=nb, ld=int(meta[5]), kmax=int(meta[6]), prog=prog.reshape(-1, 12), tinfo=tinfo.reshape(-1, 4)[:nt],
-                    tab=tab[:nw], src=src[:nTi], blk=blk.reshape(-1, 2), Ti=Ti[:nTi])
+                    tab=tab[:nw], src=src[:nTi], blk=blk.reshape(-1, 2), Ti=Ti[:nTi], mode=int(meta[0]))
 
     def factor_status(self):
         st = np.zeros(self.batch, np.int64)

@@ -24,9 +24,15 @@ def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to("cuda:0")
 
 
+@pytest.mark.parametrize("tables", ["K-tiles", "L-tiles"])
 @pytest.mark.parametrize("N", [1, 3, 20, 45])
-def test_tiles_tables_and_solve(N):
+def test_tiles_tables_and_solve(N, tables, monkeypatch):
+    """tables = "L-tiles": the round-2 form (RLDL_PROD_V1=1: coupling tiles hold L(b+1, b), one use of every tile per pass);
+    "K-tiles": the default since round 3 (stage_prod_solve2: coupling tiles hold the KKT matrix's own coupling blocks K(b+1, b) and
+    every diagonal tile is applied twice per pass: L(b+1, b) = K(b+1, b) L_bb^-T D_b^-1 is never streamed)."""
     import osqp_recursive_ldl_amd as R
+    if tables == "L-tiles":
+        monkeypatch.setenv("RLDL_PROD_V1", "1")
     wl = R.workloads.MPCStageQPs(N=N)
     B = 2
     Px, Ax, q, l, u = wl.values(B)
@@ -42,6 +48,7 @@ def test_tiles_tables_and_solve(N):
     for inst in range(B):
         pr = ls.export_prod(inst)
         assert pr is not None, "stage handle without product tables"
+        assert pr["mode"] == (1 if tables == "L-tiles" else 2)
         f = ls.export_factor(inst)
         L = sparse.csc_matrix((f["Lx"], sym["Li"], sym["Lp"]), shape=(Nk, Nk)).toarray() + np.eye(Nk)
         # (1) tile values: D tiles hold -(strictly lower part of L_bb^-1), C tiles hold L(b+1, b)
@@ -54,20 +61,31 @@ def test_tiles_tables_and_solve(N):
                 assert kind == 0
                 Xi = np.linalg.inv(L[s0:s1, s0:s1])
                 src = pr["src"][ti0:ti0 + E].astype(np.int64)
+                tv = pr["Ti"][ti0:ti0 + E]
+                if pr["mode"] == 2:                                    # pair layout: padding slots (source 0xffff) hold 0.0
+                    assert np.all(tv[src == 0xffff] == 0.0)
+                    tv, src = tv[src != 0xffff], src[src != 0xffff]
                 want = -Xi[src // ld, src % ld]
-                assert np.max(np.abs(pr["Ti"][ti0:ti0 + E] - want)) <= 1e-11 * max(1.0, np.max(np.abs(Xi)))
+                assert np.max(np.abs(tv - want)) <= 1e-11 * max(1.0, np.max(np.abs(Xi)))
                 dense = np.zeros_like(Xi); dense[src // ld, src % ld] = Xi[src // ld, src % ld]
                 assert np.max(np.abs(np.tril(Xi, -1) - dense)) <= 1e-13 * max(1.0, np.max(np.abs(Xi))), "inverse pattern misses an entry"
-            if tc >= 0:
+            if tc >= 0 and pr["mode"] == 1:
                 ti0, E, kind, g0 = [int(v) for v in pr["tinfo"][tc]]
                 assert kind == 1 and E == np.count_nonzero(sym["Li"][sym["Lp"][s0]:sym["Lp"][s1]] >= s1)
+            if tc >= 0 and pr["mode"] == 2:                            # the coupling tile IS the KKT matrix's coupling block: values = Kx[src]
+                ti0, E, kind, g0 = [int(v) for v in pr["tinfo"][tc]]
+                src = pr["src"][ti0:ti0 + E].astype(np.int64)
+                tv = pr["Ti"][ti0:ti0 + E]
+                assert kind == 1 and np.all(tv[src == 0xffff] == 0.0)
+                assert np.array_equal(tv[src != 0xffff], f["KKTx"][src[src != 0xffff]]) and len(set(src[src != 0xffff].tolist())) == int((src != 0xffff).sum())
         # (2) the emulation of the two passes against a triangular solve with the exported factor
         perm = sym["perm"]
         bp = rhs[inst][perm]
         ref = solve_triangular(L.T, f["Dinv"] * solve_triangular(L, bp, lower=True, unit_diagonal=True), lower=False, unit_diagonal=True)
-        emu = emulate(pr, f["Dinv"], bp)
         scale = max(1.0, np.max(np.abs(ref)))
-        assert np.max(np.abs(emu - ref)) <= 1e-9 * scale
+        if pr["mode"] == 1:
+            emu = emulate(pr, f["Dinv"], bp)
+            assert np.max(np.abs(emu - ref)) <= 1e-9 * scale
         # (3) the kernel: x_tilde / z_tilde epilogue undone (qdldl_interface.c:563-579)
         sol = np.empty(Nk); sol[perm] = ref
         got = out[inst].copy()
