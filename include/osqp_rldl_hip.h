@@ -210,6 +210,9 @@ void  osqp_batch_cleanup(osqp_batch *w);                                /* osqp.
  * re-checks the settings of every member (they can change through osqp_batch_update_settings) and returns 2 when the set no longer
  * qualifies.  The workspaces stay owned by the caller. */
 typedef struct osqp_multi osqp_multi;
+/* the key of the fused kernel instantiation the workspace's pattern selects (equal keys share launches), -1: off the tile kernels,
+ * the workspace cannot join a set */
+c_int osqp_batch_multi_key(const osqp_batch *w);
 c_int osqp_multi_create(osqp_multi **mp, osqp_batch **ws, c_int count, const c_int *dest, void *stream);
 c_int osqp_multi_solve(osqp_multi *mm);
 /* osqp_update_P_A of every workspace of the set in one chain (scatter, numeric factorisation, tail inverse over the stacked instances);

@@ -70,7 +70,7 @@ EXPORTED = [
     "rldl_batch_init_recursive", "rldl_batch_update_from_stage", "rldl_version",
     "rldl_symbolic_analyze", "rldl_stage_permutation", "rldl_plan_export", "rldl_stage_prod_export", "rldl_setup_AP_matrices", "rldl_csc_free",
     "osqp_horizon_setup", "osqp_horizon_update", "osqp_horizon_workspace", "osqp_horizon_N", "osqp_horizon_last_update",
-    "osqp_horizon_free", "osqp_horizon_is_single", "osqp_horizon_workspaces", "osqp_horizon_ld", "osqp_horizon_update_P_A", "osqp_horizon_warm_start",
+    "osqp_horizon_free", "osqp_batch_multi_key", "osqp_horizon_is_single", "osqp_horizon_workspaces", "osqp_horizon_ld", "osqp_horizon_update_P_A", "osqp_horizon_warm_start",
     "osqp_multi_create", "osqp_multi_solve", "osqp_multi_update_P_A", "osqp_multi_get", "osqp_multi_free",
 ]
 
@@ -215,6 +215,8 @@ def _declare(L):
     L.osqp_horizon_workspace.restype = VP
     L.osqp_horizon_N.argtypes = [VP]
     L.osqp_horizon_N.restype = c_int
+    L.osqp_batch_multi_key.argtypes = [VP]
+    L.osqp_batch_multi_key.restype = c_int
     for name in ("osqp_horizon_is_single", "osqp_horizon_workspaces"):
         getattr(L, name).argtypes = [VP]
         getattr(L, name).restype = c_int

@@ -511,16 +511,22 @@ c_int osqp_batch_get(osqp_batch *w, c_float **d_x, c_float **d_y, c_float **d_z,
 struct osqp_multi {
   c_int count, total, n, m;
   osqp_batch **ws;                                   /* sorted by kernel instantiation (rldl_multi_key): partitions are ranges of it */
-  rldl_dev_multi M;                                  /* all groups (solve_begin, closing check, gather); S / N / W = the device arrays below */
-  int nparts, part_first[RLDL_MULTI_MAX + 1], part_xdw[RLDL_MULTI_MAX];   /* partition p = groups [part_first[p], part_first[p + 1]) */
+  rldl_dev_multi M;                                  /* all groups (solve_begin, closing check, gather); its arrays are the device arrays below */
+  int nparts, *part_first, *part_xdw;                /* partition p = groups [part_first[p], part_first[p + 1]); [count + 1], [count] */
+  rldl_dev_multi *Mp;                                /* [nparts] descriptor of each partition (first_tile rebased to the partition) */
+  int *d_first_tile, *d_first_inst, *d_xdw;          /* device [count + 1], [count + 1], [count] */
+  int *d_part_tile;                                  /* device: the partitions' rebased first_tile arrays, one after the other ([count + nparts]) */
   rldl_dev_sym *dS; rldl_dev_num *dN; rldl_dev_admm *dW;
   rldl_dev_admm *hW;                                 /* pinned staging of the W structs (write_delta is set per solve) */
   int *d_dest;
-  int orig_of[RLDL_MULTI_MAX];                       /* group i of the set = ws[orig_of[i]] of the caller's array */
+  int *orig_of;                                      /* [count] group i of the set = ws[orig_of[i]] of the caller's array */
+  const double **d_pa[2], **h_pa[2];                 /* device / pinned host [4][count], two sets used in turn: Px, Ax, keepP, keepA pointers of an update of all groups */
+  void *ev_pa[2]; int pa_turn;                       /* event behind the copy of each set: a set is rewritten only after its last copy has run */
   int upd_key, upd_flds, upd_ilds;                   /* one update chain for all groups: factor kernel instantiation (-1: not available), LDS sizes */
   int *h_fail, *d_fail;                              /* pinned / device [count]: factorisation verdicts read back by osqp_multi_solve */
   int w_uploaded;
   void *stream;
+  void **ustreams; int nustreams;                    /* the distinct streams of the member workspaces other than `stream` (work queued there comes first) */
 };
 
 void osqp_multi_free(osqp_multi *mm) {
@@ -532,9 +538,19 @@ void osqp_multi_free(osqp_multi *mm) {
   if (mm->d_dest) (void)hipFree(mm->d_dest);
   if (mm->d_fail) (void)hipFree(mm->d_fail);
   if (mm->h_fail) (void)hipHostFree(mm->h_fail);
+  if (mm->d_first_tile) (void)hipFree(mm->d_first_tile);
+  if (mm->d_first_inst) (void)hipFree(mm->d_first_inst);
+  if (mm->d_xdw) (void)hipFree(mm->d_xdw);
+  if (mm->d_part_tile) (void)hipFree(mm->d_part_tile);
+  { int k2; for (k2 = 0; k2 < 2; k2++) { if (mm->d_pa[k2]) (void)hipFree((void *)mm->d_pa[k2]); if (mm->h_pa[k2]) (void)hipHostFree((void *)mm->h_pa[k2]); if (mm->ev_pa[k2]) (void)hipEventDestroy((hipEvent_t)mm->ev_pa[k2]); } }
+  free(mm->part_first); free(mm->part_xdw); free(mm->Mp); free(mm->orig_of); free(mm->ustreams);
   free(mm->ws);
   free(mm);
 }
+
+/* which launch chain a workspace can join: the key of the fused kernel instantiation its pattern selects (workspaces with equal keys share
+ * the launches of osqp_multi_solve), or -1 when the pattern is off the tile kernels (it must be solved on its own) */
+c_int osqp_batch_multi_key(const osqp_batch *w) { return w ? rldl_multi_key(&w->ls->dsym, &w->ls->num, &w->W) : -1; }
 
 /* the fixed-iteration case the launch chain covers: no termination checks, no rho adaptation, no polish, same n, m, max_iter and
  * warm_start in every workspace.  Checked at creation AND at every solve (check_termination, max_iter, warm_start can be changed
@@ -552,55 +568,74 @@ static int multi_qualifies(osqp_batch *const *ws, c_int count) {
 c_int osqp_multi_create(osqp_multi **mp, osqp_batch **ws, c_int count, const c_int *dest, void *stream) {
   osqp_multi *mm;
   c_int g, total = 0;
-  int keys[RLDL_MULTI_MAX], order[RLDL_MULTI_MAX], first_orig[RLDL_MULTI_MAX + 1], wpb = rldl_multi_tile_wpb(), *h_dest = 0, ok = 1, i, k;
+  int *keys = 0, *order = 0, *first_orig = 0, *h_dest = 0, *h_ft = 0, *h_fi = 0, *h_xdw = 0, *h_pt = 0;
+  int wpb = rldl_multi_tile_wpb(), ok = 1, i, k, p;
   if (!mp) return 1;
   *mp = 0;
   if (!ws || count <= 0 || !dest) return 1;
-  if (count > RLDL_MULTI_MAX) return 2;                            /* more patterns than one descriptor holds: the per-workspace route */
-  first_orig[0] = 0;
   if (!multi_qualifies(ws, count)) return 2;                      /* the fixed-iteration case on the tile kernels, same n and m */
+  keys = (int *)malloc(sizeof(int) * (size_t)count); order = (int *)malloc(sizeof(int) * (size_t)count);
+  first_orig = (int *)malloc(sizeof(int) * (size_t)(count + 1));
+  if (!keys || !order || !first_orig) { free(keys); free(order); free(first_orig); return RLDL_MEM_ALLOC_ERROR; }
+  first_orig[0] = 0;
   for (g = 0; g < count; g++) {
     const osqp_batch *w = ws[g];
     keys[g] = rldl_multi_key(&w->ls->dsym, &w->ls->num, &w->W);
-    if (keys[g] < 0) return 2;
+    if (keys[g] < 0) { free(keys); free(order); free(first_orig); return 2; }
     first_orig[g + 1] = first_orig[g] + (int)w->batch;
     total += w->batch;
   }
   {                                                               /* dest must be a permutation of 0 .. total-1: k_multi_gather writes x / y / status rows there */
     unsigned char *seen = (unsigned char *)calloc((size_t)total, 1);
     c_int t, bad = 0;
-    if (!seen) return RLDL_MEM_ALLOC_ERROR;
+    if (!seen) { free(keys); free(order); free(first_orig); return RLDL_MEM_ALLOC_ERROR; }
     for (t = 0; t < total && !bad; t++) {
       if (dest[t] < 0 || dest[t] >= total || seen[dest[t]]) bad = 1; else seen[dest[t]] = 1;
     }
     free(seen);
-    if (bad) return 1;
+    if (bad) { free(keys); free(order); free(first_orig); return 1; }
   }
-  for (i = 0; i < count; i++) order[i] = i;                        /* groups by key (insertion sort, stable): one launch of the iterations per key */
-  for (i = 1; i < count; i++) {
-    const int v = order[i];
-    for (k = i; k > 0 && keys[order[k - 1]] > keys[v]; k--) order[k] = order[k - 1];
-    order[k] = v;
+  {                                                               /* groups by key (stable counting over the distinct keys: one launch of the iterations per key) */
+    int nk = 0, *ukeys = (int *)malloc(sizeof(int) * (size_t)count), pos = 0, u;
+    if (!ukeys) { free(keys); free(order); free(first_orig); return RLDL_MEM_ALLOC_ERROR; }
+    for (i = 0; i < count; i++) {
+      for (u = 0; u < nk && ukeys[u] != keys[i]; u++) {}
+      if (u == nk) { for (k = nk; k > 0 && ukeys[k - 1] > keys[i]; k--) ukeys[k] = ukeys[k - 1]; ukeys[k] = keys[i]; nk++; }
+    }
+    for (u = 0; u < nk; u++) for (i = 0; i < count; i++) if (keys[i] == ukeys[u]) order[pos++] = i;
+    free(ukeys);
   }
   mm = (osqp_multi *)calloc(1, sizeof(osqp_multi));
-  if (!mm) return RLDL_MEM_ALLOC_ERROR;
+  if (!mm) { free(keys); free(order); free(first_orig); return RLDL_MEM_ALLOC_ERROR; }
   mm->count = count; mm->total = total; mm->n = ws[0]->n; mm->m = ws[0]->m; mm->stream = stream;
   mm->ws = (osqp_batch **)malloc(sizeof(osqp_batch *) * (size_t)count);
+  mm->part_first = (int *)calloc((size_t)count + 1, sizeof(int)); mm->part_xdw = (int *)calloc((size_t)count, sizeof(int));
+  mm->orig_of = (int *)malloc(sizeof(int) * (size_t)count);
   h_dest = (int *)malloc(sizeof(int) * (size_t)total);
-  if (!mm->ws || !h_dest) { free(h_dest); osqp_multi_free(mm); return RLDL_MEM_ALLOC_ERROR; }
-  if (!HIP_OK(hipMalloc((void **)&mm->dS, sizeof(rldl_dev_sym) * (size_t)count))) ok = 0;
+  h_ft = (int *)malloc(sizeof(int) * (size_t)(count + 1)); h_fi = (int *)malloc(sizeof(int) * (size_t)(count + 1));
+  h_xdw = (int *)malloc(sizeof(int) * (size_t)count); h_pt = (int *)malloc(sizeof(int) * (size_t)(2 * count + 2));
+  if (!mm->ws || !mm->part_first || !mm->part_xdw || !mm->orig_of || !h_dest || !h_ft || !h_fi || !h_xdw || !h_pt) ok = 0;
+  if (ok && !HIP_OK(hipMalloc((void **)&mm->dS, sizeof(rldl_dev_sym) * (size_t)count))) ok = 0;
   if (ok && !HIP_OK(hipMalloc((void **)&mm->dN, sizeof(rldl_dev_num) * (size_t)count))) ok = 0;
   if (ok && !HIP_OK(hipMalloc((void **)&mm->dW, sizeof(rldl_dev_admm) * (size_t)count))) ok = 0;
   if (ok && !HIP_OK(hipHostMalloc((void **)&mm->hW, sizeof(rldl_dev_admm) * (size_t)count, hipHostMallocDefault))) { mm->hW = 0; ok = 0; }
   if (ok && !HIP_OK(hipMalloc((void **)&mm->d_dest, sizeof(int) * (size_t)total))) ok = 0;
-  if (ok && !HIP_OK(hipMalloc((void **)&mm->d_fail, sizeof(int) * RLDL_MULTI_MAX))) ok = 0;
-  if (ok && !HIP_OK(hipHostMalloc((void **)&mm->h_fail, sizeof(int) * RLDL_MULTI_MAX, hipHostMallocDefault))) { mm->h_fail = 0; ok = 0; }
+  if (ok && !HIP_OK(hipMalloc((void **)&mm->d_fail, sizeof(int) * (size_t)count))) ok = 0;
+  if (ok && !HIP_OK(hipHostMalloc((void **)&mm->h_fail, sizeof(int) * (size_t)count, hipHostMallocDefault))) { mm->h_fail = 0; ok = 0; }
+  if (ok && !HIP_OK(hipMalloc((void **)&mm->d_first_tile, sizeof(int) * (size_t)(count + 1)))) ok = 0;
+  if (ok && !HIP_OK(hipMalloc((void **)&mm->d_first_inst, sizeof(int) * (size_t)(count + 1)))) ok = 0;
+  if (ok && !HIP_OK(hipMalloc((void **)&mm->d_xdw, sizeof(int) * (size_t)count))) ok = 0;
+  if (ok && !HIP_OK(hipMalloc((void **)&mm->d_part_tile, sizeof(int) * (size_t)(2 * count + 2)))) ok = 0;
+  for (k = 0; ok && k < 2; k++) {
+    if (!HIP_OK(hipMalloc((void **)&mm->d_pa[k], sizeof(double *) * 4 * (size_t)count))) { mm->d_pa[k] = 0; ok = 0; }
+    if (ok && !HIP_OK(hipHostMalloc((void **)&mm->h_pa[k], sizeof(double *) * 4 * (size_t)count, hipHostMallocDefault))) { mm->h_pa[k] = 0; ok = 0; }
+    if (ok && !HIP_OK(hipEventCreateWithFlags((hipEvent_t *)&mm->ev_pa[k], hipEventDisableTiming))) { mm->ev_pa[k] = 0; ok = 0; }
+  }
   mm->upd_key = -2;
-  mm->M.ngroups = (int)count;
-  mm->M.first_tile[0] = mm->M.first_inst[0] = 0;
+  if (ok) { h_ft[0] = 0; h_fi[0] = 0; }
   for (i = 0; ok && i < count; i++) {
     const osqp_batch *w = ws[order[i]];
-    const int xdw = rldl_multi_tile_xdw(&w->ls->dsym), p = mm->nparts;
+    const int xdw = rldl_multi_tile_xdw(&w->ls->dsym);
     mm->ws[i] = ws[order[i]];
     mm->orig_of[i] = order[i];
     {                                                             /* the update chain needs one factor kernel instantiation and no equilibration */
@@ -610,19 +645,49 @@ c_int osqp_multi_create(osqp_multi **mp, osqp_batch **ws, c_int count, const c_i
       if (fl > mm->upd_flds) mm->upd_flds = fl;
       if (il > mm->upd_ilds) mm->upd_ilds = il;
     }
-    if (i == 0 || keys[order[i]] != keys[order[i - 1]]) { mm->part_first[p] = i; mm->part_xdw[p] = 0; mm->nparts++; }
+    if (i == 0 || keys[order[i]] != keys[order[i - 1]]) { mm->part_first[mm->nparts] = i; mm->part_xdw[mm->nparts] = 0; mm->nparts++; }
     if (xdw > mm->part_xdw[mm->nparts - 1]) mm->part_xdw[mm->nparts - 1] = xdw;
-    for (k = 0; k < (int)w->batch; k++) h_dest[mm->M.first_inst[i] + k] = (int)dest[first_orig[order[i]] + k];
-    mm->M.first_inst[i + 1] = mm->M.first_inst[i] + (int)w->batch;
-    mm->M.first_tile[i + 1] = mm->M.first_tile[i] + ((int)w->batch + wpb - 1) / wpb;
-    mm->M.xdw[i] = xdw;
+    for (k = 0; k < (int)w->batch; k++) h_dest[h_fi[i] + k] = (int)dest[first_orig[order[i]] + k];
+    h_fi[i + 1] = h_fi[i] + (int)w->batch;
+    h_ft[i + 1] = h_ft[i] + ((int)w->batch + wpb - 1) / wpb;
+    h_xdw[i] = xdw;
     if (!HIP_OK(hipMemcpy(mm->dS + i, &w->ls->dsym, sizeof(rldl_dev_sym), hipMemcpyHostToDevice))) ok = 0;
     if (ok && !HIP_OK(hipMemcpy(mm->dN + i, &w->ls->num, sizeof(rldl_dev_num), hipMemcpyHostToDevice))) ok = 0;
   }
-  mm->part_first[mm->nparts] = (int)count;
-  if (ok && !HIP_OK(hipMemcpy(mm->d_dest, h_dest, sizeof(int) * (size_t)total, hipMemcpyHostToDevice))) ok = 0;
-  free(h_dest);
-  mm->M.S = mm->dS; mm->M.N = mm->dN; mm->M.W = mm->dW;
+  if (ok) {
+    int off = 0;
+    mm->part_first[mm->nparts] = (int)count;
+    mm->Mp = (rldl_dev_multi *)calloc((size_t)mm->nparts, sizeof(rldl_dev_multi));
+    if (!mm->Mp) ok = 0;
+    for (p = 0; ok && p < mm->nparts; p++) {                      /* per partition: first_tile rebased to its first group */
+      const int gs = mm->part_first[p], ge = mm->part_first[p + 1];
+      rldl_dev_multi *Mp = &mm->Mp[p];
+      for (i = 0; i <= ge - gs; i++) h_pt[off + i] = h_ft[gs + i] - h_ft[gs];
+      Mp->ngroups = ge - gs; Mp->total_tiles = h_ft[ge] - h_ft[gs]; Mp->total_insts = h_fi[ge] - h_fi[gs];
+      Mp->first_tile = mm->d_part_tile + off; Mp->first_inst = 0; Mp->xdw = mm->d_xdw + gs;
+      Mp->S = mm->dS + gs; Mp->N = mm->dN + gs; Mp->W = mm->dW + gs;
+      off += ge - gs + 1;
+    }
+    if (ok && (!HIP_OK(hipMemcpy(mm->d_part_tile, h_pt, sizeof(int) * (size_t)off, hipMemcpyHostToDevice)) ||
+               !HIP_OK(hipMemcpy(mm->d_first_tile, h_ft, sizeof(int) * (size_t)(count + 1), hipMemcpyHostToDevice)) ||
+               !HIP_OK(hipMemcpy(mm->d_first_inst, h_fi, sizeof(int) * (size_t)(count + 1), hipMemcpyHostToDevice)) ||
+               !HIP_OK(hipMemcpy(mm->d_xdw, h_xdw, sizeof(int) * (size_t)count, hipMemcpyHostToDevice)) ||
+               !HIP_OK(hipMemcpy(mm->d_dest, h_dest, sizeof(int) * (size_t)total, hipMemcpyHostToDevice)))) ok = 0;
+    mm->M.ngroups = (int)count; mm->M.total_tiles = h_ft[count]; mm->M.total_insts = h_fi[count];
+    mm->M.first_tile = mm->d_first_tile; mm->M.first_inst = mm->d_first_inst; mm->M.xdw = mm->d_xdw;
+    mm->M.S = mm->dS; mm->M.N = mm->dN; mm->M.W = mm->dW;
+  }
+  if (ok) {                                                       /* distinct streams of the members (a set of a thousand workspaces shares a handful) */
+    mm->ustreams = (void **)malloc(sizeof(void *) * (size_t)count);
+    if (!mm->ustreams) ok = 0;
+    for (i = 0; ok && i < count; i++) {
+      void *st = mm->ws[i]->stream;
+      if (st == mm->stream) continue;
+      for (k = 0; k < mm->nustreams && mm->ustreams[k] != st; k++) {}
+      if (k == mm->nustreams) mm->ustreams[mm->nustreams++] = st;
+    }
+  }
+  free(keys); free(order); free(first_orig); free(h_dest); free(h_ft); free(h_fi); free(h_xdw); free(h_pt);
   if (!ok) { osqp_multi_free(mm); return RLDL_MEM_ALLOC_ERROR; }
   *mp = mm;
   return 0;
@@ -654,21 +719,13 @@ c_int osqp_multi_solve(osqp_multi *mm) {
   if (!mm) return 7;
   if (!multi_qualifies(mm->ws, mm->count)) return 2;              /* settings of a member changed since creation: the caller solves the workspaces one by one */
   w0 = mm->ws[0]; st = (hipStream_t)mm->stream;
-  for (g = 0; g < mm->count; g++)                                 /* work still queued on the workspaces' own streams comes first */
-    if (mm->ws[g]->stream != mm->stream && !HIP_OK(hipStreamSynchronize((hipStream_t)mm->ws[g]->stream))) return 1;
+  for (p = 0; p < mm->nustreams; p++)                             /* work still queued on the workspaces' own streams comes first */
+    if (!HIP_OK(hipStreamSynchronize((hipStream_t)mm->ustreams[p]))) return 1;
   if (multi_sync_W(mm)) return 1;
   if (rldl_launch_multi_solve_begin(&mm->M, (int)mm->total, (int)mm->n, (int)mm->m, w0->st.warm_start ? 0 : 1, 0, mm->stream)) return 1;
   for (p = 0; p < mm->nparts; p++) {                              /* the fused iterations: one launch per kernel instantiation */
-    const int gs = mm->part_first[p], ge = mm->part_first[p + 1];
-    const osqp_batch *wp = mm->ws[gs];
-    rldl_dev_multi Mp;
-    int i;
-    memset(&Mp, 0, sizeof(Mp));
-    Mp.ngroups = ge - gs;
-    for (i = 0; i <= ge - gs; i++) Mp.first_tile[i] = mm->M.first_tile[gs + i] - mm->M.first_tile[gs];
-    for (i = 0; i < ge - gs; i++) Mp.xdw[i] = mm->M.xdw[gs + i];
-    Mp.S = mm->dS + gs; Mp.N = mm->dN + gs; Mp.W = mm->dW + gs;
-    if (rldl_launch_multi_admm_iters(&Mp, &wp->ls->dsym, &wp->ls->num, &wp->W, (int)w0->st.max_iter, mm->part_xdw[p], mm->stream)) return 1;
+    const osqp_batch *wp = mm->ws[mm->part_first[p]];
+    if (rldl_launch_multi_admm_iters(&mm->Mp[p], &wp->ls->dsym, &wp->ls->num, &wp->W, (int)w0->st.max_iter, mm->part_xdw[p], mm->stream)) return 1;
   }
   if (rldl_launch_multi_check_final(&mm->M, &w0->ls->dsym, &w0->W, (int)mm->total, (int)w0->st.max_iter, (int)(mm->n + mm->m), mm->stream)) return 1;
   for (g = 0; g < mm->count; g++) { mm->ws[g]->last_loop_launches = w0->st.max_iter; mm->ws[g]->last_loop_groups = 1; }
@@ -696,13 +753,23 @@ c_int osqp_multi_update_P_A(osqp_multi *mm, const c_float *const *d_Px, const c_
   if (!mm || !d_Px || !d_Ax) return 1;
   if (mm->upd_key < 0) return 2;
   C = mm->count;
-  memset(&PA, 0, sizeof(PA));
-  for (i = 0; i < C; i++) {
-    osqp_batch *w = mm->ws[i];
-    if (!d_Px[mm->orig_of[i]] || !d_Ax[mm->orig_of[i]]) return 1;
-    if (w->stream != mm->stream && !HIP_OK(hipStreamSynchronize((hipStream_t)w->stream))) return 1;
-    PA.Px[i] = d_Px[mm->orig_of[i]]; PA.Ax[i] = d_Ax[mm->orig_of[i]];
-    PA.keepP[i] = w->Px; PA.keepA[i] = w->Ax;
+  {
+    const int tn = mm->pa_turn;
+    const double **hp = mm->h_pa[tn], **dp = mm->d_pa[tn];
+    mm->pa_turn ^= 1;
+    if (!HIP_OK(hipEventSynchronize((hipEvent_t)mm->ev_pa[tn]))) return 1;   /* (the copy that last read this pinned set has run) */
+    for (i = 0; i < mm->nustreams; i++)
+      if (!HIP_OK(hipStreamSynchronize((hipStream_t)mm->ustreams[i]))) return 1;
+    for (i = 0; i < C; i++) {
+      osqp_batch *w = mm->ws[i];
+      if (!d_Px[mm->orig_of[i]] || !d_Ax[mm->orig_of[i]]) return 1;
+      hp[i] = d_Px[mm->orig_of[i]]; hp[C + i] = d_Ax[mm->orig_of[i]];
+      hp[2 * C + i] = w->Px; hp[3 * C + i] = w->Ax;
+    }
+    if (!HIP_OK(hipMemcpyAsync((void *)dp, hp, sizeof(double *) * 4 * (size_t)C, hipMemcpyHostToDevice, (hipStream_t)mm->stream)) ||
+        !HIP_OK(hipEventRecord((hipEvent_t)mm->ev_pa[tn], (hipStream_t)mm->stream))) return 1;
+    PA.Px = (const double *const *)dp; PA.Ax = (const double *const *)(dp + C);
+    PA.keepP = (double *const *)(dp + 2 * C); PA.keepA = (double *const *)(dp + 3 * C);
   }
   if (multi_sync_W(mm)) return 1;
   if (rldl_launch_multi_update(&mm->M, &PA, (int)mm->total, mm->upd_key, mm->upd_flds, mm->upd_ilds, mm->stream)) return 1;

@@ -86,7 +86,7 @@ typedef struct {
   int arrow_vsteps, arrow_vrows;          /* virtual rows: coupling rows cut into pieces of <= vsteps entries, one piece per lane */
   int tile_ok, tile_ta, tile_tq, tile_lanes, nTi, ldTi;   /* tail inverse by register tiles (rldl_symbolic.h); ldTi = nTi rounded up to even */
   int po_tlane, po_tmap, po_tislot, po_tmask, po_pinv, po_trc;
-  int tile_admm_ok, tile_vslots, tile_slots, po_tpos;   /* ADMM slots of the tile kernels (rldl_symbolic.h) */
+  int tile_admm_ok, tile_scatter_ok, tile_vslots, tile_slots, po_tpos;   /* ADMM slots of the tile kernels (rldl_symbolic.h) */
   int tile_ck[3], tile_tk, tile_sp, po_cmap, po_crow;            /* backward coupling product gathered by the owner lane */
   int arrow_g0, arrow_g;       /* index range of the tail group */
   int arrow_tb;                /* its triangle base relative to slot nOp, or -1 */
@@ -140,19 +140,19 @@ typedef struct {
 /* Several workspaces in ONE launch (batches whose instances fall into a few sparsity patterns, one workspace per pattern): the
  * kernels that take this descriptor look their workgroup up in first_* and run it on the structs of its group.  ngroups = 0: an
  * ordinary launch on the structs passed by value. */
-#define RLDL_MULTI_MAX 64
 typedef struct {
   int ngroups;
-  int first_tile[RLDL_MULTI_MAX + 1];     /* first workgroup of each group in grids of TILE_WPB instances per workgroup (k_tile_admm) */
-  int first_inst[RLDL_MULTI_MAX + 1];     /* first workgroup in grids of one instance per workgroup (k_solve_begin, k_admm_check, k_multi_gather) */
-  int xdw[RLDL_MULTI_MAX];                /* per-wave LDS doubles of k_tile_admm */
+  int total_tiles, total_insts;           /* workgroups of the two kinds of grid */
+  const int *first_tile;                  /* DEVICE [ngroups + 1]: first workgroup of each group in grids of TILE_WPB instances per workgroup (k_tile_admm) */
+  const int *first_inst;                  /* DEVICE [ngroups + 1]: first workgroup in grids of one instance per workgroup (k_solve_begin, k_admm_check, k_multi_gather) */
+  const int *xdw;                         /* DEVICE [ngroups]: per-wave LDS doubles of k_tile_admm */
   const rldl_dev_sym *S;                  /* device arrays [ngroups] */
   const rldl_dev_num *N;
   const rldl_dev_admm *W;
 } rldl_dev_multi;
 /* per-group value arrays of an update of all groups: the caller's new P / A values and the workspaces' own copies, which the scatter
- * writes on the way.  Passed by value (kernel argument): captured at launch time, no staging buffer a later call could overwrite. */
-typedef struct { const double *Px[RLDL_MULTI_MAX], *Ax[RLDL_MULTI_MAX]; double *keepP[RLDL_MULTI_MAX], *keepA[RLDL_MULTI_MAX]; } rldl_dev_multi_pa;
+ * writes on the way.  DEVICE arrays [ngroups] of device pointers. */
+typedef struct { const double *const *Px, *const *Ax; double *const *keepP, *const *keepA; } rldl_dev_multi_pa;
 
 /* shared-memory footprint (bytes) of the LDS-resident variants; the launchers pick the global-memory
  * variant by themselves when this exceeds RLDL_LDS_LIMIT */

@@ -65,10 +65,10 @@ __device__ __forceinline__ int wave_any(int p) { return __any(p); }
 // Kx[rhotoK[j]] = -1/rho[j], sigma-only slots.  One workgroup of 256 threads per instance.
 // ------------------------------------------------------------------------------------------------
 // Several workspaces in one launch (rldl_dev_multi): group of workgroup `bid` in a grid whose groups start at first[]
-__device__ __forceinline__ int multi_group(const int *first, int ng, int bid) {
-  int g = 0;
-  while (g + 1 < ng && bid >= first[g + 1]) g++;
-  return g;
+__device__ __forceinline__ int multi_group(const int *__restrict__ first, int ng, int bid) {   // largest g with first[g] <= bid (bisection: a set may hold thousands of groups)
+  int lo = 0, hi = ng;
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (first[mid] <= bid) lo = mid; else hi = mid; }
+  return lo;
 }
 __device__ __forceinline__ void kkt_assemble_body(const rldl_dev_sym &S, const rldl_dev_num &Nn, const double *__restrict__ Px,
                                                   const double *__restrict__ Ax, const double *__restrict__ rho_vec,
@@ -3321,8 +3321,11 @@ __global__ __launch_bounds__(256, 2) void k_tile_admm(rldl_dev_sym S, rldl_dev_n
   const unsigned jra = lane < S.arrow_vrows ? xb + 8u * (unsigned)(S.plan + S.po_avrow)[lane] : dmy;
   const unsigned dta = lane < g ? xb + 8u * (unsigned)(g0 + lane) : dmy;
   const double dtail = Fg[S.nS + g0 + (lane < g ? lane : 0)];
-  ColRegs<TK> Q;                                                 // the owner's copy of the coupling values (backward product as a gather)
-  col_load<TK>(S, Fg, lane, xb + 8u * (unsigned)g0, dmy, Q);
+  // TK > 0: the owner's copy of the coupling values (backward product as a gather).  TK == 0: no copies -- the backward product is the
+  // scatter of tile_tri_solve<.., true> (atomics into the head slots of x), for patterns whose owner-gather steps fit no compiled split
+  ColRegs<(TK > 0 ? TK : 2)> Q;
+  if constexpr (TK > 0) col_load<TK>(S, Fg, lane, xb + 8u * (unsigned)g0, dmy, Q);
+  unsigned zh[TS];                                               // TK == 0: address of the slot's x entry when that is a head entry, else the dummy word
   int oo[TS];                                                    // index of the slot's entry in its own arrays (variable 0..n-1, constraint 0..m-1), -1: none
   unsigned xz[TS];                                               // address of x[position] | address where the solve leaves the entry's x (dummy: head entry) << 16
   double va[TS], vb[TS], rinv[TS];                               // slot 0: x, q; slots 1, 2: z, y, rho_inv
@@ -3337,7 +3340,8 @@ __global__ __launch_bounds__(256, 2) void k_tile_admm(rldl_dev_sym S, rldl_dev_n
       const int o = on ? permg[jp] : 0, i = var ? o : o - n;      // (host: slot 0 holds perm < n, the others perm >= n)
       oo[t] = on ? i : -1;
       const unsigned xa = on ? xb + 8u * (unsigned)jp : dmy;
-      xz[t] = xa | ((head ? dmy : xa) << 16);
+      xz[t] = xa | ((head && TK > 0 ? dmy : xa) << 16);            // (scatter variant: a head slot of x ends as -sum_r L(r, c) x_r and is read like a tail entry)
+      zh[t] = head && TK == 0 ? xa : dmy;
       va[t] = !on ? 0.0 : var ? x[i] : z[i];
       vb[t] = !on ? 0.0 : var ? q[i] : y[i];
       const bool con = on && !var;
@@ -3362,11 +3366,13 @@ __global__ __launch_bounds__(256, 2) void k_tile_admm(rldl_dev_sym S, rldl_dev_n
     for (int s2 = 0; s2 < TA; s2++) asm volatile("" : "+v"(A.rc[s2]));
 #pragma unroll
     for (int t = 0; t < TS; t++) asm volatile("" : "+v"(xz[t]), "+v"(oo[t]));   // (oo: else the 15 store addresses of the last iteration are hoisted)
+    if constexpr (TK > 0) {
 #pragma unroll
-    for (int k2 = 0; k2 < TK / 2; k2++) asm volatile("" : "+v"(Q.a[k2]));
+      for (int k2 = 0; k2 < TK / 2; k2++) asm volatile("" : "+v"(Q.a[k2]));
+    }
     unsigned cbo = cb;
     asm volatile("" : "+v"(cbo));
-    const unsigned za[TS] = {dmy, dmy, dmy};                     // (unused: no scatter)
+    const unsigned za[TS] = {zh[0], zh[1], zh[2]};               // (TK > 0: all dummy words, no scatter)
     double rhs[TS];                                              // compute_rhs (auxil.c:164-178) in permuted order
     rhs[0] = sigma * va[0] - vb[0];
 #pragma unroll
@@ -3375,9 +3381,9 @@ __global__ __launch_bounds__(256, 2) void k_tile_admm(rldl_dev_sym S, rldl_dev_n
     for (int t = 0; t < TS; t++) lds_st(shb, pk_lo(xz[t]), rhs[t]);
     wave_sync();
     if (trit && lane == 0) tr[1] = wall_clock64();              // rhs in LDS
-    tile_tri_solve<TG, TA, TS, false>(R, C, T, A, dtail, shb, jra, dta, za, lane, trit ? tr : nullptr);
+    tile_tri_solve<TG, TA, TS, TK == 0>(R, C, T, A, dtail, shb, jra, dta, za, lane, trit ? tr : nullptr);
     double hs[TS] = {0.0, 0.0, 0.0};                             // sum_r L(r, c) x_r of the head entry this lane owns in slot t (0: tail entry)
-    col_gather<TK, SP>(Q, shb, hs[1], hs[2]);
+    if constexpr (TK > 0) col_gather<TK, SP>(Q, shb, hs[1], hs[2]);
     if (trit && lane == 0) tr[5] = wall_clock64();              // backward coupling product done
     double xs_[TS], dinv[TS], lo[TS], hi[TS], rho[TS], dl[TS];
 #pragma unroll
@@ -3819,12 +3825,18 @@ static bool tile_usable(const rldl_dev_sym *S, const rldl_dev_num *Nn) {
 }
 // fused ADMM iterations: also needs the slot table (at most 3 slots of variables-only / constraints-only positions); the wave
 // timeline (W->trace) exists for the metric shape's instantiation only
+// owner-gather variant: its steps fit a compiled split and the register file
+static bool tile_admm_gather(const rldl_dev_sym *S) {
+  static const int off = getenv("RLDL_TILE_SCATTER") ? 1 : 0;      // diagnostic: every pattern on the scatter variant
+  const int tg = S->arrow_vsteps <= 12 ? 12 : S->arrow_vsteps <= 18 ? 18 : 24;
+  return !off && S->tile_admm_ok && 2 * tg + 2 * S->tile_ta * S->tile_ta + (26 * S->tile_tk) / 10 + 89 <= 256;
+}
 static bool tile_admm_usable(const rldl_dev_sym *S, const rldl_dev_num *Nn, const rldl_dev_admm *W) {
   // register need of the instantiation the launcher would pick (measured fit: 2 TG + 2 TA^2 + 2.6 TK + 89): beyond 256 the
   // kernel would spill inside its loop -- those shapes stay on the sweep kernels
-  const int tg = S->arrow_vsteps <= 12 ? 12 : S->arrow_vsteps <= 18 ? 18 : 24;
-  if (2 * tg + 2 * S->tile_ta * S->tile_ta + (26 * S->tile_tk) / 10 + 89 > 256) return false;
-  return tile_usable(S, Nn) && S->tile_admm_ok && (!W->trace || (S->arrow_vsteps > 12 && S->arrow_vsteps <= 18 && S->tile_ta == 5 && S->tile_tk == 24 && S->tile_sp == 18));
+  if (!tile_usable(S, Nn)) return false;
+  if (tile_admm_gather(S)) return !W->trace || (S->arrow_vsteps > 12 && S->arrow_vsteps <= 18 && S->tile_ta == 5 && S->tile_tk == 24 && S->tile_sp == 18);
+  return S->tile_scatter_ok && !W->trace;                          // the scatter variant (k_tile_admm<.., TK = 0>)
 }
 #define TILE_TA_SWITCH(CALL)                  \
   switch (S->tile_ta) {                       \
@@ -3904,7 +3916,7 @@ static int launch_tile_admm(const rldl_dev_sym *S, const rldl_dev_num *Nn, const
 #define TA_(TG, TA, TK, SP) do { if constexpr (2 * TG + 2 * TA * TA + (26 * TK) / 10 + 89 <= 256) { \
     if (M) hipLaunchKernelGGL((k_tile_admm<TG, TA, TK, SP, false, true>), dim3(grid), dim3(TILE_WPB * WAVE), lds, (hipStream_t)stream, *S, *Nn, *W, pw, iters, MM); \
     else hipLaunchKernelGGL((k_tile_admm<TG, TA, TK, SP, false>), dim3(grid), dim3(TILE_WPB * WAVE), lds, (hipStream_t)stream, *S, *Nn, *W, pw, iters, MM); launched = 1; } } while (0)
-#define TK_(TG, TA) switch (S->tile_tk * 100 + S->tile_sp) { case 1612: TA_(TG, TA, 16, 12); break; case 1610: TA_(TG, TA, 16, 10); break; \
+#define TK_(TG, TA) switch (tile_admm_gather(S) ? S->tile_tk * 100 + S->tile_sp : 0) { case 0: TA_(TG, TA, 0, 0); break; case 1612: TA_(TG, TA, 16, 12); break; case 1610: TA_(TG, TA, 16, 10); break; \
     case 2418: TA_(TG, TA, 24, 18); break; case 2416: TA_(TG, TA, 24, 16); break; case 3224: TA_(TG, TA, 32, 24); break; case 3220: TA_(TG, TA, 32, 20); break; default: return -1; }
   if (S->arrow_vsteps <= 12) {
 #define C(TA) TK_(12, TA)
@@ -4304,9 +4316,15 @@ extern "C" int rldl_launch_multi_update(const rldl_dev_multi *M, const rldl_dev_
 // which groups may share the launches: the instantiation of k_tile_admm their pattern selects (-1: not on the tile kernels) and
 // the entry-parallel check kernel
 extern "C" int rldl_multi_key(const rldl_dev_sym *S, const rldl_dev_num *Nn, const rldl_dev_admm *W) {
-  if (!(arrow_usable(S) && S->N <= 8 * WAVE && tile_admm_usable(S, Nn, W)) || W->trace || !S->flat_ok || getenv("RLDL_CHECK_STAGED")) return -1;
+  if (!(arrow_usable(S) && S->N <= 8 * WAVE && tile_admm_usable(S, Nn, W)) || W->trace || !S->flat_ok || getenv("RLDL_CHECK_STAGED")) {
+    if (getenv("RLDL_VERBOSE"))
+      fprintf(stderr, "[rldl] pattern off the tile chain: arrow_ok %d vsteps %d vrows %d g %d tb %d | tile_ok %d ta %d admm_ok %d vslots %d slots %d ck %d %d %d tk %d sp %d | flat %d\n",
+              S->arrow_ok, S->arrow_vsteps, S->arrow_vrows, S->arrow_g, S->arrow_tb, S->tile_ok, S->tile_ta, S->tile_admm_ok, S->tile_vslots, S->tile_slots,
+              S->tile_ck[0], S->tile_ck[1], S->tile_ck[2], S->tile_tk, S->tile_sp, S->flat_ok);
+    return -1;
+  }
   const int tg = S->arrow_vsteps <= 12 ? 12 : S->arrow_vsteps <= 18 ? 18 : 24;
-  return ((tg * 16 + S->tile_ta) * 64 + S->tile_tk) * 64 + S->tile_sp;
+  return tile_admm_gather(S) ? ((tg * 16 + S->tile_ta) * 64 + S->tile_tk) * 64 + S->tile_sp : ((tg * 16 + S->tile_ta) * 64) * 64;   // (scatter variant: tk = sp = 0)
 }
 extern "C" int rldl_multi_tile_xdw(const rldl_dev_sym *S) { return tile_per_wave(S); }
 extern "C" int rldl_multi_tile_wpb(void) { return TILE_WPB; }
@@ -4319,7 +4337,7 @@ extern "C" int rldl_launch_multi_solve_begin(const rldl_dev_multi *M, int total,
 extern "C" int rldl_launch_multi_admm_iters(const rldl_dev_multi *M, const rldl_dev_sym *S0, const rldl_dev_num *N0, const rldl_dev_admm *W0,
                                             int iters, int max_xdw, void *stream) {
   if (iters <= 0 || M->ngroups <= 0) return 0;
-  return launch_tile_admm(S0, N0, W0, iters, stream, M, M->first_tile[M->ngroups], max_xdw);
+  return launch_tile_admm(S0, N0, W0, iters, stream, M, M->total_tiles, max_xdw);
 }
 extern "C" int rldl_launch_multi_check_final(const rldl_dev_multi *M, const rldl_dev_sym *S0, const rldl_dev_admm *W0, int total, int iter,
                                              int max_nm, void *stream) {
@@ -4330,11 +4348,12 @@ extern "C" int rldl_launch_multi_check_final(const rldl_dev_multi *M, const rldl
 }
 // verdicts of the factorisations enqueued since the last read, one word per group: the sticky flags of rldl_dev_num.fail, read and cleared
 __global__ void k_multi_fail(rldl_dev_multi M, int *__restrict__ out) {
-  const int g = threadIdx.x;
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g < M.ngroups) out[g] = M.N[g].fail ? atomicExch(M.N[g].fail, 0) : 0;
 }
 extern "C" int rldl_launch_multi_fail(const rldl_dev_multi *M, int *d_out, void *stream) {
-  hipLaunchKernelGGL(k_multi_fail, dim3(1), dim3(RLDL_MULTI_MAX), 0, (hipStream_t)stream, *M, d_out);
+  if (M->ngroups <= 0) return 0;
+  hipLaunchKernelGGL(k_multi_fail, dim3((M->ngroups + 63) / 64), dim3(64), 0, (hipStream_t)stream, *M, d_out);
   return launch_status();
 }
 // results of every group into caller-order arrays, one workgroup per instance

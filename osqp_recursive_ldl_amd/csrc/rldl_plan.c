@@ -40,7 +40,7 @@ int rldl_plan_build(rldl_symbolic *s) {
   int ng = 0, i, k, c, p, q, nO = 0, nOp = 0, tri = 0, na = 0, nr = 0, words, nfs = 0, nbs = 0, rc = -2;
   int arrow_k = -1, arrow_steps = 0, ngather = 0, ntri = 0, vpad = 0;
 
-  s->plan_ok = 0; s->tile_ok = 0; s->tile_admm_ok = 0;
+  s->plan_ok = 0; s->tile_ok = 0; s->tile_admm_ok = 0; s->tile_scatter_ok = 0;
   s->LtoS = (int *)malloc(sizeof(int) * (size_t)(s->nnzL > 0 ? s->nnzL : 1));
   group_of = (int *)malloc(sizeof(int) * (size_t)(N + 1));
   gstart = (int *)malloc(sizeof(int) * (size_t)(N + 2));
@@ -207,6 +207,9 @@ int rldl_plan_build(rldl_symbolic *s) {
       s->po_trc = words; words += a * 64;
       s->tile_vslots = (s->n + 63) / 64; s->tile_slots = s->tile_vslots + (s->m + 63) / 64;
       s->tile_admm_ok = s->tile_slots <= 3 && !s->polish;
+      /* fused iterations with the backward coupling product as a SCATTER (no owner copies of the coupling values, fewer registers): what a
+       * pattern runs whose owner-gather steps do not fit the compiled splits or the register file; needs only the slot layout */
+      s->tile_scatter_ok = s->tile_slots <= 3 && s->tile_vslots == 1 && !s->polish;
       s->po_tpos = words; words += 3 * 64;
       /* owner gather of the backward coupling product: positions of a kind by decreasing column count, steps per slot */
       s->tile_ck[0] = s->tile_ck[1] = s->tile_ck[2] = 0; s->tile_tk = 16; s->tile_sp = 12;
@@ -445,7 +448,7 @@ int rldl_plan_build(rldl_symbolic *s) {
       const int g0 = gstart[arrow_k];
       for (l = 0; l < 3 * 64; l++) tp[l] = -1;
       for (l = 0; l < (s->tile_tk / 2) * 64; l++) { cm[l] = 0xffffffffu; cr[l] = 0u; }
-      if (s->tile_admm_ok) {
+      if (s->tile_admm_ok || s->tile_scatter_ok) {
         kv *ord = (kv *)malloc(sizeof(kv) * (size_t)(N + 1));
         int kind, t;
         if (!ord) goto out;
@@ -457,6 +460,7 @@ int rldl_plan_build(rldl_symbolic *s) {
           for (i = 0; i < cntk; i++) tp[base + i] = ord[i].idx;
         }
         free(ord);
+        if (s->tile_admm_ok)
         /* Entries of the owner's column on the steps [e0, e0 + ck[t]) of its slot.  WHICH step an entry takes is free, and it
          * decides the LDS bank conflicts of the gather: a ds_read_b64 serves 32 lanes per pass and two lanes of a pass collide
          * when they read different words of one bank pair ((word index) mod 32).  Greedy placement, lane by lane: an entry goes

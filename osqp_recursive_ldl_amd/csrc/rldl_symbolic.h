@@ -77,7 +77,7 @@ typedef struct {
   /* ADMM slots of the tile kernels: the permuted positions are dealt to (slot, lane) so that a slot holds variables only or
    * constraints only (uniform code per slot, no per-lane role test): po_tpos [3][64] = permuted position or -1;
    * tile_vslots = number of leading variable slots, tile_slots = slots in use (<= 3; more -> tile_admm_ok = 0) */
-  int tile_admm_ok, tile_vslots, tile_slots, po_tpos;
+  int tile_admm_ok, tile_scatter_ok, tile_vslots, tile_slots, po_tpos;   /* tile_scatter_ok: the slot layout alone (fused iterations with the backward coupling product as a scatter) */
   /* Backward coupling product as a GATHER by the owner of each head entry (scattered ds_add_f64 costs ~14 LDS cycles per
    * instruction, a read 2-5): the lane that owns position c in slot t also holds the entries L(r, c) of column c (a second
    * register copy of the coupling values) and sums L(r, c) x_r itself.  Positions are dealt to the slots of their kind by

@@ -1,4 +1,5 @@
-"""Batches whose instances do NOT share one sparsity pattern ("per-instance pattern" variant of config 2).
+"""Batches whose instances do NOT share one sparsity pattern ("per-instance pattern" variant of config 2) -- down to
+one pattern per instance (the reference's semantics: every osqp_setup owns its pattern, qdldl_interface.c:99-166).
 
 The backend factorises one pattern per handle, so the instances are bucketed by pattern: one OSQPBatch per distinct
 (P pattern, A pattern).  With a fixed number of iterations (no termination checks, no rho adaptation, no polish) and patterns
@@ -39,12 +40,13 @@ class OSQPBatchGroups:
         dev = torch.device(device)
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)
         self.groups = []
-        for idx in buckets.values():
+        pool = [torch.cuda.Stream(device=dev) for _ in range(min(8, len(buckets)))]   # (a stream per group only pays for few groups)
+        for gi, idx in enumerate(buckets.values()):
             Pu, Ac = canon[idx[0]]
             Px = np.stack([canon[i][0].data for i in idx]); Ax = np.stack([canon[i][1].data for i in idx])
             q = np.stack([np.asarray(problems[i][1], float) for i in idx])
             l = np.stack([np.asarray(problems[i][3], float) for i in idx]); u = np.stack([np.asarray(problems[i][4], float) for i in idx])
-            stream = torch.cuda.Stream(device=dev)
+            stream = pool[gi % len(pool)]
             torch.cuda.synchronize(dev)                              # uploads above ran on torch's current stream
             w = OSQPBatch(CscPattern(Pu), CscPattern(Ac), t(Px), t(Ax), t(q), t(l), t(u), stream=stream, **settings)
             if w.status != 0:
@@ -57,18 +59,32 @@ class OSQPBatchGroups:
         # all groups in one launch chain when the set qualifies (osqp_multi_create returns 2 otherwise)
         self._multi = None
         self._mstream = torch.cuda.Stream(device=dev)
-        hs = (C.c_void_p * len(self.groups))(*[w.h for _, w in self.groups])
-        dest = np.ascontiguousarray(order, dtype=np.int64)
-        mh = C.c_void_p()
-        rc = _lib.lib().osqp_multi_create(C.byref(mh), hs, len(self.groups), dest.ctypes.data_as(_lib.IP), C.c_void_p(self._mstream.cuda_stream)) if one_launch else 2
-        if rc == 0:
-            self._multi = mh
-            B, n, m = self.count, self.n, self.m
-            f = lambda *shape: torch.empty(shape, dtype=torch.float64, device=dev)
-            i = lambda *shape: torch.empty(shape, dtype=torch.int32, device=dev)
-            self._out = dict(x=f(B, n), y=f(B, m), z=f(B, m), status=i(B), iter=i(B), obj=f(B), pri_res=f(B), dua_res=f(B))
-        elif rc != 2:
-            raise RuntimeError("osqp_multi_create failed (%d)" % rc)
+        # the groups whose patterns run on the tile kernels form ONE set (a handful of launches for all of them); a group whose pattern
+        # is off those kernels (a few per hundred random patterns) keeps its own stream and is solved beside the set
+        L = _lib.lib()
+        self._in_set = [int(L.osqp_batch_multi_key(w.h)) >= 0 for _, w in self.groups] if one_launch else [False] * len(self.groups)
+        members = [k for k, ok in enumerate(self._in_set) if ok]
+        if members:
+            hs = (C.c_void_p * len(members))(*[self.groups[k][1].h for k in members])
+            rows = torch.cat([self.groups[k][0] for k in members])            # caller row of every stacked instance of the set
+            self._set_rows = rows
+            whole = len(members) == len(self.groups)
+            # every group in the set: the set writes straight into caller order; else into compact arrays of its own that solve() spreads
+            dest = np.ascontiguousarray(rows.cpu().numpy(), dtype=np.int64) if whole else np.arange(int(rows.numel()), dtype=np.int64)
+            mh = C.c_void_p()
+            rc = L.osqp_multi_create(C.byref(mh), hs, len(members), dest.ctypes.data_as(_lib.IP), C.c_void_p(self._mstream.cuda_stream))
+            if rc == 0:
+                self._multi = mh
+                self._members = members
+                Bs, n, m = int(rows.numel()), self.n, self.m
+                f = lambda *shape: torch.empty(shape, dtype=torch.float64, device=dev)
+                i = lambda *shape: torch.empty(shape, dtype=torch.int32, device=dev)
+                self._out = dict(x=f(Bs, n), y=f(Bs, m), z=f(Bs, m), status=i(Bs), iter=i(Bs), obj=f(Bs), pri_res=f(Bs), dua_res=f(Bs))
+                self._whole = whole
+            elif rc != 2:
+                raise RuntimeError("osqp_multi_create failed (%d)" % rc)
+        if self._multi is None:
+            self._in_set = [False] * len(self.groups)
 
     @property
     def n_patterns(self):
@@ -76,18 +92,29 @@ class OSQPBatchGroups:
 
     @property
     def one_launch(self):
-        """True when a solve of all groups is one launch chain (osqp_multi_solve)."""
+        """True when a solve of (nearly) all groups is one launch chain (osqp_multi_solve); groups_outside_the_chain counts the rest."""
         return self._multi is not None
+
+    @property
+    def groups_outside_the_chain(self):
+        return sum(1 for ok in self._in_set if not ok)
 
     def solve(self):
         """Solve every group and return results in the original instance order (the arrays are reused by the next solve)."""
         import torch
+        rest = [(idx, w) for (idx, w), ok in zip(self.groups, self._in_set) if not ok]
+        for _, w in rest:                                    # the groups outside the set run on their own streams beside it
+            w.solve_async()
+        sub = None
         if self._multi is not None:
             L = _lib.lib()
             rc = L.osqp_multi_solve(self._multi)
             if rc == 2:                                      # a member's settings left the fixed-iteration case: per-workspace route from now on
                 L.osqp_multi_free(self._multi)
                 self._multi = None
+                self._in_set = [False] * len(self.groups)
+                for _, w in rest:
+                    w.wait(clone=False)
                 return self.solve()
             if rc:
                 raise RuntimeError("osqp_multi_solve failed (%d)" % rc)
@@ -95,19 +122,29 @@ class OSQPBatchGroups:
             p = lambda t: C.c_void_p(t.data_ptr())
             if L.osqp_multi_get(self._multi, p(o["x"]), p(o["y"]), p(o["z"]), p(o["status"]), p(o["iter"]), p(o["obj"]), p(o["pri_res"]), p(o["dua_res"])):
                 raise RuntimeError("osqp_multi_get failed")
-            return dict(o)
-        for _, w in self.groups:
-            w.solve_async()
+            if self._whole and not rest:
+                return dict(o)
+            sub = o
         parts, err = [], None
-        for _, w in self.groups:                             # wait for every group before raising: a verdict must not linger in another group
+        for _, w in rest:                                    # wait for every group before raising: a verdict must not linger in another group
             try:
                 parts.append(w.wait(clone=False))
             except RuntimeError as e:
                 err = e
         if err is not None:
             raise err
-        # one concatenation + one gather per result field (not one indexed copy per field and group)
-        return {key: torch.cat([res[key] for res in parts], 0)[self._inv] for key in parts[0]}
+        if sub is None:
+            # one concatenation + one gather per result field (not one indexed copy per field and group)
+            return {key: torch.cat([res[key] for res in parts], 0)[self._inv] for key in parts[0]}
+        out = {}
+        rows_rest = torch.cat([idx for idx, _ in rest]) if rest else None
+        for key, val in sub.items():
+            full = torch.empty((self.count,) + tuple(val.shape[1:]), dtype=val.dtype, device=val.device)
+            full[self._set_rows] = val
+            if rest:
+                full[rows_rest] = torch.cat([res[key] for res in parts], 0)
+            out[key] = full
+        return out
 
     def update_P_A(self, values):
         """New P / A values for every group: values[k] = (Px, Ax) device tensors [batch_k, nnz] of group k (the order of self.groups).
@@ -120,19 +157,22 @@ class OSQPBatchGroups:
         # (an event on the producer stream) and tell the caching allocator which streams still read the arrays
         ready = torch.cuda.Event()
         ready.record(torch.cuda.current_stream(self._dev))
+        rest = [k for k, ok in enumerate(self._in_set) if not ok]
         if self._multi is not None:
             self._mstream.wait_event(ready)
-            for v in values:
+            mv = [values[k] for k in self._members]
+            for v in mv:
                 v[0].record_stream(self._mstream); v[1].record_stream(self._mstream)
-            G = len(values)
-            px = (C.c_void_p * G)(*[C.c_void_p(v[0].data_ptr()) for v in values])
-            ax = (C.c_void_p * G)(*[C.c_void_p(v[1].data_ptr()) for v in values])
+            G = len(mv)
+            px = (C.c_void_p * G)(*[C.c_void_p(v[0].data_ptr()) for v in mv])
+            ax = (C.c_void_p * G)(*[C.c_void_p(v[1].data_ptr()) for v in mv])
             rc = _lib.lib().osqp_multi_update_P_A(self._multi, px, ax)
-            if rc == 0:
-                return
-            if rc != 2:
+            if rc == 2:
+                rest = list(range(len(self.groups)))
+            elif rc:
                 raise RuntimeError("osqp_multi_update_P_A failed (%d)" % rc)
-        for (_, w), (Px, Ax) in zip(self.groups, values):
+        for k in rest:
+            (_, w), (Px, Ax) = self.groups[k], values[k]
             if w._stream is not None:
                 w._stream.wait_event(ready)
                 Px.record_stream(w._stream); Ax.record_stream(w._stream)

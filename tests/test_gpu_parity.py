@@ -637,6 +637,54 @@ def test_pattern_groups_in_one_launch_chain(R):
     g1.cleanup(); g0.cleanup()
 
 
+def test_one_sparsity_pattern_per_instance_in_one_launch_chain(R):
+    """BASELINE config 2, literal reading: every instance with its own sparsity pattern (the reference: each osqp_setup analyses its own
+    pattern, qdldl_interface.c:99-166).  One workspace per pattern, all of them in ONE set (more than the 64 groups one descriptor used to
+    hold); patterns whose owner-gather steps fit no compiled split run the scatter variant of the fused kernel (k_tile_admm<.., TK = 0>)
+    inside the same chain.  Every instance equals the oracle set up on its own pattern."""
+    from osqp_recursive_ldl_amd import _lib
+    kw = dict(rho=0.1, sigma=1e-6, alpha=1.6, max_iter=60, check_termination=0, adaptive_rho=0, warm_start=0, scaling=0)
+    problems, scatter = [], 0
+    for s in range(400):                                            # ~1.5 % of the random patterns need the scatter variant: make sure some are in
+        wl = R.workloads.SharedPatternQPs(pattern_seed=5000 + s)
+        if len(problems) >= 70 and scatter >= 2:
+            break
+        if len(problems) >= 70:                                     # (only looking for scatter patterns from here on)
+            Px, Ax, q, l, u = wl.values(1)
+            w = R.OSQPBatch(wl.P_pattern, wl.A_pattern, dev(Px), dev(Ax), dev(q), dev(l), dev(u), **kw)
+            key = int(_lib.lib().osqp_batch_multi_key(w.h))
+            w.cleanup()
+            if key < 0 or key % 4096 != 0:
+                continue
+        problems.append(wl.instance(0))
+    g = R.OSQPBatchGroups(problems, **kw)
+    assert g.n_patterns == len(problems) > 64
+    keys = [int(_lib.lib().osqp_batch_multi_key(w.h)) for _, w in g.groups]
+    if not any(os.environ.get(k) for k in ("RLDL_NO_TILE", "RLDL_NO_ARROW", "RLDL_CHECK_STAGED")):
+        assert g.one_launch and g.groups_outside_the_chain == 0 and min(keys) >= 0
+        assert sum(1 for k in keys if k % 4096 == 0) >= 2           # scatter-variant patterns are in the chain
+    r = {k: v.clone() for k, v in g.solve().items()}
+    for k, (P, q, A, l, u) in enumerate(problems):
+        w = [w for idx, w in g.groups if int(idx[0]) == k][0]
+        ro = ob.OracleOSQP(P, q, A, l, u, perm=w.linsys().export_symbolic()["perm"], **kw).solve()
+        assert relerr(r["x"][k].cpu().numpy(), ro["x"]) < 1e-8 and relerr(r["y"][k].cpu().numpy(), ro["y"]) < 1e-8, k
+    # new values for every pattern in one update chain, then the same check on a few
+    vals = []
+    for idx, w in g.groups:
+        P, q, A, l, u = problems[int(idx[0])]
+        Pu = sparse.triu(sparse.csc_matrix(P), format="csc"); Pu.sort_indices()
+        Ac = sparse.csc_matrix(A); Ac.sort_indices()
+        vals.append((dev(Pu.data[None, :] * 1.03), dev(Ac.data[None, :] * 0.98)))
+    g.update_P_A(vals)
+    r2 = g.solve()
+    for k in (0, 33, len(problems) - 1):
+        P, q, A, l, u = problems[k]
+        w = [w for idx, w in g.groups if int(idx[0]) == k][0]
+        ro = ob.OracleOSQP(P * 1.03, q, A * 0.98, l, u, perm=w.linsys().export_symbolic()["perm"], **kw).solve()
+        assert relerr(r2["x"][k].cpu().numpy(), ro["x"]) < 1e-8
+    g.cleanup()
+
+
 def test_pattern_groups_values_from_the_producer_stream_and_changed_settings(R):
     """(1) update_P_A values that a torch kernel has just produced on torch's current stream: the chain runs on the set's own
     stream and must be ordered behind the producer (event wait) -- result bit-equal to the per-workspace route fed the same
