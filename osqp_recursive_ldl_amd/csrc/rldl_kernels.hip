@@ -1107,7 +1107,14 @@ __device__ __forceinline__ void wave_sync() {
 // LDS accesses by byte address (shb = base of the wave's LDS region)
 __device__ __forceinline__ double lds_ld(const char *shb, unsigned a) { return *reinterpret_cast<const double *>(shb + a); }
 __device__ __forceinline__ void lds_st(char *shb, unsigned a, double v) { *reinterpret_cast<double *>(shb + a) = v; }
-__device__ __forceinline__ void lds_add(char *shb, unsigned a, double v) { unsafeAtomicAdd(reinterpret_cast<double *>(shb + a), v); }
+// The LDS double atomic of the tile / arrow kernels.  Lanes hand values to OTHER lanes through these adds, a dependence the compiler
+// cannot see: as a plain intrinsic it may move a lane's later ds_read above the lane's own add whenever it proves the two addresses
+// differ -- legal per thread, wrong for lane-to-lane traffic.  asm volatile with a memory clobber pins every LDS access of the wave on
+// its side of the add (the wave's LDS operations then execute in program order), which is what makes the products' phases --
+// reads, adds, reads of the sums -- correct; the wave_sync() fences between phases stay as documentation and cost no instruction.
+__device__ __forceinline__ void lds_add(char *shb, unsigned a, double v) {
+  asm volatile("ds_add_f64 %0, %1" : : "v"((unsigned)(unsigned long long)shb + a), "v"(v) : "memory");
+}
 __device__ __forceinline__ double readlane_f64(double v, int src) {   // src must be wave-uniform
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);

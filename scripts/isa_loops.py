@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """Instruction mix of the loops of one gfx950 kernel (compile-only, no GPU).
-usage: scripts/isa_loops.py <mangled-name substring> [--dump]   (compiles csrc/rldl_kernels.hip to /tmp/rldl_kernels.s once per change)"""
+usage: scripts/isa_loops.py <mangled-name substring> [--dump] [--lds-seq]   (compiles csrc/rldl_kernels.hip to /tmp/rldl_kernels.s once per change)
+--lds-seq: per loop, the order of its LDS operations as the hardware will see them (a wave's LDS operations execute in program order),
+run-length encoded: R = ds_read, W = ds_write, A = ds_add / ds_max (atomic), | = s_waitcnt lgkmcnt.  Lanes hand values to other lanes
+through W and A, so a phase's reads must not appear in front of the previous phase's W / A: the sequence is the evidence."""
 import os, re, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "osqp_recursive_ldl_amd", "csrc", "rldl_kernels.hip")
@@ -29,3 +32,15 @@ for m in re.finditer(r"^(_Z\S*):[^\n]*\n(.*?)\n\s*\.end_amdhsa_kernel", txt, re.
             print("loop %s [%d, %d] %d lines:" % (mm.group(1), a, i, i - a), mix(lines[a:i + 1]))
             if "--dump" in sys.argv:
                 print("\n".join(lines[a:i + 1]))
+            if "--lds-seq" in sys.argv:
+                seq = []
+                for x in lines[a:i + 1]:
+                    c = "R" if re.search(r"\bds_read", x) else "W" if re.search(r"\bds_write", x) else "A" if re.search(r"ds_add|ds_max", x) else \
+                        "|" if re.search(r"s_waitcnt.*lgkmcnt", x) else None
+                    if c is None:
+                        continue
+                    if seq and seq[-1][0] == c:
+                        seq[-1][1] += 1
+                    else:
+                        seq.append([c, 1])
+                print("  LDS order:", " ".join("%s%s" % (c, n if n > 1 else "") for c, n in seq if c != "|" or True).replace("| ", "|"))
