@@ -40,6 +40,7 @@ typedef struct {
 #define HIP_LDL_SOLVER 20
 
 /* ---- error / status codes: include/constants.h:18-51 ---- */
+#define RLDL_LINSYS_SOLVER_LOAD_ERROR 3 /* OSQP_LINSYS_SOLVER_LOAD_ERROR: a library opened at run time is missing (librccl.so for the multi-GPU gather) */
 #define RLDL_LINSYS_SOLVER_INIT_ERROR 4 /* OSQP_LINSYS_SOLVER_INIT_ERROR */
 #define RLDL_NONCVX_ERROR 5             /* OSQP_NONCVX_ERROR */
 #define RLDL_MEM_ALLOC_ERROR 6          /* OSQP_MEM_ALLOC_ERROR */
@@ -311,6 +312,23 @@ c_int osqp_horizon_ld(const osqp_horizon *h, c_int *ld_n, c_int *ld_m);
 c_int osqp_horizon_update_P_A(osqp_horizon *h, const c_float *d_Px, const c_float *d_Ax);   /* osqp_update_P_A at the current horizon */
 c_int osqp_horizon_warm_start(osqp_horizon *h, const c_float *d_x, const c_float *d_y);      /* osqp_warm_start at the current horizon */
 void osqp_horizon_free(osqp_horizon *h);
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * 7. Multi-GPU in C: one process per GPU, the batch shards by contiguous ranges, the data path has no collective;
+ *    ONE RCCL all-gather of the packed result records collects the solutions.  librccl.so is dlopen'ed at the first call (the
+ *    reference loads its optional Pardiso backend the same way, lin_sys/lib_handler.c:7-49): no link-time dependency.
+ *      rank 0:      osqp_dist_unique_id(id)          -> ship the 128 bytes to the other ranks (launcher's business)
+ *      every rank:  osqp_dist_init(&d, id, rank, nranks, stream)
+ *                   ... osqp_batch_solve(w) ...
+ *                   osqp_dist_gather_results(d, w, d_out)   d_out [nranks * batch][n + m + 5] on the device:
+ *                                                           x | y | obj | pri_res | dua_res | iter | status per instance, ranks in order
+ * --------------------------------------------------------------------------------------------------------------------- */
+typedef struct osqp_dist osqp_dist;
+c_int osqp_dist_unique_id(char id[128]);
+c_int osqp_dist_init(osqp_dist **dp, const char id[128], c_int rank, c_int nranks, void *stream);
+c_int osqp_dist_record_len(const osqp_batch *w);                         /* n + m + 5 */
+c_int osqp_dist_gather_results(osqp_dist *d, osqp_batch *w, c_float *d_out);
+void  osqp_dist_free(osqp_dist *d);
 
 const char *rldl_version(void);
 

@@ -70,7 +70,7 @@ EXPORTED = [
     "rldl_batch_init_recursive", "rldl_batch_update_from_stage", "rldl_version",
     "rldl_symbolic_analyze", "rldl_stage_permutation", "rldl_plan_export", "rldl_stage_prod_export", "rldl_setup_AP_matrices", "rldl_csc_free",
     "osqp_horizon_setup", "osqp_horizon_update", "osqp_horizon_workspace", "osqp_horizon_N", "osqp_horizon_last_update",
-    "osqp_horizon_free", "osqp_batch_multi_key", "osqp_horizon_is_single", "osqp_horizon_workspaces", "osqp_horizon_ld", "osqp_horizon_update_P_A", "osqp_horizon_warm_start",
+    "osqp_horizon_free", "osqp_batch_multi_key", "osqp_dist_unique_id", "osqp_dist_init", "osqp_dist_record_len", "osqp_dist_gather_results", "osqp_dist_free", "osqp_horizon_is_single", "osqp_horizon_workspaces", "osqp_horizon_ld", "osqp_horizon_update_P_A", "osqp_horizon_warm_start",
     "osqp_multi_create", "osqp_multi_solve", "osqp_multi_update_P_A", "osqp_multi_get", "osqp_multi_free",
 ]
 
@@ -217,6 +217,16 @@ def _declare(L):
     L.osqp_horizon_N.restype = c_int
     L.osqp_batch_multi_key.argtypes = [VP]
     L.osqp_batch_multi_key.restype = c_int
+    L.osqp_dist_unique_id.argtypes = [C.c_char_p]
+    L.osqp_dist_unique_id.restype = c_int
+    L.osqp_dist_init.argtypes = [C.POINTER(VP), C.c_char_p, c_int, c_int, VP]
+    L.osqp_dist_init.restype = c_int
+    L.osqp_dist_record_len.argtypes = [VP]
+    L.osqp_dist_record_len.restype = c_int
+    L.osqp_dist_gather_results.argtypes = [VP, VP, VP]
+    L.osqp_dist_gather_results.restype = c_int
+    L.osqp_dist_free.argtypes = [VP]
+    L.osqp_dist_free.restype = None
     for name in ("osqp_horizon_is_single", "osqp_horizon_workspaces"):
         getattr(L, name).argtypes = [VP]
         getattr(L, name).restype = c_int

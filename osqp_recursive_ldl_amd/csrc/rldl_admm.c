@@ -522,8 +522,11 @@ struct osqp_multi {
   int *orig_of;                                      /* [count] group i of the set = ws[orig_of[i]] of the caller's array */
   const double **d_pa[2], **h_pa[2];                 /* device / pinned host [4][count], two sets used in turn: Px, Ax, keepP, keepA pointers of an update of all groups */
   void *ev_pa[2]; int pa_turn;                       /* event behind the copy of each set: a set is rewritten only after its last copy has run */
-  int upd_key, upd_flds, upd_ilds;                   /* one update chain for all groups: factor kernel instantiation (-1: not available), LDS sizes */
+  int upd_key, fac_key, upd_flds, upd_ilds;          /* fac_key: factor kernel instantiation shared by all groups (-1: none): the rho refactorisation of a solve;
+                                                      * upd_key: the same when osqp_multi_update_P_A can use it too (no equilibration), else -1; LDS sizes */
   int *h_fail, *d_fail;                              /* pinned / device [count]: factorisation verdicts read back by osqp_multi_solve */
+  int *d_nact, *h_nact;                              /* device [SLOTS] / pinned [2][SLOTS]: instances of all groups still iterating */
+  void *evn[2];
   int w_uploaded;
   void *stream;
   void **ustreams; int nustreams;                    /* the distinct streams of the member workspaces other than `stream` (work queued there comes first) */
@@ -538,6 +541,10 @@ void osqp_multi_free(osqp_multi *mm) {
   if (mm->d_dest) (void)hipFree(mm->d_dest);
   if (mm->d_fail) (void)hipFree(mm->d_fail);
   if (mm->h_fail) (void)hipHostFree(mm->h_fail);
+  if (mm->d_nact) (void)hipFree(mm->d_nact);
+  if (mm->h_nact) (void)hipHostFree(mm->h_nact);
+  if (mm->evn[0]) (void)hipEventDestroy((hipEvent_t)mm->evn[0]);
+  if (mm->evn[1]) (void)hipEventDestroy((hipEvent_t)mm->evn[1]);
   if (mm->d_first_tile) (void)hipFree(mm->d_first_tile);
   if (mm->d_first_inst) (void)hipFree(mm->d_first_inst);
   if (mm->d_xdw) (void)hipFree(mm->d_xdw);
@@ -552,15 +559,18 @@ void osqp_multi_free(osqp_multi *mm) {
  * the launches of osqp_multi_solve), or -1 when the pattern is off the tile kernels (it must be solved on its own) */
 c_int osqp_batch_multi_key(const osqp_batch *w) { return w ? rldl_multi_key(&w->ls->dsym, &w->ls->num, &w->W) : -1; }
 
-/* the fixed-iteration case the launch chain covers: no termination checks, no rho adaptation, no polish, same n, m, max_iter and
- * warm_start in every workspace.  Checked at creation AND at every solve (check_termination, max_iter, warm_start can be changed
- * on a member workspace by osqp_batch_update_settings afterwards). */
+/* what the launch chain covers: no polish; the same n, m, max_iter, warm_start, check_termination and rho adaptation schedule in every
+ * workspace (the host loop of the set is one loop: groups of iterations up to the next check / adaptation, as in osqp_batch_solve;
+ * tolerances and rho are per workspace, the kernels read them from each group's own struct).  Checked at creation AND at every solve
+ * (osqp_batch_update_settings on a member may change them afterwards). */
 static int multi_qualifies(osqp_batch *const *ws, c_int count) {
   c_int g;
   for (g = 0; g < count; g++) {
-    const osqp_batch *w = ws[g];
-    if (!w || w->st.check_termination || w->st.adaptive_rho || w->st.polish || w->n != ws[0]->n || w->m != ws[0]->m ||
-        w->st.max_iter != ws[0]->st.max_iter || w->st.warm_start != ws[0]->st.warm_start) return 0;
+    const osqp_batch *w = ws[g], *w0 = ws[0];
+    if (!w || w->st.polish || w->n != w0->n || w->m != w0->m || w->st.max_iter != w0->st.max_iter || w->st.warm_start != w0->st.warm_start ||
+        w->st.check_termination != w0->st.check_termination || w->st.adaptive_rho != w0->st.adaptive_rho ||
+        w->st.adaptive_rho_interval != w0->st.adaptive_rho_interval)
+      return 0;
   }
   return 1;
 }
@@ -622,6 +632,9 @@ c_int osqp_multi_create(osqp_multi **mp, osqp_batch **ws, c_int count, const c_i
   if (ok && !HIP_OK(hipMalloc((void **)&mm->d_dest, sizeof(int) * (size_t)total))) ok = 0;
   if (ok && !HIP_OK(hipMalloc((void **)&mm->d_fail, sizeof(int) * (size_t)count))) ok = 0;
   if (ok && !HIP_OK(hipHostMalloc((void **)&mm->h_fail, sizeof(int) * (size_t)count, hipHostMallocDefault))) { mm->h_fail = 0; ok = 0; }
+  if (ok && !HIP_OK(hipMalloc((void **)&mm->d_nact, sizeof(int) * RLDL_NACT_SLOTS))) ok = 0;
+  if (ok && !HIP_OK(hipHostMalloc((void **)&mm->h_nact, sizeof(int) * 2 * RLDL_NACT_SLOTS, hipHostMallocDefault))) { mm->h_nact = 0; ok = 0; }
+  for (k = 0; ok && k < 2; k++) if (!HIP_OK(hipEventCreateWithFlags((hipEvent_t *)&mm->evn[k], hipEventDisableTiming))) { mm->evn[k] = 0; ok = 0; }
   if (ok && !HIP_OK(hipMalloc((void **)&mm->d_first_tile, sizeof(int) * (size_t)(count + 1)))) ok = 0;
   if (ok && !HIP_OK(hipMalloc((void **)&mm->d_first_inst, sizeof(int) * (size_t)(count + 1)))) ok = 0;
   if (ok && !HIP_OK(hipMalloc((void **)&mm->d_xdw, sizeof(int) * (size_t)count))) ok = 0;
@@ -631,7 +644,7 @@ c_int osqp_multi_create(osqp_multi **mp, osqp_batch **ws, c_int count, const c_i
     if (ok && !HIP_OK(hipHostMalloc((void **)&mm->h_pa[k], sizeof(double *) * 4 * (size_t)count, hipHostMallocDefault))) { mm->h_pa[k] = 0; ok = 0; }
     if (ok && !HIP_OK(hipEventCreateWithFlags((hipEvent_t *)&mm->ev_pa[k], hipEventDisableTiming))) { mm->ev_pa[k] = 0; ok = 0; }
   }
-  mm->upd_key = -2;
+  mm->upd_key = -2; mm->fac_key = -2;
   if (ok) { h_ft[0] = 0; h_fi[0] = 0; }
   for (i = 0; ok && i < count; i++) {
     const osqp_batch *w = ws[order[i]];
@@ -639,9 +652,10 @@ c_int osqp_multi_create(osqp_multi **mp, osqp_batch **ws, c_int count, const c_i
     mm->ws[i] = ws[order[i]];
     mm->orig_of[i] = order[i];
     {                                                             /* the update chain needs one factor kernel instantiation and no equilibration */
-      const int uk = w->st.scaling ? -1 : rldl_multi_update_key(&w->ls->dsym, &w->ls->num), fl = rldl_multi_update_lds(&w->ls->dsym, 0),
+      const int fk = rldl_multi_update_key(&w->ls->dsym, &w->ls->num), uk = w->st.scaling ? -1 : fk, fl = rldl_multi_update_lds(&w->ls->dsym, 0),
                 il = rldl_multi_update_lds(&w->ls->dsym, 1);
       if (mm->upd_key == -2) mm->upd_key = uk; else if (mm->upd_key != uk) mm->upd_key = -1;
+      if (mm->fac_key == -2) mm->fac_key = fk; else if (mm->fac_key != fk) mm->fac_key = -1;
       if (fl > mm->upd_flds) mm->upd_flds = fl;
       if (il > mm->upd_ilds) mm->upd_ilds = il;
     }
@@ -721,13 +735,54 @@ c_int osqp_multi_solve(osqp_multi *mm) {
   w0 = mm->ws[0]; st = (hipStream_t)mm->stream;
   for (p = 0; p < mm->nustreams; p++)                             /* work still queued on the workspaces' own streams comes first */
     if (!HIP_OK(hipStreamSynchronize((hipStream_t)mm->ustreams[p]))) return 1;
+  if ((w0->st.adaptive_rho && w0->st.adaptive_rho_interval) && mm->fac_key < 0) return 2;   /* rho adaptation refactorises: needs one factor kernel for all groups */
   if (multi_sync_W(mm)) return 1;
   if (rldl_launch_multi_solve_begin(&mm->M, (int)mm->total, (int)mm->n, (int)mm->m, w0->st.warm_start ? 0 : 1, 0, mm->stream)) return 1;
-  for (p = 0; p < mm->nparts; p++) {                              /* the fused iterations: one launch per kernel instantiation */
-    const osqp_batch *wp = mm->ws[mm->part_first[p]];
-    if (rldl_launch_multi_admm_iters(&mm->Mp[p], &wp->ls->dsym, &wp->ls->num, &wp->W, (int)w0->st.max_iter, mm->part_xdw[p], mm->stream)) return 1;
+  {                                                               /* osqp_solve's loop (osqp.c:354-519) for the whole set: see solve_impl */
+    c_int iter = 0, last_iter = 0, nchecks = 0;
+    int can_check = 0, refactored = 0;
+    while (iter < w0->st.max_iter) {
+      c_int next = w0->st.max_iter, k;
+      int do_adapt;
+      if (w0->st.check_termination) { k = (iter / w0->st.check_termination + 1) * w0->st.check_termination; if (k < next) next = k; }
+      if (w0->st.adaptive_rho && w0->st.adaptive_rho_interval) {
+        k = (iter / w0->st.adaptive_rho_interval + 1) * w0->st.adaptive_rho_interval;
+        if (k < next) next = k;
+      }
+      for (p = 0; p < mm->nparts; p++) {                          /* the fused iterations: one launch per kernel instantiation */
+        const osqp_batch *wp = mm->ws[mm->part_first[p]];
+        if (rldl_launch_multi_admm_iters(&mm->Mp[p], &wp->ls->dsym, &wp->ls->num, &wp->W, (int)(next - iter), mm->part_xdw[p], mm->stream)) return 1;
+      }
+      iter = next;
+      can_check = w0->st.check_termination && (iter % w0->st.check_termination == 0);
+      do_adapt = w0->st.adaptive_rho && w0->st.adaptive_rho_interval && (iter % w0->st.adaptive_rho_interval == 0);
+      last_iter = iter;
+      if (can_check || do_adapt) {
+        if (rldl_launch_multi_check(&mm->M, &w0->ls->dsym, &w0->W, (int)mm->total, (int)iter, (can_check ? 1 : 0) | (do_adapt ? 2 : 0), 0,
+                                    (int)(mm->n + mm->m), mm->stream)) return 1;
+        if (do_adapt) {                                           /* osqp_update_rho -> update_rho_vec -> refactor, only where rho moved */
+          if (rldl_launch_multi_update_rho(&mm->M, (int)mm->total, mm->fac_key, mm->upd_flds, mm->upd_ilds, mm->stream)) return 1;
+          refactored = 1;
+        }
+        if (can_check) {                                          /* active instances of all groups, read one check late (as solve_impl) */
+          const int slot = (int)(nchecks & 1);
+          if (rldl_launch_multi_nactive(&mm->M, mm->d_nact, mm->stream)) return 1;
+          if (!HIP_OK(hipMemcpyAsync(&mm->h_nact[slot * RLDL_NACT_SLOTS], mm->d_nact, sizeof(int) * RLDL_NACT_SLOTS, hipMemcpyDeviceToHost, st))) return 1;
+          (void)hipEventRecord((hipEvent_t)mm->evn[slot], st);
+          if (nchecks > 0) {
+            int left = 0, kk;
+            if (!HIP_OK(hipEventSynchronize((hipEvent_t)mm->evn[slot ^ 1]))) return 1;
+            for (kk = 0; kk < RLDL_NACT_SLOTS; kk++) left += mm->h_nact[(slot ^ 1) * RLDL_NACT_SLOTS + kk];
+            if (left == 0) break;
+          }
+          nchecks++;
+        }
+      }
+    }
+    /* tail of osqp_solve (osqp.c:521-633) */
+    if (rldl_launch_multi_check(&mm->M, &w0->ls->dsym, &w0->W, (int)mm->total, (int)last_iter, 0, can_check ? 1 : 2, (int)(mm->n + mm->m), mm->stream)) return 1;
+    if (refactored) for (g = 0; g < mm->count; g++) mm->ws[g]->refactor_pending = 1;
   }
-  if (rldl_launch_multi_check_final(&mm->M, &w0->ls->dsym, &w0->W, (int)mm->total, (int)w0->st.max_iter, (int)(mm->n + mm->m), mm->stream)) return 1;
   for (g = 0; g < mm->count; g++) { mm->ws[g]->last_loop_launches = w0->st.max_iter; mm->ws[g]->last_loop_groups = 1; }
   {                                                               /* verdict of the refactorisations enqueued since the last solve (osqp_multi_update_P_A, _async updates) */
     int pending = 0, bad = 0;

@@ -219,7 +219,12 @@ int rldl_launch_multi_solve_begin(const rldl_dev_multi *M, int total, int n, int
 /* new P / A values for every group in one chain: scatter (+ the workspaces' own copies), arrowhead factorisation, tail inverse */
 int rldl_multi_update_key(const rldl_dev_sym *S, const rldl_dev_num *Nn);
 int rldl_multi_update_lds(const rldl_dev_sym *S, int which);
-int rldl_launch_multi_fail(const rldl_dev_multi *M, int *d_out, void *stream);   /* d_out[g] = sticky factorisation verdict of group g, cleared */
+int rldl_launch_multi_update_rho(const rldl_dev_multi *M, int total, int key, int factor_lds, int invert_lds, void *stream);
+int rldl_launch_multi_nactive(const rldl_dev_multi *M, int *d_out, void *stream);
+int rldl_launch_multi_check(const rldl_dev_multi *M, const rldl_dev_sym *S0, const rldl_dev_admm *W0, int total, int iter, int approximate,
+                            int final_pass, int max_nm, void *stream);
+int rldl_launch_multi_fail(const rldl_dev_multi *M, int *d_out, void *stream);
+int rldl_launch_pack_results(const rldl_dev_admm *W, int n, int m, double *rec, void *stream);   /* rldl_dist.c */   /* d_out[g] = sticky factorisation verdict of group g, cleared */
 int rldl_launch_multi_update(const rldl_dev_multi *M, const rldl_dev_multi_pa *PA, int total, int key, int factor_lds, int invert_lds, void *stream);
 int rldl_launch_multi_admm_iters(const rldl_dev_multi *M, const rldl_dev_sym *S0, const rldl_dev_num *N0, const rldl_dev_admm *W0, int iters,
                                  int max_xdw, void *stream);

@@ -125,6 +125,17 @@ __global__ __launch_bounds__(256) void k_kkt_assemble(rldl_dev_sym S, rldl_dev_n
                                                       double *__restrict__ keepP, double *__restrict__ keepA) {
   kkt_assemble_body(S, Nn, Px, Ax, rho_vec, set_sigma_only, mask, keepP, keepA, blockIdx.x);
 }
+// rho_vec of the instances whose rho moved (W.refactor) into rho_inv and the KKT values, every group of a set (update_rho_vec, qdldl_interface.c:605-619)
+__global__ __launch_bounds__(256) void k_kkt_assemble_multi_rho(rldl_dev_multi M) {
+  const int g = multi_group(M.first_inst, M.ngroups, blockIdx.x);
+  kkt_assemble_body(M.S[g], M.N[g], nullptr, nullptr, M.W[g].rho_vec, 0, M.W[g].refactor, nullptr, nullptr, (int)blockIdx.x - M.first_inst[g]);
+}
+// instances of all groups that are still iterating, per counter slot (the groups keep their own counters; the host reads one array)
+__global__ __launch_bounds__(RLDL_NACT_SLOTS) void k_multi_nactive(rldl_dev_multi M, int *__restrict__ out) {
+  int acc = 0;
+  for (int g = 0; g < M.ngroups; g++) acc += M.W[g].n_active[threadIdx.x];
+  out[threadIdx.x] = acc;
+}
 // the same for the stacked instances of several workspaces: new P / A values of every group (osqp_multi_update_P_A)
 __global__ __launch_bounds__(256) void k_kkt_assemble_multi(rldl_dev_multi M, rldl_dev_multi_pa PA) {
   const int g = multi_group(M.first_inst, M.ngroups, blockIdx.x);
@@ -2469,9 +2480,9 @@ __global__ __launch_bounds__(WAVE) void k_arrow_factor(rldl_dev_sym S, rldl_dev_
   arrow_factor_body<SM>(S, Nn, mask, blockIdx.x);
 }
 template <int SM>
-__global__ __launch_bounds__(WAVE) void k_arrow_factor_multi(rldl_dev_multi M) {
+__global__ __launch_bounds__(WAVE) void k_arrow_factor_multi(rldl_dev_multi M, int masked) {   // masked: only the instances whose W.refactor is set (rho adaptation)
   const int g = multi_group(M.first_inst, M.ngroups, blockIdx.x);
-  arrow_factor_body<SM>(M.S[g], M.N[g], nullptr, (int)blockIdx.x - M.first_inst[g]);
+  arrow_factor_body<SM>(M.S[g], M.N[g], masked ? M.W[g].refactor : nullptr, (int)blockIdx.x - M.first_inst[g]);
 }
 
 // ================================================================================================
@@ -3063,9 +3074,11 @@ __global__ __launch_bounds__(WAVE) void k_tile_invert(rldl_dev_sym S, rldl_dev_n
   tile_invert_body<SM>(S, Nn, mask, blockIdx.x);
 }
 template <int SM>
-__global__ __launch_bounds__(WAVE) void k_tile_invert_multi(rldl_dev_multi M) {
-  const int g = multi_group(M.first_inst, M.ngroups, blockIdx.x);
-  tile_invert_body<SM>(M.S[g], M.N[g], nullptr, (int)blockIdx.x - M.first_inst[g]);
+__global__ __launch_bounds__(WAVE) void k_tile_invert_multi(rldl_dev_multi M, int masked) {
+  const int g = multi_group(M.first_inst, M.ngroups, blockIdx.x), inst = (int)blockIdx.x - M.first_inst[g];
+  int *mask = masked ? M.W[g].refactor : nullptr;
+  tile_invert_body<SM>(M.S[g], M.N[g], mask, inst);
+  if (mask && threadIdx.x == 0) mask[inst] = 0;                  // (last reader of the mask of this rho update)
 }
 
 // LDS per wave of the tile kernels (pws doubles): x (xdw doubles, incl. the padding rows of the last block row), 64 dummy words
@@ -4313,11 +4326,37 @@ extern "C" int rldl_launch_multi_update(const rldl_dev_multi *M, const rldl_dev_
   const dim3 grid(total), blk(WAVE);
   hipLaunchKernelGGL(k_kkt_assemble_multi, grid, dim3(256), 0, (hipStream_t)stream, *M, *PA);
   if (launch_status()) return -1;
-#define MU(SMV) do { hipLaunchKernelGGL(k_arrow_factor_multi<SMV>, grid, blk, (size_t)factor_lds, (hipStream_t)stream, *M); \
+#define MU(SMV, MASKED) do { hipLaunchKernelGGL(k_arrow_factor_multi<SMV>, grid, blk, (size_t)factor_lds, (hipStream_t)stream, *M, MASKED); \
                      if (launch_status()) return -1; \
-                     hipLaunchKernelGGL(k_tile_invert_multi<SMV>, grid, blk, (size_t)invert_lds, (hipStream_t)stream, *M); } while (0)
-  switch (key) { case 16: MU(16); break; case 32: MU(32); break; case 48: MU(48); break; case 56: MU(56); break; case 64: MU(64); break; default: return -1; }
+                     hipLaunchKernelGGL(k_tile_invert_multi<SMV>, grid, blk, (size_t)invert_lds, (hipStream_t)stream, *M, MASKED); } while (0)
+  switch (key) { case 16: MU(16, 0); break; case 32: MU(32, 0); break; case 48: MU(48, 0); break; case 56: MU(56, 0); break; case 64: MU(64, 0); break; default: return -1; }
+  return launch_status();
+}
+// osqp_update_rho of every group of a set after an adapt_rho step (osqp.c:1268-1319 -> update_rho_vec): only the instances whose rho moved
+extern "C" int rldl_launch_multi_update_rho(const rldl_dev_multi *M, int total, int key, int factor_lds, int invert_lds, void *stream) {
+  if (total <= 0) return 0;
+  const dim3 grid(total), blk(WAVE);
+  hipLaunchKernelGGL(k_kkt_assemble_multi_rho, grid, dim3(256), 0, (hipStream_t)stream, *M);
+  if (launch_status()) return -1;
+  switch (key) { case 16: MU(16, 1); break; case 32: MU(32, 1); break; case 48: MU(48, 1); break; case 56: MU(56, 1); break; case 64: MU(64, 1); break; default: return -1; }
 #undef MU
+  return launch_status();
+}
+extern "C" int rldl_launch_multi_nactive(const rldl_dev_multi *M, int *d_out, void *stream) {
+  hipLaunchKernelGGL(k_multi_nactive, dim3(1), dim3(RLDL_NACT_SLOTS), 0, (hipStream_t)stream, *M, d_out);
+  return launch_status();
+}
+// a termination check and / or an adapt_rho step of every group (rldl_launch_admm_check's arguments)
+extern "C" int rldl_launch_multi_check(const rldl_dev_multi *M, const rldl_dev_sym *S0, const rldl_dev_admm *W0, int total, int iter, int approximate,
+                                       int final_pass, int max_nm, void *stream) {
+  if (total <= 0) return 0;
+  int mode = 0;
+  if (approximate & 1) mode |= CHK_TERMINATION;
+  if (approximate & 2) mode |= CHK_ADAPT;
+  if (final_pass) mode |= CHK_FINAL;
+  if (final_pass == 2) mode |= CHK_FINAL_NEEDS_INFO;
+  const size_t lds = sizeof(double) * (size_t)(6 * max_nm + 8);
+  hipLaunchKernelGGL((k_admm_check<false, true>), dim3(total), dim3(WAVE), lds, (hipStream_t)stream, *S0, *W0, iter, mode, *M);
   return launch_status();
 }
 // which groups may share the launches: the instantiation of k_tile_admm their pattern selects (-1: not on the tile kernels) and
@@ -4382,6 +4421,23 @@ extern "C" int rldl_launch_multi_gather(const rldl_dev_multi *M, int total, int 
                                         int *status, int *iter, double *obj, double *pri, double *dua, void *stream) {
   if (total <= 0) return 0;
   hipLaunchKernelGGL(k_multi_gather, dim3(total), dim3(WAVE), 0, (hipStream_t)stream, *M, n, m, dest, x, y, z, status, iter, obj, pri, dua);
+  return launch_status();
+}
+
+// the result record of every instance, packed for the all-gather of a multi-GPU run: [x | y | obj | pri_res | dua_res | iter | status]
+__global__ __launch_bounds__(WAVE) void k_pack_results(rldl_dev_admm W, int n, int m, double *__restrict__ rec) {
+  const int inst = blockIdx.x, lane = threadIdx.x, L = n + m + 5;
+  double *r = rec + (size_t)inst * L;
+  for (int k = lane; k < n; k += WAVE) r[k] = W.sol_x[(size_t)inst * n + k];
+  for (int k = lane; k < m; k += WAVE) r[n + k] = W.sol_y[(size_t)inst * m + k];
+  if (lane == 0) {
+    r[n + m] = W.obj[inst]; r[n + m + 1] = W.pri_res[inst]; r[n + m + 2] = W.dua_res[inst];
+    r[n + m + 3] = (double)W.iter[inst]; r[n + m + 4] = (double)W.status[inst];
+  }
+}
+extern "C" int rldl_launch_pack_results(const rldl_dev_admm *W, int n, int m, double *rec, void *stream) {
+  if (W->batch <= 0) return 0;
+  hipLaunchKernelGGL(k_pack_results, dim3(W->batch), dim3(WAVE), 0, (hipStream_t)stream, *W, n, m, rec);
   return launch_status();
 }
 

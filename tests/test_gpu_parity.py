@@ -685,6 +685,36 @@ def test_one_sparsity_pattern_per_instance_in_one_launch_chain(R):
     g.cleanup()
 
 
+def test_pattern_groups_with_the_reference_defaults_run_in_one_chain(R):
+    """Termination checks every 25 iterations, adaptive rho, scaling = 10 (include/constants.h:59-115: what a caller who changes nothing gets):
+    the set's host loop is osqp_solve's loop for all groups at once -- groups of iterations up to the next check, one check launch, one
+    masked refactorisation chain where rho moved, the active count of all groups read one check late.  Same kernels on the same data as
+    the per-workspace route: bit-identical results, and status / iteration count / solution equal to the oracle per instance."""
+    wls = [R.workloads.SharedPatternQPs(pattern_seed=s) for s in (2000, 2001, 2002, 2003, 2004)]
+    problems = [wls[k % 5].instance(k // 5) for k in range(5 * 6 + 3)]
+    for kw in (dict(rho=0.1, sigma=1e-6, alpha=1.6, max_iter=4000, check_termination=25, adaptive_rho=1, adaptive_rho_interval=50, eps_abs=1e-4, eps_rel=1e-4,
+                    warm_start=0, scaling=10),
+               dict(rho=5.0, sigma=1e-6, alpha=1.6, max_iter=4000, check_termination=10, adaptive_rho=1, adaptive_rho_interval=30, eps_abs=1e-5, eps_rel=1e-5,
+                    warm_start=0, scaling=0)):
+        g1 = R.OSQPBatchGroups(problems, **kw)
+        g0 = R.OSQPBatchGroups(problems, one_launch=False, **kw)
+        if not any(os.environ.get(k) for k in ("RLDL_NO_TILE", "RLDL_NO_ARROW", "RLDL_CHECK_STAGED", "RLDL_NO_ARROW_FACTOR")):
+            assert g1.one_launch and g1.groups_outside_the_chain == 0
+        r1 = {k: v.clone() for k, v in g1.solve().items()}
+        assert g1.one_launch or any(os.environ.get(k) for k in ("RLDL_NO_TILE", "RLDL_NO_ARROW", "RLDL_CHECK_STAGED", "RLDL_NO_ARROW_FACTOR"))   # (the solve did not drop the set)
+        r0 = g0.solve()
+        for key in ("x", "y", "z", "obj", "pri_res", "dua_res", "iter", "status"):
+            assert torch.equal(r1[key], r0[key]), key
+        assert int(r1["status"].min()) == 1 and len(set(r1["iter"].tolist())) > 1          # solved, after different numbers of iterations
+        for k in (0, 7, 32):
+            P, q, A, l, u = problems[k]
+            w = [w for idx, w in g1.groups if int(k) in idx.tolist()][0]
+            ro = ob.OracleOSQP(P, q, A, l, u, perm=w.linsys().export_symbolic()["perm"], **kw).solve()
+            assert int(r1["iter"][k]) == ro["iter"] and int(r1["status"][k]) == ro["status"]
+            assert relerr(r1["x"][k].cpu().numpy(), ro["x"]) < 1e-7 and relerr(r1["y"][k].cpu().numpy(), ro["y"]) < 1e-7
+        g1.cleanup(); g0.cleanup()
+
+
 def test_pattern_groups_values_from_the_producer_stream_and_changed_settings(R):
     """(1) update_P_A values that a torch kernel has just produced on torch's current stream: the chain runs on the set's own
     stream and must be ordered behind the producer (event wait) -- result bit-equal to the per-workspace route fed the same

@@ -23,7 +23,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_abi_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, "include", "osqp_rldl_hip.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    names = set(re.findall(r"\b([A-Za-z0-9_]*(?:hipldl|rldl_|osqp_batch|osqp_horizon|osqp_multi)[A-Za-z0-9_]*)\s*\(", hdr))
+    names = set(re.findall(r"\b([A-Za-z0-9_]*(?:hipldl|rldl_|osqp_batch|osqp_horizon|osqp_multi|osqp_dist)[A-Za-z0-9_]*)\s*\(", hdr))
     names = {n for n in names if not n.startswith("c_")}
     assert len(names) >= 30
     L = C.CDLL(_lib.LIB_PATH)
