@@ -542,6 +542,7 @@ __device__ __forceinline__ int dual_infeasible(const rldl_dev_sym &S, const doub
 
 // STAGED: the instance's P and A values are copied to LDS first (coalesced), so the three SpMVs of update_info and
 // the ones of the infeasibility tests walk LDS instead of issuing dependent global loads entry by entry.
+// (4 waves per SIMD with 10 spilled registers: 3 waves per SIMD without spills measured 64 instead of 47 us per 4096 final checks)
 template <bool STAGED, bool MULTI = false>
 __global__ __launch_bounds__(WAVE, 4) void k_admm_check(rldl_dev_sym S, rldl_dev_admm W, int iter, int mode, rldl_dev_multi M) {
   int inst = blockIdx.x;
@@ -1754,6 +1755,7 @@ __device__ __forceinline__ void invert_block(const double *T, double *X, int ldT
     for (int r = 0; r < SB; r++) X[r * ldT + lane] = x[r];
   }
 }
+// (4 waves per SIMD with 14 spilled registers on the 24-wide instance: 3 waves per SIMD without spills measured 2 % slower end to end)
 template <int SM>
 __global__ __launch_bounds__(WAVE, 4) void k_stage_invert(rldl_dev_sym S, rldl_dev_num Nn, const int *__restrict__ mask, int b0,
                                                           const int *__restrict__ b0v) {
