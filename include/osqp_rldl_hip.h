@@ -139,6 +139,9 @@ c_int rldl_batch_time_solve_rotating(rldl_batch **hs, c_float **d_b, c_int count
 /* tracing aid: wave timeline of one launch of the solve kernel, host_out[batch][8] int64 ticks of the 100 MHz device clock
  * (wave start, all loads landed, forward gather / forward product / backward product / scatter done, stores issued, 0); 2 = this handle's solve kernel carries no timeline */
 c_int rldl_batch_trace_solve(rldl_batch *h, c_float *d_b, long long *host_out);
+/* the same for one numeric factorisation of the values the handle holds (arrowhead factor kernel): wave start, KKT values in the
+ * workspace, head contributions added, tail in registers, tail eliminated, factor row stored, triangle packed, tail inverse stored */
+c_int rldl_batch_trace_factor(rldl_batch *h, long long *host_out);
 
 /* =====================================================================================
  * 3. Batched ADMM driver (device-resident mirror of src/osqp.c + src/auxil.c step kernels)

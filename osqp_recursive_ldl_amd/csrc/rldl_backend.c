@@ -541,6 +541,28 @@ c_int rldl_batch_trace_solve(rldl_batch *h, c_float *d_b, long long *host_out) {
   return rc;
 }
 
+/* Wave timeline of one numeric factorisation of the values the handle holds (rldl_batch_refactor's launch):
+ * host_out[batch][8] = 100 MHz stamps of the arrowhead factor kernel (0 start, 1 KKT values in the workspace, 2 head
+ * contributions added, 3 tail in registers, 4 tail eliminated, 5 factor row stored, 6 triangle packed, 7 tail inverse stored).
+ * 2: the pattern is factorised by another kernel (no timeline).  Second of two launches, as rldl_batch_trace_solve. */
+c_int rldl_batch_trace_factor(rldl_batch *h, long long *host_out) {
+  long long *d = 0;
+  size_t bytes;
+  c_int rc = 1;
+  if (!h || !host_out) return 1;
+  bytes = sizeof(long long) * 8 * (size_t)h->batch;
+  if (!HIP_OK(hipMalloc((void **)&d, bytes))) return RLDL_MEM_ALLOC_ERROR;
+  if (HIP_OK(hipMemsetAsync(d, 0, bytes, (hipStream_t)h->stream))) {
+    int lr = rldl_launch_factor_trace(&h->dsym, &h->num, d, h->stream);
+    if (lr == 0) lr = rldl_launch_factor_trace(&h->dsym, &h->num, d, h->stream);
+    rc = lr < 0 ? 2 : (lr ? 1 : 0);
+    if (!rc && !(HIP_OK(hipMemcpyAsync(host_out, d, bytes, hipMemcpyDeviceToHost, (hipStream_t)h->stream)) &&
+                 HIP_OK(hipStreamSynchronize((hipStream_t)h->stream)))) rc = 1;
+  }
+  (void)hipFree(d);
+  return rc;
+}
+
 /* =====================================================================================
  * Legacy single-instance plugin: a batch of one with host<->device staging per call.
  * ===================================================================================== */

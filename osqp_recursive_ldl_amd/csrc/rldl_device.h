@@ -178,6 +178,7 @@ int rldl_launch_horizon_adopt(const rldl_dev_sym *So, const rldl_dev_num *No, co
                               int *d_n_reused, void *stream);
 int rldl_launch_factor_from(const rldl_dev_sym *S, const rldl_dev_num *Nn, int c_start, void *stream);
 int rldl_launch_solve(const rldl_dev_sym *S, const rldl_dev_num *Nn, double *d_b, void *stream);
+int rldl_launch_factor_trace(const rldl_dev_sym *S, const rldl_dev_num *Nn, long long *d_trace, void *stream);
 int rldl_launch_solve_trace(const rldl_dev_sym *S, const rldl_dev_num *Nn, double *d_b, long long *d_trace, void *stream);
 int rldl_launch_admm_iter(const rldl_dev_sym *S, const rldl_dev_num *Nn, const rldl_dev_admm *W, void *stream);
 int rldl_launch_bcast_rows(int batch, int len, double *dst, const double *src, void *stream);

@@ -2379,9 +2379,18 @@ __global__ __launch_bounds__(WAVE) void k_stage_factor_r(rldl_dev_sym S, rldl_de
 // Same outputs as k_factor (factor in plan slot order, D, Dinv, status); summation order of the Schur complement differs.
 // ------------------------------------------------------------------------------------------------
 template <int SM>
-__device__ __forceinline__ void arrow_factor_body(const rldl_dev_sym &S, const rldl_dev_num &Nn, const int *__restrict__ mask, int inst) {
+__device__ __forceinline__ void tile_invert_lds(const rldl_dev_sym &S, const rldl_dev_num &Nn, int inst, double *sh, int lane);
+// INV: the tail's inverse (the tile store Ti of the solve kernels) is formed in the same launch, from the triangle while it is
+// still in registers -- no second launch that reads it back from the factor row (k_tile_invert, kept for the other factor kernels)
+template <int SM, bool INV, bool LP>
+__device__ __forceinline__ void arrow_factor_body(const rldl_dev_sym &S, const rldl_dev_num &Nn, const int *__restrict__ mask, int inst,
+                                                  long long *__restrict__ trace = nullptr) {
   const int lane = threadIdx.x;
   if (mask && !mask[inst]) return;
+  // wave timeline (rldl_batch_trace_factor): 0 start, 1 KKT values in the workspace, 2 head contributions added, 3 tail in registers,
+  // 4 tail eliminated, 5 factor row and D stored, 6 triangle packed, 7 tail inverse stored
+  long long *tr = trace && lane == 0 ? trace + 8 * (size_t)inst : nullptr;
+  if (tr) tr[0] = wall_clock64();
   extern __shared__ double sh[];                                  // W = [L values, CSC order | D] as in k_factor, then scratch
   const int nW = S.nnzL + S.N, g0 = S.arrow_g0, g = S.arrow_g;
   double *Wd = sh + S.nnzL, *dih = sh + nW;
@@ -2401,6 +2410,7 @@ __device__ __forceinline__ void arrow_factor_body(const rldl_dev_sym &S, const r
     for (int u = 0; u < FB; u++) if (k0 + u * WAVE + lane < S.nnzK) sh[ix[u]] = v[u];
   }
   wave_sync();
+  if (tr) tr[1] = wall_clock64();
   int npos = 0, zero = 0;
   for (int j = lane; j < g0; j += WAVE) {                        // head pivots are final as they come
     const double d = Wd[j];
@@ -2427,12 +2437,45 @@ __device__ __forceinline__ void arrow_factor_body(const rldl_dev_sym &S, const r
 #pragma unroll
   for (int c = 0; c < SM; c++) tp[c] = c < g ? S.arrow_tpos[c * 64 + r] : -1;
   wave_sync();
+  if (tr) tr[2] = wall_clock64();
 #pragma unroll
   for (int c = 0; c < SM; c++) {
     const double lo = sh[tp[c] >= 0 ? tp[c] : 0];
     w[c] = tp[c] >= 0 ? lo : (c == r ? Wd[g0 + r] : 0.0);
   }
   wave_sync();
+  if (tr) tr[3] = wall_clock64();
+  if (LP) {
+  // The pivot column of step j goes through a 64-entry LDS buffer and every lane reads the entries it multiplies with as broadcast
+  // reads, two per instruction (2 v_readlane + hazard nop + fma per update was 3.5 issue slots; this is 1.5, and the kernel is
+  // bound by issue slots).  Look-ahead: column j + 1 is final after its first update, so its scaled copy is written (other buffer)
+  // before the rest of step j's updates -- the LDS round trip of the next step hides behind them.
+  double *pc = sh + ((nW + g0 + 1) & ~1);
+  double dcur = readlane_f64(w[0], 0), lcur = w[0] * recip_nr(dcur);
+  pc[lane] = lane < g ? lcur : 0.0;
+#pragma unroll
+  for (int j = 0; j < SM; j++) {
+    if (j < g) {                                                 // uniform
+      if (dcur == 0.0) zero = 1;
+      if (lane == 0 && dcur > 0.0) npos++;
+      const double *cur = pc + (j & 1) * 64;
+      double *nxt = pc + ((j + 1) & 1) * 64;
+      const double a = w[j];
+      if (lane > j) w[j] = lcur;
+      wave_sync();                                               // (compiler fence: the reads below stay behind the write of cur)
+      if (j + 1 < SM) {
+        w[j + 1] = fma(-a, cur[j + 1], w[j + 1]);
+        if (j + 1 < g) {                                         // uniform
+          dcur = readlane_f64(w[j + 1], j + 1);
+          lcur = w[j + 1] * recip_nr(dcur);
+          nxt[lane] = lane < g ? lcur : 0.0;
+        }
+      }
+#pragma unroll
+      for (int k = j + 2; k < SM; k++) w[k] = fma(-a, cur[k], w[k]);
+    }
+  }
+  } else {
 #pragma unroll
   for (int j = 0; j < SM; j++) {
     if (j < g) {                                                 // uniform
@@ -2448,6 +2491,8 @@ __device__ __forceinline__ void arrow_factor_body(const rldl_dev_sym &S, const r
       for (int k = j + 1; k < SM; k++) w[k] = fma(-a, readlane_f64(lv, k), w[k]);
     }
   }
+  }
+  if (tr) tr[4] = wall_clock64();
   // back to the CSC workspace, then the common coalesced write-out in plan slot order
   if (lane < g) {
 #pragma unroll
@@ -2476,15 +2521,31 @@ __device__ __forceinline__ void arrow_factor_body(const rldl_dev_sym &S, const r
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { npos += __shfl_xor(npos, o); zero |= __shfl_xor(zero, o); }
   if (lane == 0) { Nn.status[inst] = zero ? -1 : npos; if (Nn.fail && (zero || npos < S.n)) atomicOr(Nn.fail, 1); }
+  if (tr) tr[5] = wall_clock64();
+  if (INV) {
+    wave_sync();                                                 // the workspace is dead: its first words become the packed triangle
+    if (lane < g) {
+      double *row = sh + ((lane * (lane - 1)) >> 1);             // row-major packed, as the factor row holds it
+#pragma unroll
+      for (int c = 0; c + 1 < SM; c++)
+        if (c < lane) row[c] = w[c];
+    }
+    wave_sync();
+    if (tr) tr[6] = wall_clock64();
+    tile_invert_lds<SM>(S, Nn, inst, sh, lane);
+    if (tr) tr[7] = wall_clock64();
+  }
 }
-template <int SM>
-__global__ __launch_bounds__(WAVE) void k_arrow_factor(rldl_dev_sym S, rldl_dev_num Nn, const int *__restrict__ mask) {
-  arrow_factor_body<SM>(S, Nn, mask, blockIdx.x);
+template <int SM, bool INV, bool LP>
+__global__ __launch_bounds__(WAVE) void k_arrow_factor(rldl_dev_sym S, rldl_dev_num Nn, const int *__restrict__ mask, long long *__restrict__ trace) {
+  arrow_factor_body<SM, INV, LP>(S, Nn, mask, blockIdx.x, trace);
 }
 template <int SM>
 __global__ __launch_bounds__(WAVE) void k_arrow_factor_multi(rldl_dev_multi M, int masked) {   // masked: only the instances whose W.refactor is set (rho adaptation)
-  const int g = multi_group(M.first_inst, M.ngroups, blockIdx.x);
-  arrow_factor_body<SM>(M.S[g], M.N[g], masked ? M.W[g].refactor : nullptr, (int)blockIdx.x - M.first_inst[g]);
+  const int g = multi_group(M.first_inst, M.ngroups, blockIdx.x), inst = (int)blockIdx.x - M.first_inst[g];
+  int *mask = masked ? M.W[g].refactor : nullptr;
+  arrow_factor_body<SM, true, true>(M.S[g], M.N[g], mask, inst);
+  if (mask && threadIdx.x == 0) mask[inst] = 0;                  // (last reader of the mask of this rho update)
 }
 
 // ================================================================================================
@@ -3034,14 +3095,10 @@ __device__ __forceinline__ void col_gather(const ColRegs<TK> &Q, const char *shb
 // Inverse of the tail's unit lower triangle, once per factorisation: lane c solves L22 X = e_c by forward substitution with
 // the rows of L22 as LDS broadcast reads (one address per wave), X in registers; the columns then go through LDS into
 // the (k, lane) tile order of Ti.  SM = compile-time bound on g.  One wave per instance.
+// (the triangle is in sh[0, g (g - 1) / 2), row-major packed; the same words then become the staging buffer)
 template <int SM>
-__device__ __forceinline__ void tile_invert_body(const rldl_dev_sym &S, const rldl_dev_num &Nn, const int *__restrict__ mask, int inst) {
-  const int lane = threadIdx.x;
-  if (mask && !mask[inst]) return;
-  extern __shared__ double sh[];                                 // g (g - 1) / 2 doubles: the triangle, then the staging buffer
-  const int g = S.arrow_g, tri = (g * (g - 1)) >> 1;
-  const double *Lg = Nn.F + (size_t)inst * S.ldF + S.nOp;        // row-major packed triangle of the tail group (plan slot order)
-  for (int i = lane; i < tri; i += WAVE) sh[i] = Lg[i];
+__device__ __forceinline__ void tile_invert_lds(const rldl_dev_sym &S, const rldl_dev_num &Nn, int inst, double *sh, int lane) {
+  const int g = S.arrow_g;
   unsigned short sl[SM];
   {
     const unsigned short *ts = reinterpret_cast<const unsigned short *>(S.plan + S.po_tislot);
@@ -3072,15 +3129,18 @@ __device__ __forceinline__ void tile_invert_body(const rldl_dev_sym &S, const rl
   for (int p = lane; p < S.nTi; p += WAVE) To[p] = sh[p];
 }
 template <int SM>
-__global__ __launch_bounds__(WAVE) void k_tile_invert(rldl_dev_sym S, rldl_dev_num Nn, const int *__restrict__ mask) {
-  tile_invert_body<SM>(S, Nn, mask, blockIdx.x);
+__device__ __forceinline__ void tile_invert_body(const rldl_dev_sym &S, const rldl_dev_num &Nn, const int *__restrict__ mask, int inst) {
+  const int lane = threadIdx.x;
+  if (mask && !mask[inst]) return;
+  extern __shared__ double sh[];                                 // g (g - 1) / 2 doubles: the triangle, then the staging buffer
+  const int g = S.arrow_g, tri = (g * (g - 1)) >> 1;
+  const double *Lg = Nn.F + (size_t)inst * S.ldF + S.nOp;        // row-major packed triangle of the tail group (plan slot order)
+  for (int i = lane; i < tri; i += WAVE) sh[i] = Lg[i];
+  tile_invert_lds<SM>(S, Nn, inst, sh, lane);
 }
 template <int SM>
-__global__ __launch_bounds__(WAVE) void k_tile_invert_multi(rldl_dev_multi M, int masked) {
-  const int g = multi_group(M.first_inst, M.ngroups, blockIdx.x), inst = (int)blockIdx.x - M.first_inst[g];
-  int *mask = masked ? M.W[g].refactor : nullptr;
-  tile_invert_body<SM>(M.S[g], M.N[g], mask, inst);
-  if (mask && threadIdx.x == 0) mask[inst] = 0;                  // (last reader of the mask of this rho update)
+__global__ __launch_bounds__(WAVE) void k_tile_invert(rldl_dev_sym S, rldl_dev_num Nn, const int *__restrict__ mask) {
+  tile_invert_body<SM>(S, Nn, mask, blockIdx.x);
 }
 
 // LDS per wave of the tile kernels (pws doubles): x (xdw doubles, incl. the padding rows of the last block row), 64 dummy words
@@ -4009,18 +4069,27 @@ extern "C" int rldl_launch_solve_begin(const rldl_dev_admm *W, int n, int m, int
   return launch_status();
 }
 
-static int launch_factor(const rldl_dev_sym *S, const rldl_dev_num *Nn, const int *d_mask, int c_start, void *stream) {
+static int launch_factor(const rldl_dev_sym *S, const rldl_dev_num *Nn, const int *d_mask, int c_start, void *stream, long long *d_trace = nullptr) {
   if (Nn->batch <= 0) return 0;
   if (c_start <= 0 && S->arrow_ok && S->arrow_dense && S->arrow_g <= 64 && !getenv("RLDL_NO_ARROW_FACTOR")) {
     const size_t al = sizeof(double) * (size_t)(S->nnzL + S->N + S->arrow_g0 + 2 + 128);
     if (al <= RLDL_LDS_LIMIT) {
       const dim3 grid(Nn->batch), blk(WAVE);
       const int g = S->arrow_g;
-      if (g <= 16) hipLaunchKernelGGL(k_arrow_factor<16>, grid, blk, al, (hipStream_t)stream, *S, *Nn, d_mask);
-      else if (g <= 32) hipLaunchKernelGGL(k_arrow_factor<32>, grid, blk, al, (hipStream_t)stream, *S, *Nn, d_mask);
-      else if (g <= 48) hipLaunchKernelGGL(k_arrow_factor<48>, grid, blk, al, (hipStream_t)stream, *S, *Nn, d_mask);
-      else if (g <= 56) hipLaunchKernelGGL(k_arrow_factor<56>, grid, blk, al, (hipStream_t)stream, *S, *Nn, d_mask);
-      else hipLaunchKernelGGL(k_arrow_factor<64>, grid, blk, al, (hipStream_t)stream, *S, *Nn, d_mask);
+      static const int split = getenv("RLDL_SPLIT_INVERT") ? 1 : 0;            // (A/B: tail inverse as its own launch, as in round 2)
+      const size_t il = sizeof(double) * (size_t)((g * (g - 1)) / 2 + 2);
+      if (S->tile_ok && Nn->Ti && S->arrow_tb == 0 && !split) {               // (the conditions of launch_tile_invert)
+        const size_t fl = al > il ? al : il;
+        static const int rl = getenv("RLDL_READLANE_PIVOT") ? 1 : 0;          // (A/B: pivot column by v_readlane, as in round 2)
+#define AF(SMV) do { if (rl) hipLaunchKernelGGL((k_arrow_factor<SMV, true, false>), grid, blk, fl, (hipStream_t)stream, *S, *Nn, d_mask, d_trace); \
+                     else hipLaunchKernelGGL((k_arrow_factor<SMV, true, true>), grid, blk, fl, (hipStream_t)stream, *S, *Nn, d_mask, d_trace); } while (0)
+        if (g <= 16) AF(16); else if (g <= 32) AF(32); else if (g <= 48) AF(48); else if (g <= 56) AF(56); else AF(64);
+#undef AF
+        return launch_status();
+      }
+#define AF(SMV) hipLaunchKernelGGL((k_arrow_factor<SMV, false, true>), grid, blk, al, (hipStream_t)stream, *S, *Nn, d_mask, d_trace)
+      if (g <= 16) AF(16); else if (g <= 32) AF(32); else if (g <= 48) AF(48); else if (g <= 56) AF(56); else AF(64);
+#undef AF
       if (launch_status()) return -1;
       return launch_tile_invert(S, Nn, d_mask, stream);
     }
@@ -4092,6 +4161,12 @@ extern "C" int rldl_launch_stage_factor_each(const rldl_dev_sym *S, const rldl_d
   return d_b0v ? launch_stage_factor(S, Nn, 0, 0, d_b0v, tiles_adopted, stream) : -1;
 }
 
+// the factorisation with the wave timeline of the arrowhead kernel ([batch][8] stamps, arrow_factor_body); -1: another kernel serves the pattern
+extern "C" int rldl_launch_factor_trace(const rldl_dev_sym *S, const rldl_dev_num *Nn, long long *d_trace, void *stream) {
+  if (!(S->arrow_ok && S->arrow_dense && S->arrow_g <= 64) || getenv("RLDL_NO_ARROW_FACTOR")) return -1;
+  if (sizeof(double) * (size_t)(S->nnzL + S->N + S->arrow_g0 + 2 + 128) > RLDL_LDS_LIMIT) return -1;
+  return launch_factor(S, Nn, 0, 0, stream, d_trace) ? 1 : 0;
+}
 extern "C" int rldl_launch_factor(const rldl_dev_sym *S, const rldl_dev_num *Nn, const int *d_mask, void *stream) {
   if (S->stage.nb > 0 && !getenv("RLDL_NO_STAGE_FACTOR")) return rldl_launch_stage_factor(S, Nn, d_mask, 0, stream);
   return launch_factor(S, Nn, d_mask, 0, stream);
@@ -4328,9 +4403,8 @@ extern "C" int rldl_launch_multi_update(const rldl_dev_multi *M, const rldl_dev_
   const dim3 grid(total), blk(WAVE);
   hipLaunchKernelGGL(k_kkt_assemble_multi, grid, dim3(256), 0, (hipStream_t)stream, *M, *PA);
   if (launch_status()) return -1;
-#define MU(SMV, MASKED) do { hipLaunchKernelGGL(k_arrow_factor_multi<SMV>, grid, blk, (size_t)factor_lds, (hipStream_t)stream, *M, MASKED); \
-                     if (launch_status()) return -1; \
-                     hipLaunchKernelGGL(k_tile_invert_multi<SMV>, grid, blk, (size_t)invert_lds, (hipStream_t)stream, *M, MASKED); } while (0)
+  // (factorisation and tail inverse are one launch; the larger of the two LDS sizes covers both)
+#define MU(SMV, MASKED) hipLaunchKernelGGL(k_arrow_factor_multi<SMV>, grid, blk, (size_t)(factor_lds > invert_lds ? factor_lds : invert_lds), (hipStream_t)stream, *M, MASKED)
   switch (key) { case 16: MU(16, 0); break; case 32: MU(32, 0); break; case 48: MU(48, 0); break; case 56: MU(56, 0); break; case 64: MU(64, 0); break; default: return -1; }
   return launch_status();
 }

@@ -257,6 +257,18 @@ class BatchLinsys:
             raise RuntimeError("trace_solve failed")
         return out
 
+    def trace_factor(self):
+        """Wave timeline of one numeric factorisation of the values the handle holds: int64 [batch, 8] ticks of the 100 MHz device
+        clock (wave start, KKT values in the workspace, head contributions added, tail in registers, tail eliminated, factor row
+        stored, triangle packed, tail inverse stored); None when the pattern is not served by the arrowhead kernel."""
+        out = np.zeros((self.batch, 8), np.int64)
+        rc = _lib.lib().rldl_batch_trace_factor(self.h, out.ctypes.data_as(C.c_void_p))
+        if rc == 2:
+            return None
+        if rc:
+            raise RuntimeError("trace_factor failed")
+        return out
+
     def free(self):
         if getattr(self, "h", None) and self._owned:
             _lib.lib().rldl_batch_free(self.h)
