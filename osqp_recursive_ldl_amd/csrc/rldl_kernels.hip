@@ -21,6 +21,7 @@
 //   k_set_rho_vec    : set_rho_vec / update_rho_vec      src/auxil.c:79-145
 //   k_scale_data / k_unscale_data / k_ew_scale : scale_data, unscale_data, scaled updates   src/scaling.c:44-192
 #include <hip/hip_runtime.h>
+#include <utility>
 #include <cstdio>
 #include <cstdlib>
 
@@ -1116,6 +1117,8 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+typedef double lds_d2 __attribute__((ext_vector_type(2)));          // 16-byte LDS reads (ds_read_b128)
+constexpr int LCH = 16;                                              // entries read ahead of their use in the factor kernels' LDS streams
 // LDS accesses by byte address (shb = base of the wave's LDS region)
 __device__ __forceinline__ double lds_ld(const char *shb, unsigned a) { return *reinterpret_cast<const double *>(shb + a); }
 __device__ __forceinline__ void lds_st(char *shb, unsigned a, double v) { *reinterpret_cast<double *>(shb + a) = v; }
@@ -2378,6 +2381,47 @@ __global__ __launch_bounds__(WAVE) void k_stage_factor_r(rldl_dev_sym S, rldl_de
 //          (pivot by v_readlane, pivot column through a 64-entry LDS buffer, one fma per column for the whole block).
 // Same outputs as k_factor (factor in plan slot order, D, Dinv, status); summation order of the Schur complement differs.
 // ------------------------------------------------------------------------------------------------
+// One column step of the tail elimination (arrow_factor_body, LP): J is a template parameter so that every step is its own
+// straight-line code (a 56-step loop with the chunk logic inside is beyond the unroller's size limit and w[] would live in scratch).
+template <int SM, int J>
+__device__ __forceinline__ void elim_step(double (&w)[SM], double *pc, int g, int lane, double &dcur, double &lcur, int &zero, int &npos) {
+  if (J < g) {                                                   // uniform
+    if (dcur == 0.0) zero = 1;
+    if (lane == 0 && dcur > 0.0) npos++;
+    const lds_d2 *cur = reinterpret_cast<const lds_d2 *>(pc + (J & 1) * 64);
+    double *nxt = pc + ((J + 1) & 1) * 64;
+    const double a = w[J];
+    if (lane > J) w[J] = lcur;
+    wave_sync();                                                 // (compiler fence: the reads below stay behind the write of cur)
+    constexpr int k0 = (J + 1) & ~1, nch = (SM - k0 + LCH - 1) / LCH;
+    lds_d2 cb[2][LCH / 2];
+#pragma unroll
+    for (int q = 0; q < LCH / 2; q++) if (k0 + 2 * q < SM) cb[0][q] = cur[k0 / 2 + q];
+#pragma unroll
+    for (int c = 0; c < nch; c++) {
+#pragma unroll
+      for (int q = 0; q < LCH / 2; q++) if (c + 1 < nch && k0 + (c + 1) * LCH + 2 * q < SM) cb[(c + 1) & 1][q] = cur[(k0 + (c + 1) * LCH) / 2 + q];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int e = 0; e < LCH; e++) {
+        const int k = k0 + c * LCH + e;
+        if (k > J && k < SM) {
+          w[k] = fma(-a, cb[c & 1][e >> 1][e & 1], w[k]);
+          if (k == J + 1 && J + 1 < g) {                         // uniform
+            dcur = readlane_f64(w[k], k);
+            lcur = w[k] * recip_nr(dcur);
+            nxt[lane] = lane < g ? lcur : 0.0;
+          }
+        }
+      }
+    }
+  }
+}
+template <int SM, int... Js>
+__device__ __forceinline__ void elim_steps(std::integer_sequence<int, Js...>, double (&w)[SM], double *pc, int g, int lane, double &dcur, double &lcur,
+                                           int &zero, int &npos) {
+  (elim_step<SM, Js>(w, pc, g, lane, dcur, lcur, zero, npos), ...);
+}
 template <int SM>
 __device__ __forceinline__ void tile_invert_lds(const rldl_dev_sym &S, const rldl_dev_num &Nn, int inst, double *sh, int lane);
 // INV: the tail's inverse (the tile store Ti of the solve kernels) is formed in the same launch, from the triangle while it is
@@ -2432,49 +2476,33 @@ __device__ __forceinline__ void arrow_factor_body(const rldl_dev_sym &S, const r
   // (l_rc = K_rc / d_c of the head columns is applied on the way out: nothing below reads the head entries again)
   // tail: Schur complement -> registers, row per lane; positions from the [g][64] table (-1: structural zero / c >= r)
   double w[SM];
-  int tp[SM];
   const int r = lane < g ? lane : g - 1;
+  {
+    int tp[SM];
 #pragma unroll
-  for (int c = 0; c < SM; c++) tp[c] = c < g ? S.arrow_tpos[c * 64 + r] : -1;
-  wave_sync();
-  if (tr) tr[2] = wall_clock64();
+    for (int c = 0; c < SM; c++) tp[c] = c < g ? S.arrow_tpos[c * 64 + r] : -1;
+    wave_sync();
+    if (tr) tr[2] = wall_clock64();
 #pragma unroll
-  for (int c = 0; c < SM; c++) {
-    const double lo = sh[tp[c] >= 0 ? tp[c] : 0];
-    w[c] = tp[c] >= 0 ? lo : (c == r ? Wd[g0 + r] : 0.0);
+    for (int c = 0; c < SM; c++) {
+      const double lo = sh[tp[c] >= 0 ? tp[c] : 0];
+      w[c] = tp[c] >= 0 ? lo : (c == r ? Wd[g0 + r] : 0.0);
+    }
   }
   wave_sync();
   if (tr) tr[3] = wall_clock64();
   if (LP) {
   // The pivot column of step j goes through a 64-entry LDS buffer and every lane reads the entries it multiplies with as broadcast
-  // reads, two per instruction (2 v_readlane + hazard nop + fma per update was 3.5 issue slots; this is 1.5, and the kernel is
-  // bound by issue slots).  Look-ahead: column j + 1 is final after its first update, so its scaled copy is written (other buffer)
-  // before the rest of step j's updates -- the LDS round trip of the next step hides behind them.
+  // reads, two per instruction (2 v_readlane + hazard nop + fma per update was 3.5 issue slots; this is 1.5).  The kernel runs at
+  // 2 waves per SIMD and is bound by latency, not issue slots (timeline: rldl_batch_trace_factor), so
+  //   * look-ahead: column j + 1 is final after its first update, its scaled copy is written (other buffer) before the rest of
+  //     step j's updates -- the LDS round trip of the next step hides behind them;
+  //   * the reads of a step are issued a chunk of LCH entries ahead of the fmas that consume them (the compiler's own schedule
+  //     keeps 2-3 reads in flight and every pair of fmas waits a full LDS latency).
   double *pc = sh + ((nW + g0 + 1) & ~1);
   double dcur = readlane_f64(w[0], 0), lcur = w[0] * recip_nr(dcur);
   pc[lane] = lane < g ? lcur : 0.0;
-#pragma unroll
-  for (int j = 0; j < SM; j++) {
-    if (j < g) {                                                 // uniform
-      if (dcur == 0.0) zero = 1;
-      if (lane == 0 && dcur > 0.0) npos++;
-      const double *cur = pc + (j & 1) * 64;
-      double *nxt = pc + ((j + 1) & 1) * 64;
-      const double a = w[j];
-      if (lane > j) w[j] = lcur;
-      wave_sync();                                               // (compiler fence: the reads below stay behind the write of cur)
-      if (j + 1 < SM) {
-        w[j + 1] = fma(-a, cur[j + 1], w[j + 1]);
-        if (j + 1 < g) {                                         // uniform
-          dcur = readlane_f64(w[j + 1], j + 1);
-          lcur = w[j + 1] * recip_nr(dcur);
-          nxt[lane] = lane < g ? lcur : 0.0;
-        }
-      }
-#pragma unroll
-      for (int k = j + 2; k < SM; k++) w[k] = fma(-a, cur[k], w[k]);
-    }
-  }
+  elim_steps<SM>(std::make_integer_sequence<int, SM>(), w, pc, g, lane, dcur, lcur, zero, npos);
   } else {
 #pragma unroll
   for (int j = 0; j < SM; j++) {
@@ -2493,8 +2521,12 @@ __device__ __forceinline__ void arrow_factor_body(const rldl_dev_sym &S, const r
   }
   }
   if (tr) tr[4] = wall_clock64();
-  // back to the CSC workspace, then the common coalesced write-out in plan slot order
+  // back to the CSC workspace, then the common coalesced write-out in plan slot order (the positions are fetched again: 56 registers
+  // held across the elimination cost the second wave per SIMD)
   if (lane < g) {
+    int tp[SM];
+#pragma unroll
+    for (int c = 0; c < SM; c++) tp[c] = c < g ? __builtin_nontemporal_load(&S.arrow_tpos[c * 64 + lane]) : -1;
 #pragma unroll
     for (int c = 0; c < SM; c++) {
       if (tp[c] >= 0) sh[tp[c]] = w[c];
@@ -3095,30 +3127,49 @@ __device__ __forceinline__ void col_gather(const ColRegs<TK> &Q, const char *shb
 // Inverse of the tail's unit lower triangle, once per factorisation: lane c solves L22 X = e_c by forward substitution with
 // the rows of L22 as LDS broadcast reads (one address per wave), X in registers; the columns then go through LDS into
 // the (k, lane) tile order of Ti.  SM = compile-time bound on g.  One wave per instance.
+// row I of the forward substitution of tile_invert_lds (template parameter for the same reason as elim_step)
+template <int SM, int I>
+__device__ __forceinline__ void invert_row(double (&X)[SM], lds_d2 (&rb)[2][LCH / 2], const lds_d2 *st, int g) {
+  if (I < g) {                                                   // uniform
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+    for (int j = 0; j < I; j++) {
+      const int p = ((I * (I - 1)) >> 1) + j, c = p / LCH, e = p % LCH;
+      if (e == 0) {
+#pragma unroll
+        for (int q = 0; q < LCH / 2; q++) rb[(c + 1) & 1][q] = st[(c + 1) * (LCH / 2) + q];
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      const double lv = rb[c & 1][e >> 1][e & 1];
+      if (j & 1) a1 = fma(lv, X[j], a1); else a0 = fma(lv, X[j], a0);
+    }
+    X[I] -= a0 + a1;                                             // lanes c >= I: all X[j < I] are 0, X[I] stays delta_Ic
+  }
+}
+template <int SM, int... Is>
+__device__ __forceinline__ void invert_rows(std::integer_sequence<int, Is...>, double (&X)[SM], lds_d2 (&rb)[2][LCH / 2], const lds_d2 *st, int g) {
+  (invert_row<SM, Is + 1>(X, rb, st, g), ...);
+}
 // (the triangle is in sh[0, g (g - 1) / 2), row-major packed; the same words then become the staging buffer)
 template <int SM>
 __device__ __forceinline__ void tile_invert_lds(const rldl_dev_sym &S, const rldl_dev_num &Nn, int inst, double *sh, int lane) {
   const int g = S.arrow_g;
-  unsigned short sl[SM];
-  {
-    const unsigned short *ts = reinterpret_cast<const unsigned short *>(S.plan + S.po_tislot);
-#pragma unroll
-    for (int i = 1; i < SM; i++) sl[i] = i < g ? ts[i * 64 + lane] : (unsigned short)0xffffu;
-  }
   wave_sync();
   double X[SM];
 #pragma unroll
   for (int i = 0; i < SM; i++) X[i] = i == lane ? 1.0 : 0.0;
+  // the packed triangle is consumed front to back: LCH entries are read ahead of the fmas that use them (see arrow_factor_body;
+  // the reads may run up to 2 LCH doubles past the triangle -- the launchers size the LDS for that)
+  const lds_d2 *st = reinterpret_cast<const lds_d2 *>(sh);
+  lds_d2 rb[2][LCH / 2];
 #pragma unroll
-  for (int i = 1; i < SM; i++) {
-    if (i < g) {                                                 // uniform
-      const double *row = sh + ((i * (i - 1)) >> 1);
-      double a0 = 0.0, a1 = 0.0;
+  for (int q = 0; q < LCH / 2; q++) rb[0][q] = st[q];
+  invert_rows<SM>(std::make_integer_sequence<int, SM - 1>(), X, rb, st, g);
+  unsigned short sl[SM];                                         // (fetched here, not ahead of the substitution: 55 registers)
+  {
+    const unsigned short *ts = reinterpret_cast<const unsigned short *>(S.plan + S.po_tislot);
 #pragma unroll
-      for (int j = 0; j + 1 < i; j += 2) { a0 = fma(row[j], X[j], a0); a1 = fma(row[j + 1], X[j + 1], a1); }
-      if (i & 1) a0 = fma(row[i - 1], X[i - 1], a0);
-      X[i] -= a0 + a1;                                           // lanes c >= i: all X[j < i] are 0, X[i] stays delta_ic
-    }
+    for (int i = 1; i < SM; i++) sl[i] = i < g ? ts[i * 64 + lane] : (unsigned short)0xffffu;
   }
   wave_sync();                                                   // the triangle is dead: same LDS becomes the tile-order buffer
 #pragma unroll
@@ -4021,7 +4072,7 @@ static int launch_tile_admm(const rldl_dev_sym *S, const rldl_dev_num *Nn, const
 static int launch_tile_invert(const rldl_dev_sym *S, const rldl_dev_num *Nn, const int *d_mask, void *stream) {
   if (!S->tile_ok || !Nn->Ti || S->arrow_tb != 0) return 0;
   const int g = S->arrow_g;
-  const size_t lds = sizeof(double) * (size_t)((g * (g - 1)) / 2 + 2);
+  const size_t lds = sizeof(double) * (size_t)((g * (g - 1)) / 2 + 2 + 2 * LCH);
   const dim3 grid(Nn->batch), blk(WAVE);
   if (g <= 16) hipLaunchKernelGGL(k_tile_invert<16>, grid, blk, lds, (hipStream_t)stream, *S, *Nn, d_mask);
   else if (g <= 32) hipLaunchKernelGGL(k_tile_invert<32>, grid, blk, lds, (hipStream_t)stream, *S, *Nn, d_mask);
@@ -4077,7 +4128,7 @@ static int launch_factor(const rldl_dev_sym *S, const rldl_dev_num *Nn, const in
       const dim3 grid(Nn->batch), blk(WAVE);
       const int g = S->arrow_g;
       static const int split = getenv("RLDL_SPLIT_INVERT") ? 1 : 0;            // (A/B: tail inverse as its own launch, as in round 2)
-      const size_t il = sizeof(double) * (size_t)((g * (g - 1)) / 2 + 2);
+      const size_t il = sizeof(double) * (size_t)((g * (g - 1)) / 2 + 2 + 2 * LCH);
       if (S->tile_ok && Nn->Ti && S->arrow_tb == 0 && !split) {               // (the conditions of launch_tile_invert)
         const size_t fl = al > il ? al : il;
         static const int rl = getenv("RLDL_READLANE_PIVOT") ? 1 : 0;          // (A/B: pivot column by v_readlane, as in round 2)
@@ -4395,7 +4446,7 @@ extern "C" int rldl_multi_update_key(const rldl_dev_sym *S, const rldl_dev_num *
 }
 extern "C" int rldl_multi_update_lds(const rldl_dev_sym *S, int which) {     // dynamic LDS bytes of the factor (0) / tail inverse (1) kernel
   const int g = S->arrow_g;
-  return which == 0 ? (int)(sizeof(double) * (size_t)(S->nnzL + S->N + S->arrow_g0 + 2 + 128)) : (int)(sizeof(double) * (size_t)((g * (g - 1)) / 2 + 2));
+  return which == 0 ? (int)(sizeof(double) * (size_t)(S->nnzL + S->N + S->arrow_g0 + 2 + 128)) : (int)(sizeof(double) * (size_t)((g * (g - 1)) / 2 + 2 + 2 * LCH));
 }
 extern "C" int rldl_launch_multi_update(const rldl_dev_multi *M, const rldl_dev_multi_pa *PA, int total, int key, int factor_lds, int invert_lds,
                                         void *stream) {
