@@ -2442,16 +2442,17 @@ __device__ __forceinline__ void arrow_factor_body(const rldl_dev_sym &S, const r
   const double *K = Nn.Kx + (size_t)inst * S.nnzK;
   // Every loop below that reads an index table from global memory takes FB rounds at a time: the FB index loads (and the
   // value loads that do not depend on them) are in flight together instead of one memory round trip per round.
-  constexpr int FB = 8;
+  // (FBV / FBP rounds while the row registers are still free, FBO with the eliminated rows live)
+  constexpr int FBV = 16, FBP = 32, FBO = 16;
   for (int i = lane; i < nW; i += WAVE) sh[i] = 0.0;
   wave_sync();
-  for (int k0 = 0; k0 < S.nnzK; k0 += FB * WAVE) {
-    int ix[FB];
-    double v[FB];
+  for (int k0 = 0; k0 < S.nnzK; k0 += FBV * WAVE) {
+    int ix[FBV];
+    double v[FBV];
 #pragma unroll
-    for (int u = 0; u < FB; u++) { const int k = min(k0 + u * WAVE + lane, S.nnzK - 1); ix[u] = S.KtoW[k]; v[u] = K[k]; }
+    for (int u = 0; u < FBV; u++) { const int k = min(k0 + u * WAVE + lane, S.nnzK - 1); ix[u] = S.KtoW[k]; v[u] = K[k]; }
 #pragma unroll
-    for (int u = 0; u < FB; u++) if (k0 + u * WAVE + lane < S.nnzK) sh[ix[u]] = v[u];
+    for (int u = 0; u < FBV; u++) if (k0 + u * WAVE + lane < S.nnzK) sh[ix[u]] = v[u];
   }
   wave_sync();
   if (tr) tr[1] = wall_clock64();
@@ -2464,12 +2465,12 @@ __device__ __forceinline__ void arrow_factor_body(const rldl_dev_sym &S, const r
   }
   wave_sync();
   // head: every pair (a, b) of column j adds -l_a l_b d_j to a tail entry; columns are independent -> no barrier, atomics
-  for (int t0 = 0; t0 < S.arrow_npairs; t0 += FB * WAVE) {       // flat over all head columns: independent iterations
-    unsigned ab[FB], dc[FB];
+  for (int t0 = 0; t0 < S.arrow_npairs; t0 += FBP * WAVE) {      // flat over all head columns: independent iterations
+    unsigned ab[FBP], dc[FBP];
 #pragma unroll
-    for (int u = 0; u < FB; u++) { const int t = min(t0 + u * WAVE + lane, S.arrow_npairs - 1); ab[u] = S.arrow_pab[t]; dc[u] = S.arrow_pdc[t]; }
+    for (int u = 0; u < FBP; u++) { const int t = min(t0 + u * WAVE + lane, S.arrow_npairs - 1); ab[u] = S.arrow_pab[t]; dc[u] = S.arrow_pdc[t]; }
 #pragma unroll
-    for (int u = 0; u < FB; u++)
+    for (int u = 0; u < FBP; u++)
       if (t0 + u * WAVE + lane < S.arrow_npairs)
         unsafeAtomicAdd(&sh[dc[u] & 0xffffu], -(sh[ab[u] & 0xffffu] * (sh[ab[u] >> 16] * dih[dc[u] >> 16])));
   }
@@ -2536,12 +2537,12 @@ __device__ __forceinline__ void arrow_factor_body(const rldl_dev_sym &S, const r
   wave_sync();
   // write-out in SLOT order: consecutive lanes store consecutive words of the factor row; the table names the workspace position
   // behind every slot and, for head columns, the column whose 1/d still has to be applied (padding slots are rewritten with 0.0)
-  for (int s0 = 0; s0 < S.nS; s0 += FB * WAVE) {
-    unsigned ot[FB];
+  for (int s0 = 0; s0 < S.nS; s0 += FBO * WAVE) {
+    unsigned ot[FBO];
 #pragma unroll
-    for (int u = 0; u < FB; u++) ot[u] = S.arrow_out[min(s0 + u * WAVE + lane, S.nS - 1)];
+    for (int u = 0; u < FBO; u++) ot[u] = S.arrow_out[min(s0 + u * WAVE + lane, S.nS - 1)];
 #pragma unroll
-    for (int u = 0; u < FB; u++) {
+    for (int u = 0; u < FBO; u++) {
       const int sl = s0 + u * WAVE + lane;
       const unsigned pos = ot[u] & 0xffffu, hc = ot[u] >> 16;
       double v = pos != 0xffffu ? sh[pos] : 0.0;
