@@ -334,12 +334,12 @@ def main(argv=None):
              "restream_equivalent_GBs": iter_bytes * B * iters_per_launch / (k_ms * 1e-3) / 1e9,
              "restream_note": "SURVEY 8d bytes of one fused iteration (which assume the factor is re-streamed every iteration) x "
                               "instances x iterations / launch duration: NOT a roofline figure, the factor is read once per launch"}
-    pmc = load_profile("r2_pmc_fused.json")
+    pmc = load_profile("r3_pmc_fused.json")
     if pmc and B == pmc.get("batch") and iters_per_launch == pmc.get("iterations_per_launch") and pmc.get("kernel") in fused["kernel"]:
         cyc = pmc["per_wave_iteration"]["SQ_LDS_IDX_ACTIVE"]
         busy = cyc * B * iters_per_launch / (k_ms * 1e-3 * N_CU * CLOCK_HZ)
         fused.update(achieved=busy * N_CU * CLOCK_HZ / 1e9, peak=N_CU * CLOCK_HZ / 1e9, unit="G LDS-array cycles/s", frac=busy,
-                     lds_cycles_per_wave_iteration=cyc, counters_source="profiles/r2_pmc_fused.json (rocprofv3 --pmc, this configuration)",
+                     lds_cycles_per_wave_iteration=cyc, counters_source="profiles/r3_pmc_fused.json (rocprofv3 --pmc, this configuration)",
                      note="frac = LDS-array busy cycles / (256 CUs x 2.4 GHz x launch duration): a lower bound of the busy fraction "
                           "(the chip clocks below 2.4 GHz under load)")
     out["roofline_fused"] = fused
