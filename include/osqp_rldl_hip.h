@@ -45,6 +45,7 @@ typedef struct {
 #define RLDL_NONCVX_ERROR 5             /* OSQP_NONCVX_ERROR */
 #define RLDL_MEM_ALLOC_ERROR 6          /* OSQP_MEM_ALLOC_ERROR */
 #define RLDL_NO_DEVICE_ERROR 100        /* no HIP device / kernel image: the product never falls back to CPU */
+#define RLDL_DEVICE_ERROR 101           /* a HIP runtime call failed inside an enqueue-only entry point (not a verdict about the data) */
 
 /* =====================================================================================
  * 1. Legacy single-instance plugin (prefix-compatible with `struct linsys_solver`,
@@ -170,6 +171,10 @@ c_int osqp_batch_solve_async(osqp_batch *w);
 c_int osqp_batch_wait(osqp_batch *w);
 c_int osqp_batch_update_lin_cost(osqp_batch *w, const c_float *d_q);   /* osqp.c:752-790 */
 c_int osqp_batch_update_bounds(osqp_batch *w, const c_float *d_l, const c_float *d_u); /* osqp.c:792-841 */
+/* the same, only enqueued (no host round trip, no stream drain): the l <= u check runs on the device, a refused update leaves l, u
+ * untouched and is reported by the next osqp_batch_wait (return code 1 = the reference's exitflag, osqp.c:805-813);
+ * RLDL_DEVICE_ERROR when a HIP call fails.  The blocking calls refuse to run while such a verdict is unread. */
+c_int osqp_batch_update_bounds_async(osqp_batch *w, const c_float *d_l, const c_float *d_u);
 c_int osqp_batch_update_rho(osqp_batch *w, c_float rho_new);           /* osqp.c:1268-1319 */
 /* osqp_update_max_iter, _eps_abs, _eps_rel, _eps_prim_inf, _eps_dual_inf, _alpha, _warm_start, _scaled_termination,
  * _check_termination, _polish_refine_iter, _delta (osqp.c:1321-1560) in one call; other fields of `s` are ignored */
@@ -216,6 +221,10 @@ void  osqp_batch_cleanup(osqp_batch *w);                                /* osqp.
 typedef struct osqp_multi osqp_multi;
 /* the key of the fused kernel instantiation the workspace's pattern selects (equal keys share launches), -1: off the tile kernels,
  * the workspace cannot join a set */
+/* problems of different sparsity patterns (each osqp_setup of the reference owns its pattern, qdldl_interface.c:99-166): bucket them
+ * by (pattern of P, pattern of A) -- group[i] = bucket of problem i, numbered by first appearance; returns the number of buckets or -1
+ * -- build one workspace per bucket (osqp_batch_setup on the stacked values), then join the workspaces into a set below. */
+c_int osqp_groups_bucket(c_int count, const csc *const *P, const csc *const *A, c_int *group);
 c_int osqp_batch_multi_key(const osqp_batch *w);
 c_int osqp_multi_create(osqp_multi **mp, osqp_batch **ws, c_int count, const c_int *dest, void *stream);
 c_int osqp_multi_solve(osqp_multi *mm);
@@ -270,6 +279,7 @@ c_int osqp_batch_setup_recursive(osqp_batch **wp, c_int batch, const rldl_stage_
                                  const OSQPBatchSettings *settings, csc **P_out, csc **A_out, void *stream);
 c_int osqp_batch_update_recursive(osqp_batch *w, c_int first_stage, const c_float *d_Px, const c_float *d_Ax);
 c_int osqp_batch_partial_update_bounds(osqp_batch *w, c_int start, c_int stop, const c_float *d_l, const c_float *d_u);
+c_int osqp_batch_partial_update_bounds_async(osqp_batch *w, c_int start, c_int stop, const c_float *d_l, const c_float *d_u);
 
 c_int rldl_setup_AP_matrices(const rldl_stage_dims *dims, const csc *Q0, const csc *Qi, const csc *QN, const csc *A0,
                              const csc *Ai, const csc *Aij, const csc *AN, csc **P_out, csc **A_out, c_int *P_kind,

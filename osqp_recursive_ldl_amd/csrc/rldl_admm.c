@@ -94,7 +94,7 @@ void osqp_batch_cleanup(osqp_batch *w) {
   FR(w->Px); FR(w->Ax); FR(w->q); FR(w->l); FR(w->u);
   FR(w->W.x); FR(w->W.z); FR(w->W.y); FR(w->W.delta_x); FR(w->W.delta_y); FR(w->W.rho_vec); FR(w->W.constr_type);
   FR(w->W.pri_res); FR(w->W.dua_res); FR(w->W.obj); FR(w->W.rho_cur); FR(w->W.rho_est); FR(w->W.status);
-  FR(w->W.iter); FR(w->W.rho_updates); FR(w->W.refactor); FR(w->W.n_active);
+  FR(w->W.iter); FR(w->W.rho_updates); FR(w->W.refactor); FR(w->W.n_active); FR(w->d_bounds);
   FR(w->W.pol_Ax); FR(w->W.pol_b); FR(w->W.pol_z); FR(w->W.pol_r); FR(w->W.pol_mask); FR(w->W.status_polish);
   FR(w->W.sD); FR(w->W.sDinv); FR(w->W.sE); FR(w->W.sEinv); FR(w->W.sc); FR(w->W.scinv); FR(w->W.sol_x); FR(w->W.sol_y);
 #undef FR
@@ -148,6 +148,8 @@ c_int osqp_batch_setup(osqp_batch **wp, c_int batch, const csc *P, const csc *A,
   w->W.rho_est = (double *)dmalloc(sizeof(double) * B, &ok);
   w->W.status = (int *)dmalloc(sizeof(int) * B, &ok); w->W.iter = (int *)dmalloc(sizeof(int) * B, &ok);
   w->W.rho_updates = (int *)dmalloc(sizeof(int) * B, &ok); w->W.refactor = (int *)dmalloc(sizeof(int) * B, &ok);
+  w->d_bounds = (int *)dmalloc(sizeof(int) * 2, &ok);
+  if (ok && !HIP_OK(hipMemsetAsync(w->d_bounds, 0, sizeof(int) * 2, (hipStream_t)stream))) ok = 0;
   w->W.n_active = (int *)dmalloc(sizeof(int) * RLDL_NACT_SLOTS, &ok);
   w->W.status_polish = (int *)dmalloc(sizeof(int) * B, &ok);
   if (w->st.polish) {
@@ -255,6 +257,16 @@ c_int osqp_batch_wait(osqp_batch *w) {
     (void)hipEventElapsedTime(&w->last_loop_ms, (hipEvent_t)w->ev0, (hipEvent_t)w->ev1);
     w->loop_pending = 0;
   }
+  if (w->bounds_pending) {                                       /* verdict of osqp_batch_update_bounds_async (sticky word) */
+    int flag[2] = {0, 0};
+    w->bounds_pending = 0;
+    if (!HIP_OK(hipMemcpy(flag, w->d_bounds, sizeof(int) * 2, hipMemcpyDeviceToHost)) ||
+        !HIP_OK(hipMemset(w->d_bounds, 0, sizeof(int) * 2))) return RLDL_DEVICE_ERROR;
+    if (flag[1]) {
+      if (w->refactor_pending) { w->refactor_pending = 0; (void)rldl_batch_check_status(w->ls); }
+      return 1;                                                  /* osqp.c:805-813: l > u somewhere, that update changed nothing */
+    }
+  }
   if (w->refactor_pending) {                                     /* verdict of osqp_batch_update_P_A_async */
     w->refactor_pending = 0;
     if (rldl_batch_check_status(w->ls)) return RLDL_NONCVX_ERROR;
@@ -340,14 +352,47 @@ c_int osqp_batch_update_lin_cost(osqp_batch *w, const c_float *d_q) {
 /* l <= u everywhere, else the update is refused and nothing changes (osqp.c:805-813: "lower bound must be lower than or
  * equal to upper bound", exitflag 1).  Uses the backend's sticky flag word as scratch would mix verdicts: own read-back. */
 c_int osqp_batch_bounds_ok(osqp_batch *w, c_int count, const c_float *d_l, const c_float *d_u) {
-  int flag = 0;
+  int flag[2] = {0, 0};
   hipStream_t st = (hipStream_t)w->stream;
-  if (!HIP_OK(hipMemsetAsync(w->W.refactor, 0, sizeof(int), st))) return 0;      /* (the refactor mask is all zero between calls: word 0 as the flag) */
-  if (rldl_launch_check_bounds((long long)count, d_l, d_u, w->W.refactor, w->stream)) return 0;
-  if (!HIP_OK(hipMemcpyAsync(&flag, w->W.refactor, sizeof(int), hipMemcpyDeviceToHost, st))) return 0;
-  if (!HIP_OK(hipMemsetAsync(w->W.refactor, 0, sizeof(int), st))) return 0;
+  if (w->bounds_pending) return 0;                                /* an unread verdict of an enqueued update: osqp_batch_wait first */
+  if (!HIP_OK(hipMemsetAsync(w->d_bounds, 0, sizeof(int) * 2, st))) return 0;
+  if (rldl_launch_check_bounds((long long)count, d_l, d_u, w->d_bounds, w->stream)) return 0;
+  if (!HIP_OK(hipMemcpyAsync(flag, w->d_bounds, sizeof(int) * 2, hipMemcpyDeviceToHost, st))) return 0;
+  if (!HIP_OK(hipMemsetAsync(w->d_bounds, 0, sizeof(int) * 2, st))) return 0;
   if (!HIP_OK(hipStreamSynchronize(st))) return 0;
-  return !flag;
+  return !flag[0];
+}
+
+/* Enqueue-only siblings of osqp_batch_update_bounds / osqp_batch_partial_update_bounds for callers that stream steps through a workspace
+ * (osqp_batch_update_P_A_async + osqp_batch_solve_async): the l <= u check (osqp.c:805-813, recursive_ldl.c:137-145) stays on the
+ * device -- k_check_bounds writes its verdict into a device word, the kernels that would store the new bounds read that word and
+ * leave l, u untouched when it is set -- and the verdict is reported by the next osqp_batch_wait (return code 1, the reference's
+ * exitflag for "lower bound must be lower than or equal to upper bound"), like the verdict of an enqueued refactorisation.
+ * No host round trip, no stream drain.  RLDL_DEVICE_ERROR: a HIP call failed (not a verdict about the data). */
+static c_int bounds_async(osqp_batch *w, c_int start, c_int cnt, const c_float *d_l, const c_float *d_u) {
+  hipStream_t st = (hipStream_t)w->stream;
+  const double *sE = w->st.scaling ? w->W.sE : 0;
+  if (!HIP_OK(hipMemsetAsync(w->d_bounds, 0, sizeof(int), st))) return RLDL_DEVICE_ERROR;          /* word 0 only: word 1 is sticky */
+  if (rldl_launch_check_bounds((long long)w->batch * cnt, d_l, d_u, w->d_bounds, w->stream)) return RLDL_DEVICE_ERROR;
+  w->bounds_pending = 1;
+  if (rldl_launch_set_range_guarded((int)w->batch, (int)w->m, (int)start, (int)cnt, w->l, d_l, sE, w->d_bounds, w->stream)) return RLDL_DEVICE_ERROR;
+  if (rldl_launch_set_range_guarded((int)w->batch, (int)w->m, (int)start, (int)cnt, w->u, d_u, sE, w->d_bounds, w->stream)) return RLDL_DEVICE_ERROR;
+  reset_info(w);
+  /* update_rho_vec (auxil.c:103-145); after a refused update l, u are unchanged, so no constraint type moves and nothing is refactorised */
+  if (rldl_launch_set_rho_vec(&w->ls->dsym, &w->W, 0, w->stream)) return RLDL_DEVICE_ERROR;
+  if (rldl_batch_update_rho_vec(w->ls, w->W.rho_vec, w->W.refactor)) return RLDL_DEVICE_ERROR;
+  if (!HIP_OK(hipMemsetAsync(w->W.refactor, 0, sizeof(int) * (size_t)w->batch, st))) return RLDL_DEVICE_ERROR;
+  return 0;
+}
+c_int osqp_batch_update_bounds_async(osqp_batch *w, const c_float *d_l, const c_float *d_u) {
+  if (!w) return 7;
+  if (!d_l || !d_u) return 1;
+  return bounds_async(w, 0, w->m, d_l, d_u);
+}
+c_int osqp_batch_partial_update_bounds_async(osqp_batch *w, c_int start, c_int stop, const c_float *d_l, const c_float *d_u) {
+  if (!w) return 7;
+  if (!d_l || !d_u || start < 0 || stop > w->m || start >= stop) return 1;
+  return bounds_async(w, start, stop - start, d_l, d_u);
 }
 
 c_int osqp_batch_update_bounds(osqp_batch *w, const c_float *d_l, const c_float *d_u) {
@@ -553,6 +598,52 @@ void osqp_multi_free(osqp_multi *mm) {
   free(mm->part_first); free(mm->part_xdw); free(mm->Mp); free(mm->orig_of); free(mm->ustreams);
   free(mm->ws);
   free(mm);
+}
+
+/* Buckets `count` problems by sparsity pattern -- every osqp_setup of the reference owns its own pattern (qdldl_interface.c:99-166);
+ * a handle here factorises one pattern, so instances are grouped by (pattern of P, pattern of A) before the workspaces are built.
+ * P[i] / A[i]: CSC patterns (x ignored; row indices in the order the caller will also use for the values).  group[i] = bucket of
+ * problem i, buckets numbered in order of first appearance; returns the number of buckets, or -1 (allocation failure / bad input).
+ * Hash table over an FNV-1a hash of the index arrays, equal hashes confirmed by comparing the arrays. */
+static unsigned long long fnv1a(unsigned long long h, const void *data, size_t bytes) {
+  const unsigned char *p = (const unsigned char *)data;
+  size_t i;
+  for (i = 0; i < bytes; i++) { h ^= p[i]; h *= 1099511628211ull; }
+  return h;
+}
+static unsigned long long pattern_hash(const csc *M) {
+  unsigned long long h = 14695981039346656037ull;
+  const c_int nnz = M->p[M->n];
+  h = fnv1a(h, &M->m, sizeof(c_int)); h = fnv1a(h, &M->n, sizeof(c_int));
+  h = fnv1a(h, M->p, sizeof(c_int) * (size_t)(M->n + 1));
+  return fnv1a(h, M->i, sizeof(c_int) * (size_t)nnz);
+}
+static int pattern_equal(const csc *X, const csc *Y) {
+  return X->m == Y->m && X->n == Y->n && !memcmp(X->p, Y->p, sizeof(c_int) * (size_t)(X->n + 1)) &&
+         !memcmp(X->i, Y->i, sizeof(c_int) * (size_t)X->p[X->n]);
+}
+c_int osqp_groups_bucket(c_int count, const csc *const *P, const csc *const *A, c_int *group) {
+  c_int i, nb = 0, cap = 16, *slot, *rep;
+  unsigned long long *hs;
+  if (count < 0 || (count && (!P || !A || !group))) return -1;
+  while (cap < 2 * count) cap *= 2;
+  slot = (c_int *)malloc(sizeof(c_int) * (size_t)cap);           /* open addressing: bucket index or -1 */
+  rep = (c_int *)malloc(sizeof(c_int) * (size_t)(count ? count : 1));   /* first problem of every bucket */
+  hs = (unsigned long long *)malloc(sizeof(unsigned long long) * (size_t)(count ? count : 1));
+  if (!slot || !rep || !hs) { free(slot); free(rep); free(hs); return -1; }
+  for (i = 0; i < cap; i++) slot[i] = -1;
+  for (i = 0; i < count; i++) {
+    unsigned long long h;
+    c_int k;
+    if (!P[i] || !A[i] || !P[i]->p || !A[i]->p) { nb = -1; break; }
+    h = pattern_hash(P[i]) * 31ull + pattern_hash(A[i]);
+    for (k = (c_int)(h & (unsigned long long)(cap - 1));; k = (k + 1) & (cap - 1)) {
+      if (slot[k] < 0) { slot[k] = nb; rep[nb] = i; hs[nb] = h; group[i] = nb++; break; }
+      if (hs[slot[k]] == h && pattern_equal(P[rep[slot[k]]], P[i]) && pattern_equal(A[rep[slot[k]]], A[i])) { group[i] = slot[k]; break; }
+    }
+  }
+  free(slot); free(rep); free(hs);
+  return nb;
 }
 
 /* which launch chain a workspace can join: the key of the fused kernel instantiation its pattern selects (workspaces with equal keys share

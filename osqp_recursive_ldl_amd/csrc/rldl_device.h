@@ -183,6 +183,8 @@ int rldl_launch_solve_trace(const rldl_dev_sym *S, const rldl_dev_num *Nn, doubl
 int rldl_launch_admm_iter(const rldl_dev_sym *S, const rldl_dev_num *Nn, const rldl_dev_admm *W, void *stream);
 int rldl_launch_bcast_rows(int batch, int len, double *dst, const double *src, void *stream);
 int rldl_launch_set_range(int batch, int ld, int start, int cnt, double *dst, const double *src, const double *s, void *stream);
+int rldl_launch_set_range_guarded(int batch, int ld, int start, int cnt, double *dst, const double *src, const double *s, const int *d_skip,
+                                  void *stream);
 /* single-store horizon change (rldl_horizon.c) */
 int rldl_launch_bcast_range(int batch, int ld, int start, int cnt, double *dst, const double *src_row, void *stream);
 int rldl_launch_scatter_rows(int batch, int cnt, int ld, const int *map, const double *src, double *dst, void *stream);

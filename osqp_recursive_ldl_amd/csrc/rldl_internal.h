@@ -41,6 +41,8 @@ struct osqp_batch {
   double *h_tmp_d;               /* [batch] host scratch */
   int loop_pending;              /* a solve loop was enqueued and its event pair not read yet */
   int refactor_pending;          /* osqp_batch_update_P_A_async: the verdict of the refactorisation has not been read yet */
+  int *d_bounds;                 /* [2] device words of k_check_bounds: [0] verdict of the update being enqueued, [1] sticky until osqp_batch_wait */
+  int bounds_pending;            /* osqp_batch_update_bounds_async: the sticky verdict has not been read yet */
   float last_loop_ms;
   c_int last_loop_launches;     /* ADMM iterations run by the last solve loop ... */
   c_int last_loop_groups;       /* ... in this many launch groups (one kernel launch each on the arrowhead path) */

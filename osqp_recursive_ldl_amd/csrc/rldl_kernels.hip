@@ -1051,8 +1051,9 @@ __global__ __launch_bounds__(256) void k_bcast_rows(int len, double *dst, const 
   for (int i = threadIdx.x; i < len; i += blockDim.x) dst[(size_t)inst * len + i] = src[i];
 }
 // dst[b][start + i] = src[b][i] * (s ? s[b][start + i] : 1), i < cnt: a column range of instance-major rows
-__global__ __launch_bounds__(256) void k_set_range(int ld, int start, int cnt, double *dst, const double *src, const double *s) {
+__global__ __launch_bounds__(256) void k_set_range(int ld, int start, int cnt, double *dst, const double *src, const double *s, const int *skip) {
   const int inst = blockIdx.x;
+  if (skip && *skip) return;                                     // refused update (l > u somewhere): nothing changes
   for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
     const size_t o = (size_t)inst * ld + start + i;
     dst[o] = src[(size_t)inst * cnt + i] * (s ? s[o] : 1.0);
@@ -4407,7 +4408,14 @@ extern "C" int rldl_launch_horizon_state_single(const rldl_dev_admm *W, int n_ma
 }
 extern "C" int rldl_launch_set_range(int batch, int ld, int start, int cnt, double *dst, const double *src, const double *s, void *stream) {
   if (batch <= 0 || cnt <= 0) return 0;
-  hipLaunchKernelGGL(k_set_range, dim3(batch), dim3(256), 0, (hipStream_t)stream, ld, start, cnt, dst, src, s);
+  hipLaunchKernelGGL(k_set_range, dim3(batch), dim3(256), 0, (hipStream_t)stream, ld, start, cnt, dst, src, s, (const int *)0);
+  return launch_status();
+}
+// the same guarded by a device word: no write when *d_skip != 0 (the verdict of k_check_bounds, read without a host round trip)
+extern "C" int rldl_launch_set_range_guarded(int batch, int ld, int start, int cnt, double *dst, const double *src, const double *s, const int *d_skip,
+                                             void *stream) {
+  if (batch <= 0 || cnt <= 0) return 0;
+  hipLaunchKernelGGL(k_set_range, dim3(batch), dim3(256), 0, (hipStream_t)stream, ld, start, cnt, dst, src, s, d_skip);
   return launch_status();
 }
 
@@ -4426,7 +4434,7 @@ extern "C" int rldl_launch_matvec_A(const rldl_dev_sym *S, const rldl_dev_admm *
 __global__ __launch_bounds__(256) void k_check_bounds(long long count, const double *__restrict__ l, const double *__restrict__ u, int *flag) {
   int bad = 0;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long long)gridDim.x * blockDim.x) bad |= l[i] > u[i];
-  if (__any(bad) && (threadIdx.x & (WAVE - 1)) == 0) atomicOr(flag, 1);
+  if (__any(bad) && (threadIdx.x & (WAVE - 1)) == 0) { atomicOr(flag, 1); atomicOr(flag + 1, 1); }   // word 0: this update, word 1: sticky until read
 }
 extern "C" int rldl_launch_check_bounds(long long count, const double *l, const double *u, int *flag, void *stream) {
   if (count <= 0) return 0;

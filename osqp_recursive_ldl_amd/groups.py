@@ -1,7 +1,7 @@
 """Batches whose instances do NOT share one sparsity pattern ("per-instance pattern" variant of config 2) -- down to
 one pattern per instance (the reference's semantics: every osqp_setup owns its pattern, qdldl_interface.c:99-166).
 
-The backend factorises one pattern per handle, so the instances are bucketed by pattern: one OSQPBatch per distinct
+The backend factorises one pattern per handle, so the instances are bucketed by pattern (osqp_groups_bucket, C): one OSQPBatch per distinct
 (P pattern, A pattern).  With a fixed number of iterations (no termination checks, no rho adaptation, no polish) and patterns
 that select the same kernel instantiation, a solve of ALL groups is three launches over the stacked instances plus one that
 writes the results in the caller's instance order (osqp_multi_*, include/osqp_rldl_hip.h).  Otherwise every group is enqueued
@@ -16,8 +16,16 @@ from .linsys import CscPattern
 from .osqp_batch import OSQPBatch
 
 
-def _key(P, A):
-    return (P.shape, A.shape, P.indptr.tobytes(), P.indices.tobytes(), A.indptr.tobytes(), A.indices.tobytes())
+def bucket_by_pattern(Ps, As):
+    """osqp_groups_bucket: group index of every problem (CscPattern lists), buckets numbered by first appearance."""
+    count = len(Ps)
+    pp = (C.c_void_p * count)(*[C.cast(C.pointer(p.s), C.c_void_p) for p in Ps])
+    aa = (C.c_void_p * count)(*[C.cast(C.pointer(a.s), C.c_void_p) for a in As])
+    group = np.zeros(count, np.int64)
+    nb = int(_lib.lib().osqp_groups_bucket(count, pp, aa, group.ctypes.data_as(_lib.IP)))
+    if nb < 0:
+        raise RuntimeError("osqp_groups_bucket failed")
+    return group, nb
 
 
 class OSQPBatchGroups:
@@ -27,16 +35,19 @@ class OSQPBatchGroups:
         import torch
         from scipy import sparse
         self.count = len(problems)
-        buckets = {}
         canon = []
         for i, (P, q, A, l, u) in enumerate(problems):
             Pu = sparse.triu(sparse.csc_matrix(P), format="csc"); Pu.sort_indices()
             Ac = sparse.csc_matrix(A); Ac.sort_indices()
             canon.append((Pu, Ac))
-            buckets.setdefault(_key(Pu, Ac), []).append(i)
         self.n, self.m = canon[0][0].shape[0], canon[0][1].shape[0]
         if any(c[0].shape[0] != self.n or c[1].shape[0] != self.m for c in canon):
             raise ValueError("all instances must have the same (n, m)")
+        pats = [(CscPattern(Pu), CscPattern(Ac)) for Pu, Ac in canon]
+        group, nb = bucket_by_pattern([p for p, _ in pats], [a for _, a in pats])      # the bucketing itself is C (osqp_groups_bucket)
+        buckets = {g: [] for g in range(nb)}
+        for i, g in enumerate(group):
+            buckets[int(g)].append(i)
         dev = torch.device(device)
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)
         self.groups = []
@@ -48,7 +59,7 @@ class OSQPBatchGroups:
             l = np.stack([np.asarray(problems[i][3], float) for i in idx]); u = np.stack([np.asarray(problems[i][4], float) for i in idx])
             stream = pool[gi % len(pool)]
             torch.cuda.synchronize(dev)                              # uploads above ran on torch's current stream
-            w = OSQPBatch(CscPattern(Pu), CscPattern(Ac), t(Px), t(Ax), t(q), t(l), t(u), stream=stream, **settings)
+            w = OSQPBatch(pats[idx[0]][0], pats[idx[0]][1], t(Px), t(Ax), t(q), t(l), t(u), stream=stream, **settings)
             if w.status != 0:
                 raise RuntimeError("setup of a pattern group failed (%d)" % w.status)
             self.groups.append((torch.as_tensor(np.asarray(idx), device=dev), w))

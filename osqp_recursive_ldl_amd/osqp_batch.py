@@ -79,10 +79,12 @@ class OSQPBatch:
         """New values from stage `first_stage` on: the factorisation restarts there (LDL_update_from_pivot semantics)."""
         return int(_lib.lib().osqp_batch_update_recursive(self.h, int(first_stage), _dptr(Px), _dptr(Ax)))
 
-    def partial_update_bounds(self, start, stop, l, u):
-        """osqp_partial_update_bounds (src/recursive_ldl.c:119-200): rows [start, stop) of the bounds of every instance."""
+    def partial_update_bounds(self, start, stop, l, u, wait=True):
+        """osqp_partial_update_bounds (src/recursive_ldl.c:119-200): rows [start, stop) of the bounds of every instance.
+        wait=False only enqueues (the l <= u verdict stays on the device and is raised by the next wait())."""
         _dev_f64(l, (self.batch, stop - start), "l"); _dev_f64(u, (self.batch, stop - start), "u")
-        return int(_lib.lib().osqp_batch_partial_update_bounds(self.h, int(start), int(stop), _dptr(l), _dptr(u)))
+        f = _lib.lib().osqp_batch_partial_update_bounds if wait else _lib.lib().osqp_batch_partial_update_bounds_async
+        return int(f(self.h, int(start), int(stop), _dptr(l), _dptr(u)))
 
     def linsys(self):
         return BatchLinsys(self.P, self.A, None, None, 0, None, _handle=_lib.lib().osqp_batch_linsys(self.h), _owned=False)
@@ -163,9 +165,11 @@ class OSQPBatch:
     def update_lin_cost(self, q):
         return int(_lib.lib().osqp_batch_update_lin_cost(self.h, _dptr(_dev_f64(q, (self.batch, self.n), "q"))))
 
-    def update_bounds(self, l, u):
+    def update_bounds(self, l, u, wait=True):
+        """osqp_update_bounds; wait=False only enqueues: a refused update (l > u somewhere) changes nothing and is raised by the next wait()."""
         _dev_f64(l, (self.batch, self.m), "l"); _dev_f64(u, (self.batch, self.m), "u")
-        return int(_lib.lib().osqp_batch_update_bounds(self.h, _dptr(l), _dptr(u)))
+        f = _lib.lib().osqp_batch_update_bounds if wait else _lib.lib().osqp_batch_update_bounds_async
+        return int(f(self.h, _dptr(l), _dptr(u)))
 
     def update_settings(self, **kw):
         """osqp_update_max_iter / _eps_* / _alpha / _warm_start / _scaled_termination / _check_termination /

@@ -501,6 +501,11 @@ def test_solve_wave_timeline_and_rotating_timing(R):
     assert torch.equal(bs[0], ref)
     for k in (1, 2):
         assert torch.equal(bs[k], hs[k].solve(rhs.clone()))
+    # the factor kernel's timeline: an ordinary refactorisation (factor and solve unchanged), stamps ordered per wave
+    tf = hs[0].trace_factor()
+    if tf is not None:
+        assert tf.shape == (B, 8) and (tf > 0).all() and (np.diff(tf, axis=1) >= 0).all()
+        assert torch.equal(hs[0].solve(rhs.clone()), ref)
     for h in hs:
         h.free()
 
@@ -841,3 +846,38 @@ def test_update_bounds_refuses_crossed_bounds_and_refactor_failure_is_sticky(R):
     assert w.update_P_A(dev(Px), dev(Ax), wait=False) == 0
     w.wait()                                                     # the verdict was cleared when it was read
     w.cleanup()
+
+
+@pytest.mark.parametrize("scaling", [0, 10])
+def test_enqueued_bounds_updates_keep_the_verdict_on_the_device(R, scaling):
+    """osqp_batch_update_bounds_async / _partial_update_bounds_async: same result as the blocking calls; an update with l > u
+    somewhere (osqp.c:805-813, recursive_ldl.c:137-145) changes nothing, is reported by the next wait() and does not stick."""
+    wl = R.workloads.SharedPatternQPs(n=20, m=30, density=0.2, pattern_seed=7)
+    B = 5
+    Px, Ax, q, l, u = wl.values(B)
+    kw = dict(rho=0.1, sigma=1e-6, alpha=1.6, max_iter=40, check_termination=0, adaptive_rho=0, warm_start=0, scaling=scaling)
+    mk = lambda: R.OSQPBatch(wl.P_pattern, wl.A_pattern, dev(Px), dev(Ax), dev(q), dev(l), dev(u), **kw)
+    wa, wb = mk(), mk()
+    l2, u2 = l - 0.3, u + 0.2
+    assert wa.update_bounds(dev(l2), dev(u2)) == 0
+    assert wb.update_bounds(dev(l2), dev(u2), wait=False) == 0
+    ra = wa.solve(); wb.solve_async(); rb = wb.wait()
+    assert torch.equal(ra["x"], rb["x"]) and torch.equal(ra["y"], rb["y"])
+    lp, up = l[:, 4:11] - 0.7, u[:, 4:11] + 0.1                  # rows [4, 11)
+    assert wa.partial_update_bounds(4, 11, dev(lp), dev(up)) == 0
+    assert wb.partial_update_bounds(4, 11, dev(lp), dev(up), wait=False) == 0
+    ra = wa.solve(); wb.solve_async(); rb = wb.wait()
+    assert torch.equal(ra["x"], rb["x"]) and torch.equal(ra["y"], rb["y"])
+    bad = lp.copy(); bad[3, 2] = up[3, 2] + 1.0                  # instance 3: l > u in one row
+    assert wb.partial_update_bounds(4, 11, dev(bad), dev(up), wait=False) == 0      # enqueued: no verdict yet
+    wb.solve_async()
+    with pytest.raises(RuntimeError, match=r"\(1\)"):
+        wb.wait()
+    wb.solve_async()
+    rc = wb.wait()                                               # verdict read and cleared; the bounds are those of before
+    assert torch.equal(rc["x"], rb["x"])
+    assert wb.update_bounds(dev(l), dev(u), wait=False) == 0     # and a later good update goes through
+    wb.solve_async(); rd = wb.wait()
+    assert wa.update_bounds(dev(l), dev(u)) == 0
+    assert torch.equal(rd["x"], wa.solve()["x"])
+    wa.cleanup(); wb.cleanup()

@@ -23,7 +23,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_abi_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, "include", "osqp_rldl_hip.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    names = set(re.findall(r"\b([A-Za-z0-9_]*(?:hipldl|rldl_|osqp_batch|osqp_horizon|osqp_multi|osqp_dist)[A-Za-z0-9_]*)\s*\(", hdr))
+    names = set(re.findall(r"\b([A-Za-z0-9_]*(?:hipldl|rldl_|osqp_batch|osqp_horizon|osqp_multi|osqp_dist|osqp_groups)[A-Za-z0-9_]*)\s*\(", hdr))
     names = {n for n in names if not n.startswith("c_")}
     assert len(names) >= 30
     L = C.CDLL(_lib.LIB_PATH)
@@ -388,3 +388,33 @@ def test_owner_gather_tables_hold_every_coupling_entry_under_its_column_owner(ca
     for t in (1, 2):                                                                   # decreasing column count inside a kind
         cols = tpos[1:].ravel()[tpos[1:].ravel() >= 0]
         assert all(cnt[cols[i]] >= cnt[cols[i + 1]] for i in range(len(cols) - 1))
+
+
+def test_pattern_bucketing_groups_equal_patterns_in_order_of_first_appearance():
+    """osqp_groups_bucket (host C): problems with equal (P pattern, A pattern) share a bucket, buckets are numbered by first
+    appearance -- against a Python dict over the index arrays; patterns that differ in one row index or only in A are told apart."""
+    from osqp_recursive_ldl_amd.groups import bucket_by_pattern
+    from osqp_recursive_ldl_amd.linsys import CscPattern
+    rng = np.random.default_rng(5)
+    n, m = 12, 17
+    base = []
+    for k in range(6):
+        P = sparse.random(n, n, density=0.25, random_state=100 + k, format="csc"); P = sparse.triu(P + P.T + sparse.eye(n), format="csc")
+        A = sparse.random(m, n, density=0.3, random_state=200 + k, format="csc")
+        base.append((P, A))
+    base.append((base[0][0], base[1][1]))                        # same P as pattern 0, A of pattern 1: a bucket of its own
+    A_mod = base[2][1].tolil(); zr, zc = np.nonzero(A_mod.toarray() == 0); A_mod[zr[0], zc[0]] = 1.0   # one more entry than pattern 2
+    base.append((base[2][0], sparse.csc_matrix(A_mod)))
+    order = rng.integers(0, len(base), size=60)
+    Ps = [CscPattern(base[k][0]) for k in order]; As = [CscPattern(base[k][1]) for k in order]
+    # values must not matter
+    Ps[3] = Ps[3].with_values(rng.standard_normal(Ps[3].nnz))
+    group, nb = bucket_by_pattern(Ps, As)
+    seen = {}
+    want = []
+    for p, a in zip(Ps, As):
+        key = (p.shape, a.shape, p.p.tobytes(), p.i.tobytes(), a.p.tobytes(), a.i.tobytes())
+        want.append(seen.setdefault(key, len(seen)))
+    assert nb == len(seen) and list(group) == want
+    assert nb == len(set(order.tolist()))
+    assert bucket_by_pattern([], [])[1] == 0
