@@ -145,6 +145,11 @@ class GpuShard:
     def results(self):
         return self.w.results(clone=False)
 
+    def gatherer(self, n, m):
+        """The per-step collective of this shard: one pack launch + an asynchronous RCCL all-gather, double-buffered (dist.ResultGather)."""
+        from osqp_recursive_ldl_amd import dist as rdist
+        return rdist.ResultGather(self.w.pack_results, self.w.batch, n, m, self.dPx.device)
+
     def device_sync(self):
         self.torch.cuda.synchronize()
 
@@ -159,9 +164,15 @@ def run_steps(args, shard, n, m, sizes, scaling, world):
     gsz = sizes if scaling == "strong" else None
     coll = world > 1 or getattr(args, "force_dist", False)    # --force-dist: the collective runs even in a world of one rank
 
+    # equal shards on the GPU: packed by one launch and gathered asynchronously, so the next step does not wait for the exchange
+    gat = shard.gatherer(n, m) if coll and gsz is None and hasattr(shard, "gatherer") and dist.get_backend() != "gloo" else None
+
     def one():
         res = shard.step()
-        return rdist.gather_results(res, n, m, sizes=gsz, force=coll) if coll else res   # the path's only collective
+        if gat is not None:
+            gat.gather()                                     # the path's only collective
+            return res
+        return rdist.gather_results(res, n, m, sizes=gsz, force=coll) if coll else res
 
     def sync():
         if coll:
@@ -171,12 +182,16 @@ def run_steps(args, shard, n, m, sizes, scaling, world):
     for _ in range(args.warmup):
         one()
     shard.finish()
+    if gat is not None:
+        gat.finish()
     sync()
     t0 = time.perf_counter()
     res = None
     for _ in range(args.steps):
         res = one()
     shard.finish()
+    if gat is not None:
+        res = gat.finish()                                   # the gathered results of the last step (all ranks' instances)
     sync()
     mine = time.perf_counter() - t0
     per_rank = [mine]
@@ -190,7 +205,12 @@ def run_steps(args, shard, n, m, sizes, scaling, world):
         sync()
         g0 = time.perf_counter()
         for _ in range(10):
-            rdist.gather_results(shard.results(), n, m, sizes=gsz, force=True)
+            if gat is not None:
+                gat.gather()
+            else:
+                rdist.gather_results(shard.results(), n, m, sizes=gsz, force=True)
+        if gat is not None:
+            gat.finish()
         sync()
         gather_ms = 1e2 * (time.perf_counter() - g0)
     return max(per_rank), per_rank, res, gather_ms
@@ -309,7 +329,8 @@ def main(argv=None):
                    "batch_total": total, "batch_per_gpu": sizes, "n": n, "m": m, "nnzKKT": dims["nnzKKT"], "nnzL": dims["nnzL"],
                    "admm_iters": args.iters, "parallelism": "batch-sharded x%d, one all-gather of the result records per step" % world,
                    "per_rank_seconds": per_rank, "gather_ms": gather_ms,
-                   "collective": ("RCCL all_gather_into_tensor of the result records inside every step (backend %s, world %d%s)"
+                   "collective": ("RCCL all_gather_into_tensor of the result records inside every step, records packed by one launch, the exchange "
+                                  "asynchronous and double-buffered so the next step does not wait for it (backend %s, world %d%s)"
                                   % (dist.get_backend(), world, ", --force-dist" if args.force_dist else "")) if coll else None},
         "roofline": {"bound": "hbm", "kernel": "batched permuted tri-solve + z~ epilogue (plugin `solve`: k_tile_solve3 on arrowhead "
                                                "patterns, else k_arrow_solve / k_plan_solve), rldl_batch_time_solve_rotating",

@@ -337,6 +337,8 @@ void osqp_horizon_free(osqp_horizon *h);
  *                                                           x | y | obj | pri_res | dua_res | iter | status per instance, ranks in order
  * --------------------------------------------------------------------------------------------------------------------- */
 typedef struct osqp_dist osqp_dist;
+/* pack only (one launch on the workspace's stream, d_rec [batch][osqp_dist_record_len]): for callers with their own collective */
+c_int osqp_batch_pack_results(osqp_batch *w, c_float *d_rec);
 c_int osqp_dist_unique_id(char id[128]);
 c_int osqp_dist_init(osqp_dist **dp, const char id[128], c_int rank, c_int nranks, void *stream);
 c_int osqp_dist_record_len(const osqp_batch *w);                         /* n + m + 5 */

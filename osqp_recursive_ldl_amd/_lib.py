@@ -64,7 +64,7 @@ EXPORTED = [
     "rldl_batch_free", "rldl_batch_dims", "rldl_batch_export_symbolic", "rldl_batch_export_factor",
     "rldl_batch_factor_status", "rldl_batch_export_prod", "rldl_batch_time_solve", "rldl_batch_trace_solve", "rldl_batch_trace_factor", "rldl_batch_time_solve_rotating",
     "osqp_batch_set_default_settings", "osqp_batch_setup", "osqp_batch_solve", "osqp_batch_update_lin_cost",
-    "osqp_groups_bucket", "osqp_batch_update_bounds", "osqp_batch_update_bounds_async", "osqp_batch_partial_update_bounds_async", "osqp_batch_update_rho", "osqp_batch_update_settings", "osqp_batch_update_P_A", "osqp_batch_update_P_A_async", "osqp_batch_warm_start",
+    "osqp_groups_bucket", "osqp_batch_pack_results", "osqp_batch_update_bounds", "osqp_batch_update_bounds_async", "osqp_batch_partial_update_bounds_async", "osqp_batch_update_rho", "osqp_batch_update_settings", "osqp_batch_update_P_A", "osqp_batch_update_P_A_async", "osqp_batch_warm_start",
     "osqp_batch_get", "osqp_batch_get_iterates", "osqp_batch_get_scaling", "osqp_batch_get_polish_status", "osqp_batch_get_rho", "osqp_batch_linsys", "osqp_batch_solve_async", "osqp_batch_wait", "osqp_batch_setup_recursive", "osqp_batch_update_recursive", "osqp_batch_partial_update_bounds",
     "osqp_batch_time_iteration", "osqp_batch_last_loop", "osqp_batch_trace_iteration", "osqp_batch_cleanup",
     "rldl_batch_init_recursive", "rldl_batch_update_from_stage", "rldl_version",
@@ -147,6 +147,8 @@ def _declare(L):
     L.osqp_batch_solve.restype = c_int
     L.osqp_batch_update_lin_cost.argtypes = [VP, VP]
     L.osqp_batch_update_lin_cost.restype = c_int
+    L.osqp_batch_pack_results.argtypes = [VP, VP]
+    L.osqp_batch_pack_results.restype = c_int
     L.osqp_groups_bucket.argtypes = [c_int, VP, VP, IP]
     L.osqp_groups_bucket.restype = c_int
     L.osqp_batch_update_bounds.argtypes = [VP, VP, VP]

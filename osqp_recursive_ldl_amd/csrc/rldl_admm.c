@@ -600,6 +600,15 @@ void osqp_multi_free(osqp_multi *mm) {
   free(mm);
 }
 
+/* The result record of every instance [x | y | obj | pri_res | dua_res | iter | status] (n + m + 5 doubles, osqp_dist_record_len) packed
+ * into d_rec [batch][n + m + 5] by one launch on the workspace's stream: the send buffer of the multi-GPU all-gather for callers that
+ * bring their own collective (bench.py: torch.distributed; osqp_dist_gather_results packs and gathers itself). */
+c_int osqp_batch_pack_results(osqp_batch *w, c_float *d_rec) {
+  if (!w) return 7;
+  if (!d_rec) return 1;
+  return rldl_launch_pack_results(&w->W, (int)w->n, (int)w->m, d_rec, w->stream) ? RLDL_DEVICE_ERROR : 0;
+}
+
 /* Buckets `count` problems by sparsity pattern -- every osqp_setup of the reference owns its own pattern (qdldl_interface.c:99-166);
  * a handle here factorises one pattern, so instances are grouped by (pattern of P, pattern of A) before the workspaces are built.
  * P[i] / A[i]: CSC patterns (x ignored; row indices in the order the caller will also use for the values).  group[i] = bucket of

@@ -61,6 +61,42 @@ def gather_results(res, n, m, sizes=None, force=False):
     return unpack_results(out, n, m)
 
 
+class ResultGather:
+    """The path's collective, pipelined: step k's records are packed by ONE launch (pack_fn, e.g. OSQPBatch.pack_results) into one of
+    two send buffers and all-gathered asynchronously (all_gather_into_tensor, RCCL's own stream), so step k + 1's kernels do not
+    wait for the exchange; a buffer pair is reused only after its collective has completed.  Equal shards only (weak scaling)."""
+
+    def __init__(self, pack_fn, batch, n, m, device):
+        import torch
+        import torch.distributed as dist
+        self.n, self.m, self.pack_fn = n, m, pack_fn
+        world = dist.get_world_size()
+        L = n + m + 5
+        self.rec = [torch.empty((batch, L), dtype=torch.float64, device=device) for _ in range(2)]
+        self.out = [torch.empty((world * batch, L), dtype=torch.float64, device=device) for _ in range(2)]
+        self.work = [None, None]
+        self.k = 0
+
+    def gather(self):
+        """Enqueue pack + all-gather of the workspace's current results; returns the index of the buffer pair."""
+        import torch.distributed as dist
+        i = self.k & 1
+        self.k += 1
+        if self.work[i] is not None:
+            self.work[i].wait()                          # (stream-level wait: the buffers of two steps ago are free again)
+        self.pack_fn(self.rec[i])
+        self.work[i] = dist.all_gather_into_tensor(self.out[i], self.rec[i], async_op=True)
+        return i
+
+    def finish(self):
+        """Wait (stream-level) for the outstanding collectives; returns the results of the last gather as a dict of views."""
+        for wk in self.work:
+            if wk is not None:
+                wk.wait()
+        self.work = [None, None]
+        return unpack_results(self.out[(self.k - 1) & 1], self.n, self.m) if self.k else None
+
+
 def shard_sizes(batch, world):
     return [shard_range(batch, r, world)[1] - shard_range(batch, r, world)[0] for r in range(world)]
 
@@ -71,4 +107,4 @@ def sharded_values(values_fn, batch, rank, world):
     return values_fn(hi - lo, lo)
 
 
-__all__ = ["shard_range", "shard_sizes", "pack_results", "unpack_results", "gather_results", "sharded_values"]
+__all__ = ["shard_range", "shard_sizes", "pack_results", "unpack_results", "gather_results", "ResultGather", "sharded_values"]

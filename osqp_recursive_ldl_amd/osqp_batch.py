@@ -162,6 +162,15 @@ class OSQPBatch:
                 self._view(p[1].value, (self.batch, self.m), torch.float64).clone(),
                 self._view(p[2].value, (self.batch,), torch.float64).clone())
 
+    def pack_results(self, rec):
+        """osqp_batch_pack_results: the result records [x | y | obj | pri_res | dua_res | iter | status] of all instances into
+        rec [batch, n + m + 5] (float64, device), one launch on the workspace's stream."""
+        _dev_f64(rec, (self.batch, self.n + self.m + 5), "rec")
+        rc = int(_lib.lib().osqp_batch_pack_results(self.h, _dptr(rec)))
+        if rc:
+            raise RuntimeError("osqp_batch_pack_results failed (%d)" % rc)
+        return rec
+
     def update_lin_cost(self, q):
         return int(_lib.lib().osqp_batch_update_lin_cost(self.h, _dptr(_dev_f64(q, (self.batch, self.n), "q"))))
 

@@ -40,6 +40,12 @@ def test_c_level_rccl_gather_with_one_rank():
     assert torch.equal(out[:, :wl.n], r["x"]) and torch.equal(out[:, wl.n:wl.n + wl.m], r["y"])
     assert torch.equal(out[:, wl.n + wl.m], r["obj"]) and torch.equal(out[:, wl.n + wl.m + 1], r["pri_res"]) and torch.equal(out[:, wl.n + wl.m + 2], r["dua_res"])
     assert torch.equal(out[:, wl.n + wl.m + 3].to(torch.int32), r["iter"]) and torch.equal(out[:, wl.n + wl.m + 4].to(torch.int32), r["status"])
+    # pack only (callers with their own collective, bench.py): the same records as the torch packing of dist.py
+    from osqp_recursive_ldl_amd import dist as rdist
+    rec = torch.full((B, reclen), float("nan"), dtype=torch.float64, device="cuda:0")
+    w.pack_results(rec)
+    torch.cuda.synchronize()
+    assert torch.equal(rec, out) and torch.equal(rec, rdist.pack_results(r, wl.n, wl.m))
     # error behaviour: bad rank / size are refused before RCCL is touched
     bad = C.c_void_p()
     assert L.osqp_dist_init(C.byref(bad), uid, 2, 2, None) == 1 and not bad.value
