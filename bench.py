@@ -310,8 +310,11 @@ def main(argv=None):
                                shard.dAx * shard.fA[k % len(shard.fA)] if shard.fA else shard.dAx, settings["sigma"], rho0)
                  for k in range(ROT - 1)]
         hs, bs = [ls] + extra, [rhs] + [torch.randn_like(rhs) for _ in extra]
+        for h in hs:
+            h.set_cache_policy("stream")                     # a caller that cycles through handles says so: non-temporal row loads
         R.BatchLinsys.time_solve_rotating(hs, bs, reps=4 * ROT)
         hbm_ms = min(R.BatchLinsys.time_solve_rotating(hs, bs, reps=40 * ROT) for _ in range(3))
+        ls.set_cache_policy("auto")
         for h in extra:
             h.free()
     hbm_gbs = tri_bytes * B / (hbm_ms * 1e-3) / 1e9
@@ -336,7 +339,7 @@ def main(argv=None):
                                                "patterns, else k_arrow_solve / k_plan_solve), rldl_batch_time_solve_rotating",
                      "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_gbs / HBM_PEAK_GBS, "traffic": None,
                      "bytes_per_instance": tri_bytes, "instances_per_launch": B, "kernel_us": 1e3 * hbm_ms,
-                     "rotation": ROT, "rotation_working_set_MB": ROT * tri_bytes * B / 1e6,
+                     "rotation": ROT, "rotation_working_set_MB": ROT * tri_bytes * B / 1e6, "cache_policy": "stream (rldl_batch_set_cache_policy 2: non-temporal loads of the factor rows)",
                      "note": "achieved = SURVEY 8d algorithmic bytes 8 (nnzL + 3 N + m) x instances / launch duration (HIP events over "
                              "%d launches on the handles' stream); the launches cycle through %d handles with their own factor / tile / "
                              "right-hand-side arrays, %d MB together, so no launch finds its rows in the 256 MB Infinity Cache: the rows come "

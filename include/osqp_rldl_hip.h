@@ -137,6 +137,10 @@ c_int rldl_batch_time_solve(rldl_batch *h, c_float *d_b, c_int reps, c_float *ms
 /* the same over a rotation of handles that share one stream (launch r solves hs[r % count] on d_b[r % count]): with a combined
  * working set beyond the 256 MB Infinity Cache every launch streams its factor from HBM */
 c_int rldl_batch_time_solve_rotating(rldl_batch **hs, c_float **d_b, c_int count, c_int reps, c_float *ms_per_launch);
+/* cache policy of the factor rows in `solve`: 0 automatic (by the size of the rows of one solve against the 256 MB Infinity Cache),
+ * 1 keep them cached between solves (one factorisation, many solves: the ADMM loop through the plugin API), 2 stream them with
+ * non-temporal loads (many handles in turn, or rows beyond the cache) */
+c_int rldl_batch_set_cache_policy(rldl_batch *h, c_int policy);
 /* tracing aid: wave timeline of one launch of the solve kernel, host_out[batch][8] int64 ticks of the 100 MHz device clock
  * (wave start, all loads landed, forward gather / forward product / backward product / scatter done, stores issued, 0); 2 = this handle's solve kernel carries no timeline */
 c_int rldl_batch_trace_solve(rldl_batch *h, c_float *d_b, long long *host_out);

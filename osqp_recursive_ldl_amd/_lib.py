@@ -62,7 +62,7 @@ EXPORTED = [
     "update_linsys_solver_rho_vec_hipldl", "free_linsys_solver_hipldl",
     "rldl_batch_init", "rldl_batch_solve", "rldl_batch_update_matrices", "rldl_batch_update_rho_vec",
     "rldl_batch_free", "rldl_batch_dims", "rldl_batch_export_symbolic", "rldl_batch_export_factor",
-    "rldl_batch_factor_status", "rldl_batch_export_prod", "rldl_batch_time_solve", "rldl_batch_trace_solve", "rldl_batch_trace_factor", "rldl_batch_time_solve_rotating",
+    "rldl_batch_factor_status", "rldl_batch_export_prod", "rldl_batch_time_solve", "rldl_batch_trace_solve", "rldl_batch_trace_factor", "rldl_batch_set_cache_policy", "rldl_batch_time_solve_rotating",
     "osqp_batch_set_default_settings", "osqp_batch_setup", "osqp_batch_solve", "osqp_batch_update_lin_cost",
     "osqp_groups_bucket", "osqp_batch_pack_results", "osqp_batch_update_bounds", "osqp_batch_update_bounds_async", "osqp_batch_partial_update_bounds_async", "osqp_batch_update_rho", "osqp_batch_update_settings", "osqp_batch_update_P_A", "osqp_batch_update_P_A_async", "osqp_batch_warm_start",
     "osqp_batch_get", "osqp_batch_get_iterates", "osqp_batch_get_scaling", "osqp_batch_get_polish_status", "osqp_batch_get_rho", "osqp_batch_linsys", "osqp_batch_solve_async", "osqp_batch_wait", "osqp_batch_setup_recursive", "osqp_batch_update_recursive", "osqp_batch_partial_update_bounds",
@@ -136,6 +136,8 @@ def _declare(L):
     L.rldl_batch_time_solve_rotating.restype = c_int
     L.rldl_batch_trace_solve.argtypes = [VP, VP, VP]
     L.rldl_batch_trace_solve.restype = c_int
+    L.rldl_batch_set_cache_policy.argtypes = [VP, c_int]
+    L.rldl_batch_set_cache_policy.restype = c_int
     L.rldl_batch_trace_factor.argtypes = [VP, VP]
     L.rldl_batch_trace_factor.restype = c_int
 

@@ -112,6 +112,7 @@ typedef struct {
   int *fail;        /* [1]             sticky: set by any factorisation whose verdict is bad (zero pivot or fewer than n positive
                      *                  pivots, qdldl_interface.c:80-92); only the host clears it when it reads the verdict, so a
                      *                  failure in a stream of asynchronous refactorisations is not overwritten by a later success */
+  int nt_loads;     /* host-side launch hint: the solve kernel reads the factor rows with non-temporal loads (rldl_batch_set_cache_policy) */
 } rldl_dev_num;
 
 /* ADMM iterate state (DEVICE pointers, instance-major) + scalar settings */

@@ -3272,7 +3272,9 @@ __global__ __launch_bounds__(256, 2) void k_tile_solve(rldl_dev_sym S, rldl_dev_
 // move from LDS to registers once they have landed (a variant that left them in LDS to fit 128 registers / 16 waves per CU spent
 // 0.9 us per wave in each of the gather and the scatter on dependent LDS round trips and was no faster: DESIGN 7.1).  Same products as k_tile_solve; the head's y_c Dinv_c enters as the
 // initial value of the scatter accumulator instead of a closing fma (last-bit differences; RLDL_SOLVE_V2=1 selects the old kernel).  TRACE: wave timeline (rldl_batch_trace_solve).
-template <int TMAX, int TG, int TA, bool TRACE>
+// NT: the factor rows (tile of Ti, coupling values) are read with non-temporal loads (cache-policy bit nt): rows that will not be read
+// again before they are evicted do not displace the Infinity Cache's contents (rldl_batch_set_cache_policy).
+template <int TMAX, int TG, int TA, bool TRACE, bool NT>
 __global__ __launch_bounds__(256, (TA <= 5 && TG <= 18) ? 3 : 2) void k_tile_solve3(rldl_dev_sym S, rldl_dev_num Nn, double *__restrict__ b_all, int xdw, int cwp,
                                                          long long *__restrict__ trace) {
   typedef __attribute__((address_space(3))) void *lptr_t;
@@ -3322,7 +3324,7 @@ __global__ __launch_bounds__(256, (TA <= 5 && TG <= 18) ? 3 : 2) void k_tile_sol
     lptr_t dst = (lptr_t)(sh + (size_t)wv * pws);
     const unsigned l16 = 16u * (unsigned)lane;
     for (int pc = 0; pc < cwp; pc += 128)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rC, (lptr_t)((__attribute__((address_space(3))) double *)dst + pc), 16, l16, 8 * pc, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rC, (lptr_t)((__attribute__((address_space(3))) double *)dst + pc), 16, l16, 8 * pc, 0, NT ? 2 : 0);
   }
   TileRegs<TA> T;
   {                                                               // slot of (register k, lane) = entries of the registers before k + set bits of k's lane mask below the lane
@@ -3335,7 +3337,7 @@ __global__ __launch_bounds__(256, (TA <= 5 && TG <= 18) ? 3 : 2) void k_tile_sol
 #pragma unroll
     for (int k = 0; k < TA * TA; k++) {
       const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(msk[k] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)msk[k], 0u));
-      const pv_v2u r = __builtin_amdgcn_raw_buffer_load_b64(rTi, pv_select(msk[k], (first + rank) << 3, 0xffffffffu), 0, 0);
+      const pv_v2u r = __builtin_amdgcn_raw_buffer_load_b64(rTi, pv_select(msk[k], (first + rank) << 3, 0xffffffffu), 0, NT ? 2 : 0);
       T.v[k] = __hiloint2double((int)r.y, (int)r.x);
       first += (unsigned)__builtin_popcountll(msk[k]);
     }
@@ -3991,8 +3993,9 @@ static bool tile_solve3_usable(const rldl_dev_sym *S) {
 static int launch_tile_solve3(const rldl_dev_sym *S, const rldl_dev_num *Nn, double *d_b, long long *d_trace, void *stream) {
   const int pw = tile_per_wave(S), cwp = tile_solve3_cwp(S), grid = (Nn->batch + TILE_WPB - 1) / TILE_WPB;
   const size_t lds = sizeof(double) * (size_t)(cwp + pw + WAVE) * TILE_WPB;
-#define TS3(TG, TA) do { if (d_trace) hipLaunchKernelGGL((k_tile_solve3<3, TG, TA, true>), dim3(grid), dim3(TILE_WPB * WAVE), lds, (hipStream_t)stream, *S, *Nn, d_b, pw, cwp, d_trace); \
-    else hipLaunchKernelGGL((k_tile_solve3<3, TG, TA, false>), dim3(grid), dim3(TILE_WPB * WAVE), lds, (hipStream_t)stream, *S, *Nn, d_b, pw, cwp, d_trace); } while (0)
+#define TS3(TG, TA) do { if (d_trace) hipLaunchKernelGGL((k_tile_solve3<3, TG, TA, true, false>), dim3(grid), dim3(TILE_WPB * WAVE), lds, (hipStream_t)stream, *S, *Nn, d_b, pw, cwp, d_trace); \
+    else if (Nn->nt_loads) hipLaunchKernelGGL((k_tile_solve3<3, TG, TA, false, true>), dim3(grid), dim3(TILE_WPB * WAVE), lds, (hipStream_t)stream, *S, *Nn, d_b, pw, cwp, d_trace); \
+    else hipLaunchKernelGGL((k_tile_solve3<3, TG, TA, false, false>), dim3(grid), dim3(TILE_WPB * WAVE), lds, (hipStream_t)stream, *S, *Nn, d_b, pw, cwp, d_trace); } while (0)
   if (S->arrow_vsteps <= 12) {
 #define C(TA) TS3(12, TA)
     TILE_TA_SWITCH(C)

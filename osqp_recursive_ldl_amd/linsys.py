@@ -257,6 +257,12 @@ class BatchLinsys:
             raise RuntimeError("trace_solve failed")
         return out
 
+    def set_cache_policy(self, policy):
+        """rldl_batch_set_cache_policy: "auto" (default), "resident" (one factorisation, many solves: keep the rows in the Infinity
+        Cache) or "stream" (many handles in turn / rows beyond the cache: non-temporal loads)."""
+        if _lib.lib().rldl_batch_set_cache_policy(self.h, {"auto": 0, "resident": 1, "stream": 2}[policy]):
+            raise RuntimeError("set_cache_policy failed")
+
     def trace_factor(self):
         """Wave timeline of one numeric factorisation of the values the handle holds: int64 [batch, 8] ticks of the 100 MHz device
         clock (wave start, KKT values in the workspace, head contributions added, tail in registers, tail eliminated, factor row

@@ -45,6 +45,16 @@ for B in [int(x) for x in a.batches.split(",")]:
         msr = min(R.BatchLinsys.time_solve_rotating(hs, bs, reps=40 * a.rot) for _ in range(3))
         rec.update(rotating_us=1e3 * msr, rotating_frac_of_8TBs=tri * B / (msr * 1e-3) / 8e12, rotation=a.rot,
                    rotation_working_set_MB=a.rot * (tri * B) / 1e6)
+        for h in hs:
+            h.set_cache_policy("stream")                           # non-temporal loads of the factor rows (rldl_batch_set_cache_policy)
+        R.BatchLinsys.time_solve_rotating(hs, bs, reps=4 * a.rot)
+        msn = min(R.BatchLinsys.time_solve_rotating(hs, bs, reps=40 * a.rot) for _ in range(3))
+        b2 = rhs.clone()
+        ls.time_solve(b2, reps=20)
+        msrn = min(ls.time_solve(b2, reps=200) for _ in range(3))
+        rec.update(rotating_stream_policy_us=1e3 * msn, rotating_stream_policy_frac_of_8TBs=tri * B / (msn * 1e-3) / 8e12,
+                   resident_stream_policy_us=1e3 * msrn)
+        ls.set_cache_policy("auto")
         for h in hs[1:]:
             h.free()
     tr = ls.trace_solve(rhs.clone())

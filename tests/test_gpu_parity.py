@@ -496,6 +496,11 @@ def test_solve_wave_timeline_and_rotating_timing(R):
     if tr is not None:                                              # (None: a kernel-selection switch took the handle off the tile kernel)
         assert tr.shape == (B, 8) and (tr[:, :7] > 0).all()
         assert (np.diff(tr[:, [0, 7, 1, 2, 3, 4, 5, 6]], axis=1) >= 0).all()      # start, loads issued, landed, gather, forward, backward, scatter, stores
+    hs[1].set_cache_policy("stream")                               # non-temporal row loads: same arithmetic, same result
+    nt = hs[1].solve(rhs.clone())
+    hs[1].set_cache_policy("resident")
+    assert torch.equal(nt, hs[1].solve(rhs.clone()))
+    hs[1].set_cache_policy("auto")
     bs = [rhs.clone() for _ in hs]
     assert R.BatchLinsys.time_solve_rotating(hs, bs, reps=3) > 0.0                  # one launch per handle: bs[k] = solve of handle k
     assert torch.equal(bs[0], ref)
