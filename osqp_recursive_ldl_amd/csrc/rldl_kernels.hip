@@ -2240,6 +2240,52 @@ __device__ __forceinline__ double recip_nr(double d) {
 // 3.8 x faster than the row-per-lane fma form with LDS broadcast reads, hand-over included (scripts/ubench_mfma_f64.hip:
 // 6.45 -> 1.72 us per block update per wave at 8 waves per CU); the f64 MFMA rate equals the f64 vector rate on gfx950, what
 // is saved are the SM^2 broadcast reads and the issue slots of SM^2 scalar fmas.  The elimination itself stays on the VALUs.
+// One column step of the tail elimination (arrow_factor_body, LP): J is a template parameter so that every step is its own
+// straight-line code (a 56-step loop with the chunk logic inside is beyond the unroller's size limit and w[] would live in scratch).
+template <int SM, int J, int CH>
+__device__ __forceinline__ void elim_step(double (&w)[SM], double *pc, int g, int lane, double &dcur, double &lcur, int &zero, int &npos) {
+  if (J < g) {                                                   // uniform
+    if (dcur == 0.0) zero = 1;
+    if (lane == 0 && dcur > 0.0) npos++;
+    const lds_d2 *cur = reinterpret_cast<const lds_d2 *>(pc + (J & 1) * 64);
+    double *nxt = pc + ((J + 1) & 1) * 64;
+    const double a = w[J];
+    if (lane > J) w[J] = lcur;
+    wave_sync();                                                 // (compiler fence: the reads below stay behind the write of cur)
+    constexpr int k0 = (J + 1) & ~1, nch = (SM - k0 + CH - 1) / CH;
+    lds_d2 cb[2][CH / 2];
+#pragma unroll
+    for (int q = 0; q < CH / 2; q++) if (k0 + 2 * q < SM) cb[0][q] = cur[k0 / 2 + q];
+#pragma unroll
+    for (int c = 0; c < nch; c++) {
+#pragma unroll
+      for (int q = 0; q < CH / 2; q++) if (c + 1 < nch && k0 + (c + 1) * CH + 2 * q < SM) cb[(c + 1) & 1][q] = cur[(k0 + (c + 1) * CH) / 2 + q];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int e = 0; e < CH; e++) {
+        const int k = k0 + c * CH + e;
+        if (k > J && k < SM) {
+          w[k] = fma(-a, cb[c & 1][e >> 1][e & 1], w[k]);
+          if (k == J + 1 && J + 1 < g) {                         // uniform
+            dcur = readlane_f64(w[k], k);
+            lcur = w[k] * recip_nr(dcur);
+            nxt[lane] = lane < g ? lcur : 0.0;
+          }
+        }
+      }
+    }
+  }
+}
+template <int SM, int CH, int... Js>
+__device__ __forceinline__ void elim_steps(std::integer_sequence<int, Js...>, double (&w)[SM], double *pc, int g, int lane, double &dcur, double &lcur,
+                                           int &zero, int &npos) {
+  (elim_step<SM, Js, CH>(w, pc, g, lane, dcur, lcur, zero, npos), ...);
+}
+// STAGE_LP: the elimination of k_stage_factor_r with the pivot column through LDS and read-ahead (elim_step) instead of v_readlane;
+// same box, B = 4096, MPC shape: 1.553 -> 1.502 ms per full factorisation (at 3 waves per SIMD; forced to 4 by launch bounds: 1.573)
+#ifndef STAGE_LP
+#define STAGE_LP 1
+#endif
 typedef double v4d __attribute__((ext_vector_type(4)));
 template <int SM, bool MFMA>
 __global__ __launch_bounds__(WAVE) void k_stage_factor_r(rldl_dev_sym S, rldl_dev_num Nn, const int *__restrict__ mask, int b0,
@@ -2260,7 +2306,7 @@ __global__ __launch_bounds__(WAVE) void k_stage_factor_r(rldl_dev_sym S, rldl_de
   int npos = 0, zero = 0;
   // every inner loop below runs to SM without range checks (checks would fence the LDS reads one by one): the tiles are
   // SM + 1 wide (host: ld), zero outside the live block, so the surplus terms are exact zeros
-  for (int p = lane; p < (2 * G.smax + lt_rows) * ld + 2 * ld + 128; p += WAVE) sh[p] = 0.0;
+  for (int p = lane; p < (2 * G.smax + lt_rows) * ld + 2 * ld + 130; p += WAVE) sh[p] = 0.0;
   wave_sync();
   for (int j = lane; j < G.bs[b0]; j += WAVE) npos += Dv[j] > 0.0 ? 1 : 0;        // pivots kept from the blocks before b0
   if (b0 > 0) {                                                  // L(b0, b0-1) and D_{b0-1} back from the stored factor
@@ -2332,6 +2378,14 @@ __global__ __launch_bounds__(WAVE) void k_stage_factor_r(rldl_dev_sym S, rldl_de
     }
     wave_sync();                                                 // T, Lt are free again
     // 3. right-looking elimination of the panel
+    if (STAGE_LP) {                                              // pivot column through LDS with read-ahead (elim_step, as k_arrow_factor)
+      double *pc = sh + (((2 * G.smax + lt_rows) * ld + 2 * ld + 1) & ~1);
+      double dpv = readlane_f64(w[0], 0), lpv = w[0] * recip_nr(dpv);
+      pc[lane] = lane < s ? lpv : 0.0;
+      elim_steps<SM, 8>(std::make_integer_sequence<int, SM>(), w, pc, s, lane, dpv, lpv, zero, npos);
+#pragma unroll
+      for (int j = 0; j < SM; j++) if (lane == j && j < s) dcur[j] = w[j];
+    } else
 #pragma unroll
     for (int j = 0; j < SM; j++) {
       if (j < s) {                                               // uniform
@@ -2382,47 +2436,6 @@ __global__ __launch_bounds__(WAVE) void k_stage_factor_r(rldl_dev_sym S, rldl_de
 //          (pivot by v_readlane, pivot column through a 64-entry LDS buffer, one fma per column for the whole block).
 // Same outputs as k_factor (factor in plan slot order, D, Dinv, status); summation order of the Schur complement differs.
 // ------------------------------------------------------------------------------------------------
-// One column step of the tail elimination (arrow_factor_body, LP): J is a template parameter so that every step is its own
-// straight-line code (a 56-step loop with the chunk logic inside is beyond the unroller's size limit and w[] would live in scratch).
-template <int SM, int J>
-__device__ __forceinline__ void elim_step(double (&w)[SM], double *pc, int g, int lane, double &dcur, double &lcur, int &zero, int &npos) {
-  if (J < g) {                                                   // uniform
-    if (dcur == 0.0) zero = 1;
-    if (lane == 0 && dcur > 0.0) npos++;
-    const lds_d2 *cur = reinterpret_cast<const lds_d2 *>(pc + (J & 1) * 64);
-    double *nxt = pc + ((J + 1) & 1) * 64;
-    const double a = w[J];
-    if (lane > J) w[J] = lcur;
-    wave_sync();                                                 // (compiler fence: the reads below stay behind the write of cur)
-    constexpr int k0 = (J + 1) & ~1, nch = (SM - k0 + LCH - 1) / LCH;
-    lds_d2 cb[2][LCH / 2];
-#pragma unroll
-    for (int q = 0; q < LCH / 2; q++) if (k0 + 2 * q < SM) cb[0][q] = cur[k0 / 2 + q];
-#pragma unroll
-    for (int c = 0; c < nch; c++) {
-#pragma unroll
-      for (int q = 0; q < LCH / 2; q++) if (c + 1 < nch && k0 + (c + 1) * LCH + 2 * q < SM) cb[(c + 1) & 1][q] = cur[(k0 + (c + 1) * LCH) / 2 + q];
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int e = 0; e < LCH; e++) {
-        const int k = k0 + c * LCH + e;
-        if (k > J && k < SM) {
-          w[k] = fma(-a, cb[c & 1][e >> 1][e & 1], w[k]);
-          if (k == J + 1 && J + 1 < g) {                         // uniform
-            dcur = readlane_f64(w[k], k);
-            lcur = w[k] * recip_nr(dcur);
-            nxt[lane] = lane < g ? lcur : 0.0;
-          }
-        }
-      }
-    }
-  }
-}
-template <int SM, int... Js>
-__device__ __forceinline__ void elim_steps(std::integer_sequence<int, Js...>, double (&w)[SM], double *pc, int g, int lane, double &dcur, double &lcur,
-                                           int &zero, int &npos) {
-  (elim_step<SM, Js>(w, pc, g, lane, dcur, lcur, zero, npos), ...);
-}
 template <int SM>
 __device__ __forceinline__ void tile_invert_lds(const rldl_dev_sym &S, const rldl_dev_num &Nn, int inst, double *sh, int lane);
 // INV: the tail's inverse (the tile store Ti of the solve kernels) is formed in the same launch, from the triangle while it is
@@ -2504,7 +2517,7 @@ __device__ __forceinline__ void arrow_factor_body(const rldl_dev_sym &S, const r
   double *pc = sh + ((nW + g0 + 1) & ~1);
   double dcur = readlane_f64(w[0], 0), lcur = w[0] * recip_nr(dcur);
   pc[lane] = lane < g ? lcur : 0.0;
-  elim_steps<SM>(std::make_integer_sequence<int, SM>(), w, pc, g, lane, dcur, lcur, zero, npos);
+  elim_steps<SM, LCH>(std::make_integer_sequence<int, SM>(), w, pc, g, lane, dcur, lcur, zero, npos);
   } else {
 #pragma unroll
   for (int j = 0; j < SM; j++) {
@@ -4193,7 +4206,7 @@ static int launch_stage_factor(const rldl_dev_sym *S, const rldl_dev_num *Nn, co
   const int sm = G->smax <= 8 ? 8 : G->smax <= 16 ? 16 : G->smax <= 24 ? 24 : 32, nt16 = 16 * ((sm + 15) / 16);
   const bool mfma = !no_mfma && nt16 * (nt16 + 1) <= 2 * G->smax * G->ld && G->ld >= sm + 1;
   const int lt_rows = mfma ? (nt16 > G->smax ? nt16 : G->smax) : G->smax;
-  const size_t lds = sizeof(double) * (size_t)((2 * G->smax + lt_rows) * G->ld + 2 * G->ld + 128);
+  const size_t lds = sizeof(double) * (size_t)((2 * G->smax + lt_rows) * G->ld + 2 * G->ld + 130);
   const dim3 grid(Nn->batch), blk(WAVE);
 #define SF(SMV) do { if (mfma) hipLaunchKernelGGL((k_stage_factor_r<SMV, true>), grid, blk, lds, (hipStream_t)stream, *S, *Nn, d_mask, first_block, d_b0v, lt_rows); \
                      else hipLaunchKernelGGL((k_stage_factor_r<SMV, false>), grid, blk, lds, (hipStream_t)stream, *S, *Nn, d_mask, first_block, d_b0v, lt_rows); } while (0)
