@@ -33,6 +33,8 @@ def test_tiles_tables_and_solve(N, tables, monkeypatch):
     import osqp_recursive_ldl_amd as R
     if tables == "L-tiles":
         monkeypatch.setenv("RLDL_PROD_V1", "1")
+    elif os.environ.get("RLDL_PROD_V1"):
+        pytest.skip("RLDL_PROD_V1 is set: the K-tile tables are off")
     wl = R.workloads.MPCStageQPs(N=N)
     B = 2
     Px, Ax, q, l, u = wl.values(B)
