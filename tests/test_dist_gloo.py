@@ -43,6 +43,22 @@ for b in range(B):                                    # every rank holds the who
 res2 = {k: v[:3] for k, v in res.items()}
 full2 = rd.gather_results(res2, n, m)
 assert full2["x"].shape == (3 * world, n)
+# the pipelined gather of the benchmark (dist.ResultGather: one pack call + an asynchronous all_gather_into_tensor, two buffer
+# pairs): four steps with results that differ per step and rank; after finish() every rank holds the LAST step's records of all
+# ranks in rank order, and the buffers of earlier steps were reused without mixing steps
+step = [0]
+def pack(rec):
+    rec.copy_(rd.pack_results({k: (v[:3] + (100 * step[0] + rank) if v.dtype == torch.float64 else v[:3]) for k, v in res.items()}, n, m))
+gat = rd.ResultGather(pack, 3, n, m, "cpu")
+for s_ in range(4):
+    step[0] = s_
+    gat.gather()
+last = gat.finish()
+ref = [torch.empty((3, n + m + 5), dtype=torch.float64) for _ in range(world)]
+mine = rd.pack_results({k: (v[:3] + (300 + rank) if v.dtype == torch.float64 else v[:3]) for k, v in res.items()}, n, m)
+dist.all_gather(ref, mine)
+assert torch.equal(last["x"], torch.cat(ref, 0)[:, :n]) and torch.equal(last["obj"], torch.cat(ref, 0)[:, n + m])
+assert last["x"].shape == (3 * world, n)
 dist.barrier()
 if rank == 0: print("DIST_OK")
 dist.destroy_process_group()
