@@ -208,22 +208,6 @@ static int upload_symbolic(rldl_batch *h) {
               free(ot);
             }
             if (!D->arrow_out) D->arrow_dense = 0;
-            if (D->arrow_dense && s->nnzK < 32768 && !s->polish) {   /* KKT assembly inside the factor kernel (rldl_launch_assemble_factor) */
-              const int nPA = s->nnzP + s->nnzA;
-              unsigned *pa = (unsigned *)malloc(sizeof(unsigned) * (size_t)(nPA + 1)), *oth = (unsigned *)malloc(sizeof(unsigned) * (size_t)(s->nnzK + 1));
-              unsigned char *hit = (unsigned char *)calloc((size_t)s->nnzK + 1, 1);
-              if (pa && oth && hit) {
-                int e, k, no = 0;
-                for (e = 0; e < s->nnzP; e++) { k = s->PtoK[e]; hit[k] = 1; pa[e] = (unsigned)s->KtoW[k] | ((unsigned)k << 16) | (s->Pisdiag[e] ? 0x80000000u : 0u); }
-                for (e = 0; e < s->nnzA; e++) { k = s->AtoK[e]; hit[k] = 1; pa[s->nnzP + e] = (unsigned)s->KtoW[k] | ((unsigned)k << 16); }
-                for (k = 0; k < s->nnzK; k++) if (!hit[k]) oth[no++] = (unsigned)s->KtoW[k] | ((unsigned)k << 16);
-                D->asm_pa = (const unsigned *)dev_upload(pa, sizeof(unsigned) * (size_t)nPA, &ok);
-                D->asm_other = (const unsigned *)dev_upload(oth, sizeof(unsigned) * (size_t)(no ? no : 1), &ok);
-                D->asm_nother = no;
-                if (!D->asm_pa || !D->asm_other) D->asm_pa = 0;
-              }
-              free(pa); free(oth); free(hit);
-            }
           }
         } else D->arrow_dense = 0;
       }
@@ -244,7 +228,7 @@ static void free_dev_symbolic(rldl_dev_sym *D) {
 #define FR(f) if (D->f) (void)hipFree((void *)D->f)
   FR(perm); FR(PtoK); FR(AtoK); FR(rhotoK); FR(sigK); FR(Pisdiag); FR(Lp); FR(Li); FR(Rp); FR(Rj); FR(Rpos);
   FR(KtoW); FR(Udst); FR(Uab); FR(Up); FR(Pp); FR(Pi); FR(Prp); FR(Prj); FR(Prpos); FR(Ap); FR(Ai); FR(Arp);
-  FR(Arj); FR(Arpos); FR(LtoS); FR(Pfl); FR(Afl); FR(Pbl); FR(Pbp); FR(Abl); FR(Abp); FR(plan); FR(arrow_tpos); FR(arrow_pab); FR(arrow_pdc); FR(arrow_out); FR(asm_pa); FR(asm_other);
+  FR(Arj); FR(Arpos); FR(LtoS); FR(Pfl); FR(Afl); FR(Pbl); FR(Pbp); FR(Abl); FR(Abp); FR(plan); FR(arrow_tpos); FR(arrow_pab); FR(arrow_pdc); FR(arrow_out);
 #undef FR
   memset(D, 0, sizeof(*D));
 }
@@ -368,10 +352,6 @@ c_int rldl_batch_update_matrices(rldl_batch *h, const c_float *d_Px, const c_flo
  * receive a copy of the incoming values in the same pass. */
 c_int rldl_batch_update_matrices_async(rldl_batch *h, const c_float *d_Px, const c_float *d_Ax, c_float *keep_Px, c_float *keep_Ax) {
   if (!h || h->sym->polish) return 1;
-  if (d_Px && d_Ax) {                                          /* both value sets: the factor kernel assembles the KKT values itself */
-    const int rc = rldl_launch_assemble_factor(&h->dsym, &h->num, d_Px, d_Ax, keep_Px, keep_Ax, h->stream);
-    if (rc >= 0) return rc ? 1 : 0;
-  }
   if (rldl_launch_kkt_assemble_keep(&h->dsym, &h->num, d_Px, d_Ax, keep_Px, keep_Ax, h->stream)) return 1;
   return rldl_launch_factor(&h->dsym, &h->num, 0, h->stream) ? 1 : 0;
 }

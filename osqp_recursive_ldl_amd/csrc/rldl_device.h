@@ -94,9 +94,6 @@ typedef struct {
   const int *arrow_tpos;       /* [arrow_g][64]: CSC position of L(g0 + lane, g0 + c), or -1 */
   const unsigned *arrow_pab, *arrow_pdc;  /* head pair updates, flat: posA | posB << 16 and dst | column << 16 (workspace positions) */
   int arrow_npairs;
-  const unsigned *asm_pa;      /* [nnzP + nnzA] KKT assembly inside k_arrow_factor: workspace position | KKT position << 16 | (P diagonal) << 31, or NULL */
-  const unsigned *asm_other;   /* [asm_nother] KKT entries no P / A value lands on (rho and sigma entries): workspace position | KKT position << 16 */
-  int asm_nother;
   const unsigned *arrow_out;   /* [nS] per factor slot: workspace position | head column << 16 (0xffff: padding slot / tail column): write-out in slot order */
   int arrow_cnt[32];           /* per virtual-row step: number of lanes with an entry (kernarg segment -> scalar loads) */
   rldl_dev_stage stage;        /* stage.nb > 0: block-tridiagonal pattern, numeric factorisation by dense stage blocks */
@@ -182,8 +179,6 @@ int rldl_launch_horizon_adopt(const rldl_dev_sym *So, const rldl_dev_num *No, co
                               int *d_n_reused, void *stream);
 int rldl_launch_factor_from(const rldl_dev_sym *S, const rldl_dev_num *Nn, int c_start, void *stream);
 int rldl_launch_solve(const rldl_dev_sym *S, const rldl_dev_num *Nn, double *d_b, void *stream);
-int rldl_launch_assemble_factor(const rldl_dev_sym *S, const rldl_dev_num *Nn, const double *d_Px, const double *d_Ax, double *keepP, double *keepA,
-                                void *stream);   /* -1: this pattern has no fused path (assemble + factor separately) */
 int rldl_launch_factor_trace(const rldl_dev_sym *S, const rldl_dev_num *Nn, long long *d_trace, void *stream);
 int rldl_launch_solve_trace(const rldl_dev_sym *S, const rldl_dev_num *Nn, double *d_b, long long *d_trace, void *stream);
 int rldl_launch_admm_iter(const rldl_dev_sym *S, const rldl_dev_num *Nn, const rldl_dev_admm *W, void *stream);

@@ -2440,10 +2440,9 @@ template <int SM>
 __device__ __forceinline__ void tile_invert_lds(const rldl_dev_sym &S, const rldl_dev_num &Nn, int inst, double *sh, int lane);
 // INV: the tail's inverse (the tile store Ti of the solve kernels) is formed in the same launch, from the triangle while it is
 // still in registers -- no second launch that reads it back from the factor row (k_tile_invert, kept for the other factor kernels)
-struct ArrowAsm { const double *Px, *Ax; double *keepP, *keepA; };   // new P / A values: the kernel assembles the KKT values itself (Px == nullptr: they are in Kx)
 template <int SM, bool INV, bool LP>
 __device__ __forceinline__ void arrow_factor_body(const rldl_dev_sym &S, const rldl_dev_num &Nn, const int *__restrict__ mask, int inst,
-                                                  long long *__restrict__ trace = nullptr, const ArrowAsm *am = nullptr) {
+                                                  long long *__restrict__ trace = nullptr) {
   const int lane = threadIdx.x;
   if (mask && !mask[inst]) return;
   // wave timeline (rldl_batch_trace_factor): 0 start, 1 KKT values in the workspace, 2 head contributions added, 3 tail in registers,
@@ -2461,36 +2460,6 @@ __device__ __forceinline__ void arrow_factor_body(const rldl_dev_sym &S, const r
   constexpr int FBV = 16, FBP = 32, FBO = 16;
   for (int i = lane; i < nW; i += WAVE) sh[i] = 0.0;
   wave_sync();
-  if (am && am->Px) {
-    // KKT assembly in the same launch (was k_kkt_assemble in front): every new P / A value goes to its workspace word, to its KKT slot
-    // (update_rho_vec and the residual kernels read Kx) and to the workspace's own copy of the data; sigma is added on P's diagonal
-    // (kkt.c:69-79).  The KKT entries no P / A value lands on (rho, bare sigma) come from Kx as before.
-    double *Kw = Nn.Kx + (size_t)inst * S.nnzK;
-    const double *px = am->Px + (size_t)inst * S.nnzP, *ax = am->Ax + (size_t)inst * S.nnzA;
-    double *kp = am->keepP ? am->keepP + (size_t)inst * S.nnzP : nullptr, *ka = am->keepA ? am->keepA + (size_t)inst * S.nnzA : nullptr;
-    const int nPA = S.nnzP + S.nnzA;
-    for (int e0 = 0; e0 < nPA; e0 += FBV * WAVE) {
-      unsigned tw[FBV];
-      double v[FBV];
-#pragma unroll
-      for (int u = 0; u < FBV; u++) {
-        const int e = min(e0 + u * WAVE + lane, nPA - 1);
-        tw[u] = S.asm_pa[e];
-        v[u] = *(e < S.nnzP ? px + e : ax + (e - S.nnzP));
-      }
-#pragma unroll
-      for (int u = 0; u < FBV; u++) {
-        const int e = e0 + u * WAVE + lane;
-        if (e < nPA) {
-          const double val = v[u] + ((tw[u] >> 31) ? Nn.sigma : 0.0);
-          sh[tw[u] & 0xffffu] = val;
-          Kw[(tw[u] >> 16) & 0x7fffu] = val;
-          if (e < S.nnzP) { if (kp) kp[e] = v[u]; } else if (ka) ka[e - S.nnzP] = v[u];
-        }
-      }
-    }
-    for (int t = lane; t < S.asm_nother; t += WAVE) { const unsigned tw = S.asm_other[t]; sh[tw & 0xffffu] = K[tw >> 16]; }
-  } else
   for (int k0 = 0; k0 < S.nnzK; k0 += FBV * WAVE) {
     int ix[FBV];
     double v[FBV];
@@ -2615,8 +2584,8 @@ __device__ __forceinline__ void arrow_factor_body(const rldl_dev_sym &S, const r
   }
 }
 template <int SM, bool INV, bool LP>
-__global__ __launch_bounds__(WAVE) void k_arrow_factor(rldl_dev_sym S, rldl_dev_num Nn, const int *__restrict__ mask, long long *__restrict__ trace, ArrowAsm am) {
-  arrow_factor_body<SM, INV, LP>(S, Nn, mask, blockIdx.x, trace, &am);
+__global__ __launch_bounds__(WAVE) void k_arrow_factor(rldl_dev_sym S, rldl_dev_num Nn, const int *__restrict__ mask, long long *__restrict__ trace) {
+  arrow_factor_body<SM, INV, LP>(S, Nn, mask, blockIdx.x, trace);
 }
 template <int SM>
 __global__ __launch_bounds__(WAVE) void k_arrow_factor_multi(rldl_dev_multi M, int masked) {   // masked: only the instances whose W.refactor is set (rho adaptation)
@@ -4169,9 +4138,7 @@ extern "C" int rldl_launch_solve_begin(const rldl_dev_admm *W, int n, int m, int
   return launch_status();
 }
 
-static int launch_factor(const rldl_dev_sym *S, const rldl_dev_num *Nn, const int *d_mask, int c_start, void *stream, long long *d_trace = nullptr,
-                         const ArrowAsm *am = nullptr) {
-  const ArrowAsm am0 = am ? *am : ArrowAsm{nullptr, nullptr, nullptr, nullptr};
+static int launch_factor(const rldl_dev_sym *S, const rldl_dev_num *Nn, const int *d_mask, int c_start, void *stream, long long *d_trace = nullptr) {
   if (Nn->batch <= 0) return 0;
   if (c_start <= 0 && S->arrow_ok && S->arrow_dense && S->arrow_g <= 64 && !getenv("RLDL_NO_ARROW_FACTOR")) {
     const size_t al = sizeof(double) * (size_t)(S->nnzL + S->N + S->arrow_g0 + 2 + 128);
@@ -4183,13 +4150,13 @@ static int launch_factor(const rldl_dev_sym *S, const rldl_dev_num *Nn, const in
       if (S->tile_ok && Nn->Ti && S->arrow_tb == 0 && !split) {               // (the conditions of launch_tile_invert)
         const size_t fl = al > il ? al : il;
         static const int rl = getenv("RLDL_READLANE_PIVOT") ? 1 : 0;          // (A/B: pivot column by v_readlane, as in round 2)
-#define AF(SMV) do { if (rl) hipLaunchKernelGGL((k_arrow_factor<SMV, true, false>), grid, blk, fl, (hipStream_t)stream, *S, *Nn, d_mask, d_trace, am0); \
-                     else hipLaunchKernelGGL((k_arrow_factor<SMV, true, true>), grid, blk, fl, (hipStream_t)stream, *S, *Nn, d_mask, d_trace, am0); } while (0)
+#define AF(SMV) do { if (rl) hipLaunchKernelGGL((k_arrow_factor<SMV, true, false>), grid, blk, fl, (hipStream_t)stream, *S, *Nn, d_mask, d_trace); \
+                     else hipLaunchKernelGGL((k_arrow_factor<SMV, true, true>), grid, blk, fl, (hipStream_t)stream, *S, *Nn, d_mask, d_trace); } while (0)
         if (g <= 16) AF(16); else if (g <= 32) AF(32); else if (g <= 48) AF(48); else if (g <= 56) AF(56); else AF(64);
 #undef AF
         return launch_status();
       }
-#define AF(SMV) hipLaunchKernelGGL((k_arrow_factor<SMV, false, true>), grid, blk, al, (hipStream_t)stream, *S, *Nn, d_mask, d_trace, am0)
+#define AF(SMV) hipLaunchKernelGGL((k_arrow_factor<SMV, false, true>), grid, blk, al, (hipStream_t)stream, *S, *Nn, d_mask, d_trace)
       if (g <= 16) AF(16); else if (g <= 32) AF(32); else if (g <= 48) AF(48); else if (g <= 56) AF(56); else AF(64);
 #undef AF
       if (launch_status()) return -1;
@@ -4263,16 +4230,6 @@ extern "C" int rldl_launch_stage_factor_each(const rldl_dev_sym *S, const rldl_d
   return d_b0v ? launch_stage_factor(S, Nn, 0, 0, d_b0v, tiles_adopted, stream) : -1;
 }
 
-// new P / A values and the numeric factorisation in ONE launch (arrowhead factor kernel with its assembly tables); -1: no such path here
-extern "C" int rldl_launch_assemble_factor(const rldl_dev_sym *S, const rldl_dev_num *Nn, const double *d_Px, const double *d_Ax, double *keepP,
-                                           double *keepA, void *stream) {
-  static const int off = getenv("RLDL_SPLIT_ASSEMBLE") ? 1 : 0;   // (A/B: k_kkt_assemble as its own launch, as in round 2)
-  if (off || !S->asm_pa || !d_Px || !d_Ax) return -1;
-  if (!(S->arrow_ok && S->arrow_dense && S->arrow_g <= 64) || getenv("RLDL_NO_ARROW_FACTOR")) return -1;
-  if (sizeof(double) * (size_t)(S->nnzL + S->N + S->arrow_g0 + 2 + 128) > RLDL_LDS_LIMIT) return -1;
-  const ArrowAsm am{d_Px, d_Ax, keepP, keepA};
-  return launch_factor(S, Nn, 0, 0, stream, nullptr, &am) ? 1 : 0;
-}
 // the factorisation with the wave timeline of the arrowhead kernel ([batch][8] stamps, arrow_factor_body); -1: another kernel serves the pattern
 extern "C" int rldl_launch_factor_trace(const rldl_dev_sym *S, const rldl_dev_num *Nn, long long *d_trace, void *stream) {
   if (!(S->arrow_ok && S->arrow_dense && S->arrow_g <= 64) || getenv("RLDL_NO_ARROW_FACTOR")) return -1;
