@@ -2457,7 +2457,7 @@ __device__ __forceinline__ void arrow_factor_body(const rldl_dev_sym &S, const r
   // Every loop below that reads an index table from global memory takes FB rounds at a time: the FB index loads (and the
   // value loads that do not depend on them) are in flight together instead of one memory round trip per round.
   // (FBV / FBP rounds while the row registers are still free, FBO with the eliminated rows live)
-  constexpr int FBV = 16, FBP = 32, FBO = 16;
+  constexpr int FBV = 16, FBP = 16, FBO = 16;
   for (int i = lane; i < nW; i += WAVE) sh[i] = 0.0;
   wave_sync();
   for (int k0 = 0; k0 < S.nnzK; k0 += FBV * WAVE) {
@@ -2479,14 +2479,36 @@ __device__ __forceinline__ void arrow_factor_body(const rldl_dev_sym &S, const r
   }
   wave_sync();
   // head: every pair (a, b) of column j adds -l_a l_b d_j to a tail entry; columns are independent -> no barrier, atomics
-  for (int t0 = 0; t0 < S.arrow_npairs; t0 += FBP * WAVE) {      // flat over all head columns: independent iterations
-    unsigned ab[FBP], dc[FBP];
+  {                                                              // flat over all head columns: independent iterations
+    // Rounds of FBP x 64 pairs; the index words of round k + 1 are fetched while round k is processed (two register sets), and a
+    // round is straight-line: its 3 LDS reads per pair are independent of its atomics (they read head entries, the atomics write
+    // tail entries), eight pairs at a time.  A pair index past the end is clamped to the last pair and adds 0.0 there (a predicate
+    // per pair made every pair its own basic block: read, wait, multiply, add, one after the other).
+    const int np = S.arrow_npairs;
+    auto fetch = [&](unsigned (&ab)[FBP], unsigned (&dc)[FBP], int t0) {
 #pragma unroll
-    for (int u = 0; u < FBP; u++) { const int t = min(t0 + u * WAVE + lane, S.arrow_npairs - 1); ab[u] = S.arrow_pab[t]; dc[u] = S.arrow_pdc[t]; }
+      for (int u = 0; u < FBP; u++) { const int t = min(t0 + u * WAVE + lane, np - 1); ab[u] = S.arrow_pab[t]; dc[u] = S.arrow_pdc[t]; }
+    };
+    auto apply = [&](const unsigned (&ab)[FBP], const unsigned (&dc)[FBP], int t0) {
 #pragma unroll
-    for (int u = 0; u < FBP; u++)
-      if (t0 + u * WAVE + lane < S.arrow_npairs)
-        unsafeAtomicAdd(&sh[dc[u] & 0xffffu], -(sh[ab[u] & 0xffffu] * (sh[ab[u] >> 16] * dih[dc[u] >> 16])));
+      for (int u0 = 0; u0 < FBP; u0 += 8) {
+        double pv[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) pv[u] = -(sh[ab[u0 + u] & 0xffffu] * (sh[ab[u0 + u] >> 16] * dih[dc[u0 + u] >> 16]));
+#pragma unroll
+        for (int u = 0; u < 8; u++) unsafeAtomicAdd(&sh[dc[u0 + u] & 0xffffu], t0 + (u0 + u) * WAVE + lane < np ? pv[u] : 0.0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    unsigned ab0[FBP], dc0[FBP], ab1[FBP], dc1[FBP];
+    if (np > 0) fetch(ab0, dc0, 0);
+    for (int t0 = 0; t0 < np; t0 += 2 * FBP * WAVE) {
+      const bool second = t0 + FBP * WAVE < np;                  // uniform
+      if (second) fetch(ab1, dc1, t0 + FBP * WAVE);
+      apply(ab0, dc0, t0);
+      if (t0 + 2 * FBP * WAVE < np) fetch(ab0, dc0, t0 + 2 * FBP * WAVE);
+      if (second) apply(ab1, dc1, t0 + FBP * WAVE);
+    }
   }
   // (l_rc = K_rc / d_c of the head columns is applied on the way out: nothing below reads the head entries again)
   // tail: Schur complement -> registers, row per lane; positions from the [g][64] table (-1: structural zero / c >= r)
@@ -3165,9 +3187,91 @@ template <int SM, int... Is>
 __device__ __forceinline__ void invert_rows(std::integer_sequence<int, Is...>, double (&X)[SM], lds_d2 (&rb)[2][LCH / 2], const lds_d2 *st, int g) {
   (invert_row<SM, Is + 1>(X, rb, st, g), ...);
 }
+// The same inverse on the matrix cores (TILE_INVERT_MFMA, the default): X = L22^-1 by block forward substitution over 16 x 16 blocks,
+//   X_JJ = L_JJ^-1,   X_IJ = -X_II (sum_{J <= K < I} L_IK X_KJ)   (I > J),
+// every block product four v_mfma_f64_16x16x4_f64.  The 16 x 16 diagonal inverses come from the register substitution above, four
+// blocks at a time (lane group d = lane / 16 inverts block d, column per lane) and go to LDS as dense blocks; the A operands (L_IK from
+// the packed triangle, -X_II from those dense blocks) are LDS reads with compile-time offsets, the B operands never leave registers:
+// register q of a lane's 16 x 16 result (rows lane / 16 + 4 q, column lane % 16) IS the B operand of k-chunk q.  All ten result blocks
+// of a block column stay in registers until the column is stored in tile order.  64 MFMAs + 120 fmas per lane instead of 1225 fmas per lane:
+// the vector-unit version spends g^2 / 2 fma slots per lane on a product of which g^3 / 6 multiply-adds are not zero.
+// LDS: [0, tri) the triangle, zo = even(tri): 64 zero words (rows >= g read them), then NT dense blocks.
+typedef double inv_v4d __attribute__((ext_vector_type(4)));
+template <int SM>
+__device__ __forceinline__ void tile_invert_mfma(const rldl_dev_sym &S, const rldl_dev_num &Nn, int inst, double *sh, int lane) {
+  constexpr int NT = (SM + 15) / 16;
+  const int g = S.arrow_g, tri = (g * (g - 1)) >> 1;
+  double *Z = sh + ((tri + 1) & ~1), *Dd = Z + 64;
+  const int lr = lane & 15, lq = lane >> 4;
+  Z[lane] = 0.0;
+  wave_sync();
+  {                                                              // 1. the diagonal blocks, four at a time
+    double X[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) X[i] = i == lr ? 1.0 : 0.0;
+#pragma unroll
+    for (int i = 1; i < 16; i++) {
+      const int R = 16 * lq + i;                                 // row of L22; rows >= g are rows of the identity
+      const double *row = R < g ? sh + ((R * (R - 1)) >> 1) + 16 * lq : Z;
+      double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+      for (int j = 0; j < i; j++) { if (j & 1) a1 = fma(row[j], X[j], a1); else a0 = fma(row[j], X[j], a0); }
+      X[i] -= a0 + a1;
+    }
+    if (lq < NT) {
+#pragma unroll
+      for (int i = 0; i < 16; i++) Dd[lq * 256 + i * 16 + lr] = X[i];
+    }
+  }
+  wave_sync();
+  // 2. block forward substitution, one block column of X at a time; a finished column goes straight to the tile store (slot of
+  //    X(row, col) from the host's table; 8-byte stores, the row is 9.8 KB and L2 merges them) -- holding all ten blocks for a staged
+  //    write-out would cost 80 registers next to the factor phases' 200
+  const unsigned short *ts = reinterpret_cast<const unsigned short *>(S.plan + S.po_tislot);
+  double *To = Nn.Ti + (size_t)inst * S.ldTi;
+  const double *lrow[NT];
+#pragma unroll
+  for (int I = 0; I < NT; I++) { const int r = 16 * I + lr; lrow[I] = (r < g ? sh + ((r * (r - 1)) >> 1) : Z) + lq; }
+#pragma unroll
+  for (int J = 0; J < NT; J++) {
+    inv_v4d Xc[NT];                                              // blocks X_IJ, I >= J, in the MFMA result layout
+    unsigned short sl[NT][4];
+#pragma unroll
+    for (int I = J; I < NT; I++)
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int row = 16 * I + lq + 4 * q, col = 16 * J + lr;
+        const unsigned short v = ts[(row < g ? row : 0) * 64 + col];
+        sl[I][q] = row < g && col < row ? v : (unsigned short)0xffffu;
+      }
+#pragma unroll
+    for (int q = 0; q < 4; q++) Xc[J][q] = Dd[J * 256 + (lq + 4 * q) * 16 + lr];
+#pragma unroll
+    for (int I = J + 1; I < NT; I++) {
+      inv_v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int K = J; K < I; K++)
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(lrow[I][16 * K + 4 * kk], Xc[K][kk], acc, 0, 0, 0);
+      inv_v4d xi = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++) xi = __builtin_amdgcn_mfma_f64_16x16x4f64(-Dd[I * 256 + lr * 16 + 4 * kk + lq], acc[kk], xi, 0, 0, 0);
+      Xc[I] = xi;
+    }
+#pragma unroll
+    for (int I = J; I < NT; I++)
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+        if (sl[I][q] != 0xffffu) To[sl[I][q]] = Xc[I][q];
+  }
+}
+#ifndef TILE_INVERT_MFMA
+#define TILE_INVERT_MFMA 1
+#endif
 // (the triangle is in sh[0, g (g - 1) / 2), row-major packed; the same words then become the staging buffer)
 template <int SM>
 __device__ __forceinline__ void tile_invert_lds(const rldl_dev_sym &S, const rldl_dev_num &Nn, int inst, double *sh, int lane) {
+  if (TILE_INVERT_MFMA) { tile_invert_mfma<SM>(S, Nn, inst, sh, lane); return; }
   const int g = S.arrow_g;
   wave_sync();
   double X[SM];
@@ -4090,7 +4194,7 @@ static int launch_tile_admm(const rldl_dev_sym *S, const rldl_dev_num *Nn, const
 static int launch_tile_invert(const rldl_dev_sym *S, const rldl_dev_num *Nn, const int *d_mask, void *stream) {
   if (!S->tile_ok || !Nn->Ti || S->arrow_tb != 0) return 0;
   const int g = S->arrow_g;
-  const size_t lds = sizeof(double) * (size_t)((g * (g - 1)) / 2 + 2 + 2 * LCH);
+  const size_t lds = sizeof(double) * (size_t)((g * (g - 1)) / 2 + 2 + 2 * LCH + 64 + 256 * ((g + 15) / 16));
   const dim3 grid(Nn->batch), blk(WAVE);
   if (g <= 16) hipLaunchKernelGGL(k_tile_invert<16>, grid, blk, lds, (hipStream_t)stream, *S, *Nn, d_mask);
   else if (g <= 32) hipLaunchKernelGGL(k_tile_invert<32>, grid, blk, lds, (hipStream_t)stream, *S, *Nn, d_mask);
@@ -4146,7 +4250,7 @@ static int launch_factor(const rldl_dev_sym *S, const rldl_dev_num *Nn, const in
       const dim3 grid(Nn->batch), blk(WAVE);
       const int g = S->arrow_g;
       static const int split = getenv("RLDL_SPLIT_INVERT") ? 1 : 0;            // (A/B: tail inverse as its own launch, as in round 2)
-      const size_t il = sizeof(double) * (size_t)((g * (g - 1)) / 2 + 2 + 2 * LCH);
+      const size_t il = sizeof(double) * (size_t)((g * (g - 1)) / 2 + 2 + 2 * LCH + 64 + 256 * ((g + 15) / 16));
       if (S->tile_ok && Nn->Ti && S->arrow_tb == 0 && !split) {               // (the conditions of launch_tile_invert)
         const size_t fl = al > il ? al : il;
         static const int rl = getenv("RLDL_READLANE_PIVOT") ? 1 : 0;          // (A/B: pivot column by v_readlane, as in round 2)
@@ -4471,7 +4575,7 @@ extern "C" int rldl_multi_update_key(const rldl_dev_sym *S, const rldl_dev_num *
 }
 extern "C" int rldl_multi_update_lds(const rldl_dev_sym *S, int which) {     // dynamic LDS bytes of the factor (0) / tail inverse (1) kernel
   const int g = S->arrow_g;
-  return which == 0 ? (int)(sizeof(double) * (size_t)(S->nnzL + S->N + S->arrow_g0 + 2 + 128)) : (int)(sizeof(double) * (size_t)((g * (g - 1)) / 2 + 2 + 2 * LCH));
+  return which == 0 ? (int)(sizeof(double) * (size_t)(S->nnzL + S->N + S->arrow_g0 + 2 + 128)) : (int)(sizeof(double) * (size_t)((g * (g - 1)) / 2 + 2 + 2 * LCH + 64 + 256 * ((g + 15) / 16)));
 }
 extern "C" int rldl_launch_multi_update(const rldl_dev_multi *M, const rldl_dev_multi_pa *PA, int total, int key, int factor_lds, int invert_lds,
                                         void *stream) {
