@@ -2249,9 +2249,9 @@ __device__ __forceinline__ void elim_step(double (&w)[SM], double *pc, int g, in
     if (lane == 0 && dcur > 0.0) npos++;
     const lds_d2 *cur = reinterpret_cast<const lds_d2 *>(pc + (J & 1) * 64);
     double *nxt = pc + ((J + 1) & 1) * 64;
-    const double a = w[J];
-    if (lane > J) w[J] = lcur;
+    if (lane > J) w[J] = lcur;                                   // l_r = a_r / d_J; the update below is w[k] -= l_r a_k with a_k, UNSCALED, from the buffer
     wave_sync();                                                 // (compiler fence: the reads below stay behind the write of cur)
+    const double lme = lcur;
     constexpr int k0 = (J + 1) & ~1, nch = (SM - k0 + CH - 1) / CH;
     lds_d2 cb[2][CH / 2];
 #pragma unroll
@@ -2265,11 +2265,11 @@ __device__ __forceinline__ void elim_step(double (&w)[SM], double *pc, int g, in
       for (int e = 0; e < CH; e++) {
         const int k = k0 + c * CH + e;
         if (k > J && k < SM) {
-          w[k] = fma(-a, cb[c & 1][e >> 1][e & 1], w[k]);
+          w[k] = fma(-lme, cb[c & 1][e >> 1][e & 1], w[k]);
           if (k == J + 1 && J + 1 < g) {                         // uniform
-            dcur = readlane_f64(w[k], k);
+            nxt[lane] = lane < g ? w[k] : 0.0;                   // the next pivot column goes out unscaled, at once: its LDS round trip runs
+            dcur = readlane_f64(w[k], k);                        // beside the reciprocal of the next pivot instead of behind it
             lcur = w[k] * recip_nr(dcur);
-            nxt[lane] = lane < g ? lcur : 0.0;
           }
         }
       }
@@ -2381,7 +2381,7 @@ __global__ __launch_bounds__(WAVE) void k_stage_factor_r(rldl_dev_sym S, rldl_de
     if (STAGE_LP) {                                              // pivot column through LDS with read-ahead (elim_step, as k_arrow_factor)
       double *pc = sh + (((2 * G.smax + lt_rows) * ld + 2 * ld + 1) & ~1);
       double dpv = readlane_f64(w[0], 0), lpv = w[0] * recip_nr(dpv);
-      pc[lane] = lane < s ? lpv : 0.0;
+      pc[lane] = lane < s ? w[0] : 0.0;                          // (unscaled column, see elim_step)
       elim_steps<SM, 8>(std::make_integer_sequence<int, SM>(), w, pc, s, lane, dpv, lpv, zero, npos);
 #pragma unroll
       for (int j = 0; j < SM; j++) if (lane == j && j < s) dcur[j] = w[j];
@@ -2538,7 +2538,7 @@ __device__ __forceinline__ void arrow_factor_body(const rldl_dev_sym &S, const r
   //     keeps 2-3 reads in flight and every pair of fmas waits a full LDS latency).
   double *pc = sh + ((nW + g0 + 1) & ~1);
   double dcur = readlane_f64(w[0], 0), lcur = w[0] * recip_nr(dcur);
-  pc[lane] = lane < g ? lcur : 0.0;
+  pc[lane] = lane < g ? w[0] : 0.0;                              // (unscaled column, see elim_step)
   elim_steps<SM, LCH>(std::make_integer_sequence<int, SM>(), w, pc, g, lane, dcur, lcur, zero, npos);
   } else {
 #pragma unroll
