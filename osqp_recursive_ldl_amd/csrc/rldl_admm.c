@@ -281,8 +281,11 @@ static c_int solve_impl(osqp_batch *w, int wait) {
   hipStream_t st;
   if (!w) return 7; /* OSQP_WORKSPACE_NOT_INIT_ERROR */
   B = (size_t)w->batch; st = (hipStream_t)w->stream;
-  /* cold_start (auxil.c:158-162) when warm starting is off, status = OSQP_UNSOLVED, active counter: one launch */
-  if (rldl_launch_solve_begin(&w->W, (int)w->n, (int)w->m, w->st.warm_start ? 0 : 1, 0, w->stream)) return 1;
+  /* cold_start (auxil.c:158-162) when warm starting is off, status = OSQP_UNSOLVED, active counter: one launch -- or, without
+   * termination checks (no counter to set up) and on the tile kernel, done by the first launch of the iterations itself */
+  w->W.begin_flags = 0;
+  if (!w->st.check_termination && rldl_admm_begin_in_kernel(&w->ls->dsym, &w->ls->num, &w->W)) w->W.begin_flags = 1 | (w->st.warm_start ? 0 : 2);
+  else if (rldl_launch_solve_begin(&w->W, (int)w->n, (int)w->m, w->st.warm_start ? 0 : 1, 0, w->stream)) return 1;
 
   (void)hipEventRecord((hipEvent_t)w->ev0, st);
   iter = 0;
@@ -299,6 +302,7 @@ static c_int solve_impl(osqp_batch *w, int wait) {
     /* delta_x / delta_y feed only the infeasibility tests of a check: stored by the last iteration of the group */
     w->W.write_delta = 1;
     if (rldl_launch_admm_iters(&w->ls->dsym, &w->ls->num, &w->W, (int)(next - iter), w->stream)) return 1;
+    w->W.begin_flags = 0;
     launches += next - iter;
     groups++;
     iter = next;

@@ -127,6 +127,8 @@ typedef struct {
   int *refactor;                                       /* [batch] mask written by the adapt-rho step */
   int *n_active;                                       /* [RLDL_NACT_SLOTS] instances still iterating, counted per slot inst % RLDL_NACT_SLOTS (one counter would serialise the batch's atomics in L2) */
   int write_delta;                                     /* 1: this iteration also stores delta_x / delta_y (a check follows) */
+  int begin_flags;                                     /* first launch of a solve on the tile kernel (rldl_admm_begin_in_kernel): 1 = status <- OSQP_UNSOLVED
+                                                        * by the kernel itself, 2 = cold start (x = z = y = 0, auxil.c:158-162): no k_solve_begin launch */
   /* polish (src/polish.c): masked copy of A (inactive rows zeroed), rhs / solution / refinement vectors [batch][n+m] */
   double *pol_Ax, *pol_b, *pol_z, *pol_r;
   int *pol_mask, *status_polish;
@@ -181,6 +183,7 @@ int rldl_launch_factor_from(const rldl_dev_sym *S, const rldl_dev_num *Nn, int c
 int rldl_launch_solve(const rldl_dev_sym *S, const rldl_dev_num *Nn, double *d_b, void *stream);
 int rldl_launch_factor_trace(const rldl_dev_sym *S, const rldl_dev_num *Nn, long long *d_trace, void *stream);
 int rldl_launch_solve_trace(const rldl_dev_sym *S, const rldl_dev_num *Nn, double *d_b, long long *d_trace, void *stream);
+int rldl_admm_begin_in_kernel(const rldl_dev_sym *S, const rldl_dev_num *Nn, const rldl_dev_admm *W);   /* 1: rldl_launch_admm_iters honours W->begin_flags */
 int rldl_launch_admm_iter(const rldl_dev_sym *S, const rldl_dev_num *Nn, const rldl_dev_admm *W, void *stream);
 int rldl_launch_bcast_rows(int batch, int len, double *dst, const double *src, void *stream);
 int rldl_launch_set_range(int batch, int ld, int start, int cnt, double *dst, const double *src, const double *s, void *stream);

@@ -3553,7 +3553,12 @@ __global__ __launch_bounds__(256, 2) void k_tile_admm(rldl_dev_sym S, rldl_dev_n
   if (MULTI) { const int g = multi_group(M.first_tile, M.ngroups, bid); S = M.S[g]; Nn = M.N[g]; W = M.W[g]; xdw = M.xdw[g]; bid -= M.first_tile[g]; }
   const int inst = bid * wpb + wv;
   if (inst >= Nn.batch) return;
-  if (W.status[inst] != ST_UNSOLVED) return;
+  // first launch of a solve without termination checks: the start of osqp_solve (status = OSQP_UNSOLVED, cold start) is done here
+  // instead of by a k_solve_begin launch in front
+  const int bf = MULTI ? 0 : W.begin_flags;
+  if (bf & 1) { if (lane == 0) W.status[inst] = ST_UNSOLVED; }
+  else if (W.status[inst] != ST_UNSOLVED) return;
+  const bool cold = (bf & 2) != 0;
   long long *tr = TRACE && W.trace ? W.trace + 8 * (size_t)inst : nullptr;
   if (TRACE && tr && lane == 0) tr[7] = wall_clock64();
   char *shb = reinterpret_cast<char *>(sh);
@@ -3596,8 +3601,8 @@ __global__ __launch_bounds__(256, 2) void k_tile_admm(rldl_dev_sym S, rldl_dev_n
       const unsigned xa = on ? xb + 8u * (unsigned)jp : dmy;
       xz[t] = xa | ((head && TK > 0 ? dmy : xa) << 16);            // (scatter variant: a head slot of x ends as -sum_r L(r, c) x_r and is read like a tail entry)
       zh[t] = head && TK == 0 ? xa : dmy;
-      va[t] = !on ? 0.0 : var ? x[i] : z[i];
-      vb[t] = !on ? 0.0 : var ? q[i] : y[i];
+      va[t] = !on || cold ? 0.0 : var ? x[i] : z[i];
+      vb[t] = !on ? 0.0 : var ? q[i] : cold ? 0.0 : y[i];
       const bool con = on && !var;
       rinv[t] = con ? ri[i] : 0.0;
       const unsigned ca = cb + 8u * (unsigned)(t * WAVE);
@@ -4375,6 +4380,11 @@ extern "C" int rldl_launch_solve_trace(const rldl_dev_sym *S, const rldl_dev_num
 
 // `iters` ADMM iterations of every active instance.  The arrowhead kernel runs them inside one launch with the factor
 // kept on chip; the other kernels are launched once per iteration (W->write_delta applies to the last one).
+// 1 when rldl_launch_admm_iters runs the tile kernel, which starts a solve itself (W->begin_flags): the caller then skips k_solve_begin
+extern "C" int rldl_admm_begin_in_kernel(const rldl_dev_sym *S, const rldl_dev_num *Nn, const rldl_dev_admm *W) {
+  static const int off = (getenv("RLDL_ITERS_PER_LAUNCH") || getenv("RLDL_SOLVE_BEGIN_LAUNCH")) ? 1 : 0;
+  return !off && Nn->batch > 0 && arrow_usable(S) && S->N <= 8 * WAVE && tile_admm_usable(S, Nn, W) && !W->trace;
+}
 extern "C" int rldl_launch_admm_iters(const rldl_dev_sym *S, const rldl_dev_num *Nn, const rldl_dev_admm *W, int iters, void *stream) {
   if (Nn->batch <= 0 || iters <= 0) return 0;
   static const int one = getenv("RLDL_ITERS_PER_LAUNCH") ? atoi(getenv("RLDL_ITERS_PER_LAUNCH")) : 0;   // timing experiments
