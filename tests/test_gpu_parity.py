@@ -122,6 +122,40 @@ def test_batched_factor_and_solve_match_oracle(R, shape):
     ls.free()
 
 
+@pytest.mark.parametrize("shape", [(6, 10, 0.5, 11), (12, 20, 0.3, 12), (16, 30, 0.25, 13), (24, 40, 0.2, 14), (33, 60, 0.18, 15),
+                                   (40, 90, 0.15, 16), (48, 110, 0.15, 17), (56, 120, 0.14, 18), (62, 130, 0.13, 19)])
+def test_tail_sizes_across_the_kernel_instantiations(R, shape):
+    """The arrowhead kernels are instantiated per tail size (16 / 32 / 48 / 56 / 64: k_arrow_factor with the inverse of the tail on the
+    matrix cores in 1 - 4 blocks of 16, k_tile_solve3's tile grid): problems whose dense tail lands in every one of them, factor and
+    solve against the oracle; a tail beyond 64 falls back to the generic kernels and must give the same answers."""
+    n, m, dens, pseed = shape
+    wl = R.workloads.SharedPatternQPs(n=n, m=m, density=dens, pattern_seed=pseed)
+    B = 5
+    Px, Ax, q, l, u = wl.values(B)
+    rho = 0.05 + np.random.default_rng(2).random((B, m))
+    ls = R.BatchLinsys(wl.P_pattern, wl.A_pattern, dev(Px), dev(Ax), 1e-6, dev(rho))
+    assert ls.status == 0 and (ls.factor_status() == n).all()
+    sym = ls.export_symbolic()
+    rhs = np.random.default_rng(3).standard_normal((B, n + m))
+    sol = ls.solve(dev(rhs)).cpu().numpy()
+    again = ls.solve(dev(rhs)).cpu().numpy()
+    assert np.array_equal(sol, again)
+    for b in range(B):
+        P, qq, A, ll, uu = wl.instance(b)
+        o = ob.OracleLinsys(P, A, 1e-6, rho[b], perm=sym["perm"])
+        assert relerr(ls.export_factor(b)["Lx"], o.export()["Lx"]) < 1e-12
+        assert relerr(sol[b], o.solve(rhs[b])) < 1e-10
+    # new values through update_matrices (the refactorisation path of the benchmark): same check
+    Px2, Ax2 = wl.values(B, seed0=77)[:2]
+    assert ls.update_matrices(dev(Px2), dev(Ax2)) == 0
+    sol2 = ls.solve(dev(rhs)).cpu().numpy()
+    for b in range(B):
+        P2, _, A2, _, _ = wl.instance(b, seed0=77)
+        o = ob.OracleLinsys(P2, A2, 1e-6, rho[b], perm=sym["perm"])
+        assert relerr(sol2[b], o.solve(rhs[b])) < 1e-10
+    ls.free()
+
+
 def test_batched_update_rho_vec_and_matrices_match_fresh_factorisation(R):
     wl = R.workloads.SharedPatternQPs(n=20, m=35, density=0.2, pattern_seed=11)
     B = 5
