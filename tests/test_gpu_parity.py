@@ -551,6 +551,28 @@ def test_solve_wave_timeline_and_rotating_timing(R):
         h.free()
 
 
+def test_warm_started_fixed_iteration_solves_continue_where_the_last_one_stopped(R):
+    """Without termination checks the first launch of the tile kernel starts the solve itself (status, cold start: no k_solve_begin
+    launch).  Cold: 50 iterations.  Warm (osqp_solve with warm_start = 1, osqp.c:380-385 keeps x, z, y): 30 iterations, then 20 more
+    from where they stopped -- the same 50 iterations, bit for bit; and a cold solve after them starts from zero again."""
+    wl = R.workloads.SharedPatternQPs()
+    B = 7
+    Px, Ax, q, l, u = wl.values(B)
+    base = dict(rho=0.1, sigma=1e-6, alpha=1.6, check_termination=0, adaptive_rho=0, scaling=0)
+    wc = R.OSQPBatch(wl.P_pattern, wl.A_pattern, dev(Px), dev(Ax), dev(q), dev(l), dev(u), max_iter=50, warm_start=0, **base)
+    ww = R.OSQPBatch(wl.P_pattern, wl.A_pattern, dev(Px), dev(Ax), dev(q), dev(l), dev(u), max_iter=30, warm_start=1, **base)
+    r50 = wc.solve()
+    r30 = ww.solve()
+    assert not torch.equal(r30["x"], r50["x"])
+    assert ww.update_settings(max_iter=20) == 0
+    r30_20 = ww.solve()
+    assert torch.equal(r30_20["x"], r50["x"]) and torch.equal(r30_20["y"], r50["y"]) and torch.equal(r30_20["z"], r50["z"])
+    assert (r30_20["status"] == r50["status"]).all()
+    again = wc.solve()                                            # cold start: the iterates of the last solve do not leak in
+    assert torch.equal(again["x"], r50["x"]) and torch.equal(again["y"], r50["y"])
+    wc.cleanup(); ww.cleanup()
+
+
 def test_resident_iterations_equal_single_iteration_launches(R):
     """The fused kernel keeps an instance's factor and iterates on chip for a whole group of iterations; running the
     same number of iterations as separate one-iteration launches (state through HBM every time) must give the same
