@@ -513,10 +513,9 @@ c_int osqp_batch_update_P_A_async(osqp_batch *w, const c_float *d_Px, const c_fl
     if (d_Px && !HIP_OK(hipMemcpyAsync(w->Px, d_Px, sizeof(double) * (size_t)w->batch * (size_t)w->nnzP, hipMemcpyDeviceToDevice, st))) return 1;
     if (d_Ax && !HIP_OK(hipMemcpyAsync(w->Ax, d_Ax, sizeof(double) * (size_t)w->batch * (size_t)w->nnzA, hipMemcpyDeviceToDevice, st))) return 1;
     if (rldl_launch_scale_data(&w->ls->dsym, &w->W, w->Px, w->Ax, w->q, w->l, w->u, (int)w->st.scaling, w->stream)) return 1;
-    if (rldl_batch_update_matrices_async(w->ls, w->Px, w->Ax, 0, 0)) return 1;
-  } else if (rldl_batch_update_matrices_async(w->ls, d_Px, d_Ax, w->Px, w->Ax)) return 1;   /* the workspace's copy is written by the scatter */
-  /* reset_info (auxil.c:628-645) in one launch */
-  if (rldl_launch_solve_begin(&w->W, (int)w->n, (int)w->m, 0, 1, w->stream)) return 1;
+    if (rldl_batch_update_matrices_async(w->ls, w->Px, w->Ax, 0, 0, w->W.status, w->W.rho_updates)) return 1;
+  } else if (rldl_batch_update_matrices_async(w->ls, d_Px, d_Ax, w->Px, w->Ax, w->W.status, w->W.rho_updates)) return 1;
+  /* (the workspace's copy of the values is written by the scatter kernel, and reset_info, auxil.c:628-645, rides along in it) */
   w->refactor_pending = 1;
   return 0;
 }

@@ -350,9 +350,10 @@ c_int rldl_batch_update_matrices(rldl_batch *h, const c_float *d_Px, const c_flo
 /* update_matrices without the host round trip: scatter + refactor are only enqueued; the QDLDL verdict (qdldl_interface.c:598-600)
  * is delivered by the next rldl_batch_check_status (which synchronises the stream).  keep_Px / keep_Ax (optional): arrays that
  * receive a copy of the incoming values in the same pass. */
-c_int rldl_batch_update_matrices_async(rldl_batch *h, const c_float *d_Px, const c_float *d_Ax, c_float *keep_Px, c_float *keep_Ax) {
+c_int rldl_batch_update_matrices_async(rldl_batch *h, const c_float *d_Px, const c_float *d_Ax, c_float *keep_Px, c_float *keep_Ax,
+                                       int *d_status_reset, int *d_rho_updates_reset) {
   if (!h || h->sym->polish) return 1;
-  if (rldl_launch_kkt_assemble_keep(&h->dsym, &h->num, d_Px, d_Ax, keep_Px, keep_Ax, h->stream)) return 1;
+  if (rldl_launch_kkt_assemble_keep(&h->dsym, &h->num, d_Px, d_Ax, keep_Px, keep_Ax, d_status_reset, d_rho_updates_reset, h->stream)) return 1;
   return rldl_launch_factor(&h->dsym, &h->num, 0, h->stream) ? 1 : 0;
 }
 c_int rldl_batch_update_rho_vec(rldl_batch *h, const c_float *d_rho_vec, const int *d_mask) {

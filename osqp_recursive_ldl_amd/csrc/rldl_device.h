@@ -165,7 +165,7 @@ typedef struct { const double *const *Px, *const *Ax; double *const *keepP, *con
 int rldl_launch_kkt_assemble(const rldl_dev_sym *S, const rldl_dev_num *Nn, const double *d_Px, const double *d_Ax,
                              const double *d_rho_vec, int set_sigma_only, const int *d_mask, void *stream);
 int rldl_launch_kkt_assemble_keep(const rldl_dev_sym *S, const rldl_dev_num *Nn, const double *d_Px, const double *d_Ax, double *keepP,
-                                  double *keepA, void *stream);
+                                  double *keepA, int *d_status_reset, int *d_rho_updates_reset, void *stream);   /* the two int arrays (or NULL): reset_info rides along */
 int rldl_launch_factor(const rldl_dev_sym *S, const rldl_dev_num *Nn, const int *d_mask, void *stream);
 int rldl_launch_stage_factor(const rldl_dev_sym *S, const rldl_dev_num *Nn, const int *d_mask, int first_block, void *stream);
 int rldl_launch_stage_invert(const rldl_dev_sym *S, const rldl_dev_num *Nn, void *stream);

@@ -58,7 +58,7 @@ int rldl_stage_prog_prefix(const rldl_batch *h, int nb_act, int **d_prog, int *n
 void osqp_batch_reset_info(osqp_batch *w);                                    /* rldl_admm.c: auxil.c:628-645 */
 c_int osqp_batch_bounds_ok(osqp_batch *w, c_int count, const c_float *d_l, const c_float *d_u);   /* rldl_admm.c: 1 when l <= u everywhere */
 c_int rldl_batch_update_matrices_async(rldl_batch *h, const c_float *d_Px, const c_float *d_Ax, c_float *keep_Px,
-                                       c_float *keep_Ax);                                       /* rldl_backend.c */
+                                       c_float *keep_Ax, int *d_status_reset, int *d_rho_updates_reset);   /* rldl_backend.c */
 c_int rldl_batch_check_status(rldl_batch *h); /* sync + qdldl_interface.c:80-92 verdict: 0 ok, 1 failed */
 
 #endif

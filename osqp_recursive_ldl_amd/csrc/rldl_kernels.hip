@@ -123,8 +123,11 @@ __device__ __forceinline__ void kkt_assemble_body(const rldl_dev_sym &S, const r
 __global__ __launch_bounds__(256) void k_kkt_assemble(rldl_dev_sym S, rldl_dev_num Nn, const double *__restrict__ Px,
                                                       const double *__restrict__ Ax, const double *__restrict__ rho_vec,
                                                       int set_sigma_only, const int *__restrict__ mask,
-                                                      double *__restrict__ keepP, double *__restrict__ keepA) {
+                                                      double *__restrict__ keepP, double *__restrict__ keepA,
+                                                      int *__restrict__ status_reset, int *__restrict__ rho_updates_reset) {
   kkt_assemble_body(S, Nn, Px, Ax, rho_vec, set_sigma_only, mask, keepP, keepA, blockIdx.x);
+  // reset_info of osqp_update_P_A (auxil.c:628-645: status = OSQP_UNSOLVED, rho_updates = 0) rides along: no launch of its own
+  if (status_reset && threadIdx.x == 0) { status_reset[blockIdx.x] = ST_UNSOLVED; rho_updates_reset[blockIdx.x] = 0; }
 }
 // rho_vec of the instances whose rho moved (W.refactor) into rho_inv and the KKT values, every group of a set (update_rho_vec, qdldl_interface.c:605-619)
 __global__ __launch_bounds__(256) void k_kkt_assemble_multi_rho(rldl_dev_multi M) {
@@ -4214,15 +4217,16 @@ extern "C" int rldl_launch_kkt_assemble(const rldl_dev_sym *S, const rldl_dev_nu
                                         const int *d_mask, void *stream) {
   if (Nn->batch <= 0) return 0;
   hipLaunchKernelGGL(k_kkt_assemble, dim3(Nn->batch), dim3(256), 0, (hipStream_t)stream, *S, *Nn, d_Px, d_Ax, d_rho_vec,
-                     set_sigma_only, d_mask, (double *)0, (double *)0);
+                     set_sigma_only, d_mask, (double *)0, (double *)0, (int *)0, (int *)0);
   return launch_status();
 }
 // the same scatter that also stores the incoming values in the caller's own arrays (osqp_update_P_A keeps a copy of the data)
 extern "C" int rldl_launch_kkt_assemble_keep(const rldl_dev_sym *S, const rldl_dev_num *Nn, const double *d_Px, const double *d_Ax,
-                                             double *keepP, double *keepA, void *stream) {
+                                             double *keepP, double *keepA, int *d_status_reset, int *d_rho_updates_reset, void *stream) {
   if (Nn->batch <= 0) return 0;
   hipLaunchKernelGGL(k_kkt_assemble, dim3(Nn->batch), dim3(256), 0, (hipStream_t)stream, *S, *Nn, d_Px, d_Ax, (const double *)0, 0,
-                     (const int *)0, d_Px ? keepP : (double *)0, d_Ax ? keepA : (double *)0);
+                     (const int *)0, d_Px ? keepP : (double *)0, d_Ax ? keepA : (double *)0,
+                     d_status_reset && d_rho_updates_reset ? d_status_reset : (int *)0, d_rho_updates_reset);
   return launch_status();
 }
 // start of osqp_solve for the whole batch in one launch: status = OSQP_UNSOLVED, rho_updates = 0 (reset_info, auxil.c:628-645),
