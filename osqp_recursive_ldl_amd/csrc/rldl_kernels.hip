@@ -129,6 +129,47 @@ __global__ __launch_bounds__(256) void k_kkt_assemble(rldl_dev_sym S, rldl_dev_n
   // reset_info of osqp_update_P_A (auxil.c:628-645: status = OSQP_UNSOLVED, rho_updates = 0) rides along: no launch of its own
   if (status_reset && threadIdx.x == 0) { status_reset[blockIdx.x] = ST_UNSOLVED; rho_updates_reset[blockIdx.x] = 0; }
 }
+// New P AND A values (osqp_update_P_A): the whole KKT row of the instance is rebuilt in LDS -- P (+ sigma on its diagonal), A, the
+// -1/rho entries from rho_inv, the bare sigma entries -- and written out front to back: coalesced 512-byte stores instead of one
+// scattered 8-byte store per value (k_kkt_assemble's scatter into Kx: 980 of them per instance of the metric shape).  The workspace's
+// own copies of the values and reset_info ride along as in k_kkt_assemble.  Dynamic LDS: nnzK doubles.
+__global__ __launch_bounds__(256) void k_kkt_assemble_full(rldl_dev_sym S, rldl_dev_num Nn, const double *__restrict__ Px, const double *__restrict__ Ax,
+                                                           double *__restrict__ keepP, double *__restrict__ keepA,
+                                                           int *__restrict__ status_reset, int *__restrict__ rho_updates_reset) {
+  extern __shared__ double kr[];
+  const int inst = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+  const double *p = Px + (size_t)inst * S.nnzP, *a = Ax + (size_t)inst * S.nnzA, *ri = Nn.rho_inv + (size_t)inst * S.m;
+  double *kp = keepP ? keepP + (size_t)inst * S.nnzP : nullptr, *ka = keepA ? keepA + (size_t)inst * S.nnzA : nullptr;
+  constexpr int U = 4;                                           // rounds of loads in flight per thread
+  for (int i0 = 0; i0 < S.nnzP; i0 += U * nt) {
+    double v[U];
+    int k[U], dg[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) { const int i = min(i0 + u * nt + tid, S.nnzP - 1); v[u] = p[i]; k[u] = S.PtoK[i]; dg[u] = S.Pisdiag[i]; }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int i = i0 + u * nt + tid;
+      if (i < S.nnzP) { kr[k[u]] = v[u] + (dg[u] ? Nn.sigma : 0.0); if (kp) kp[i] = v[u]; }
+    }
+  }
+  for (int i0 = 0; i0 < S.nnzA; i0 += U * nt) {
+    double v[U];
+    int k[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) { const int i = min(i0 + u * nt + tid, S.nnzA - 1); v[u] = a[i]; k[u] = S.AtoK[i]; }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int i = i0 + u * nt + tid;
+      if (i < S.nnzA) { kr[k[u]] = v[u]; if (ka) ka[i] = v[u]; }
+    }
+  }
+  for (int j = tid; j < S.m; j += nt) kr[S.rhotoK[j]] = -ri[j];
+  for (int i = tid; i < S.nsig; i += nt) kr[S.sigK[i]] = Nn.sigma;
+  __syncthreads();
+  double *K = Nn.Kx + (size_t)inst * S.nnzK;
+  for (int k = tid; k < S.nnzK; k += nt) K[k] = kr[k];
+  if (status_reset && tid == 0) { status_reset[inst] = ST_UNSOLVED; rho_updates_reset[inst] = 0; }
+}
 // rho_vec of the instances whose rho moved (W.refactor) into rho_inv and the KKT values, every group of a set (update_rho_vec, qdldl_interface.c:605-619)
 __global__ __launch_bounds__(256) void k_kkt_assemble_multi_rho(rldl_dev_multi M) {
   const int g = multi_group(M.first_inst, M.ngroups, blockIdx.x);
@@ -4224,9 +4265,15 @@ extern "C" int rldl_launch_kkt_assemble(const rldl_dev_sym *S, const rldl_dev_nu
 extern "C" int rldl_launch_kkt_assemble_keep(const rldl_dev_sym *S, const rldl_dev_num *Nn, const double *d_Px, const double *d_Ax,
                                              double *keepP, double *keepA, int *d_status_reset, int *d_rho_updates_reset, void *stream) {
   if (Nn->batch <= 0) return 0;
+  int *sr = d_status_reset && d_rho_updates_reset ? d_status_reset : (int *)0;
+  static const int scatter = getenv("RLDL_ASSEMBLE_SCATTER") ? 1 : 0;   // (A/B: the scatter kernel also for full updates)
+  if (d_Px && d_Ax && !S->polish && !scatter && sizeof(double) * (size_t)S->nnzK <= 48 * 1024) {   // both value sets: the row is rebuilt in LDS
+    hipLaunchKernelGGL(k_kkt_assemble_full, dim3(Nn->batch), dim3(256), sizeof(double) * (size_t)S->nnzK, (hipStream_t)stream, *S, *Nn, d_Px, d_Ax,
+                       keepP, keepA, sr, d_rho_updates_reset);
+    return launch_status();
+  }
   hipLaunchKernelGGL(k_kkt_assemble, dim3(Nn->batch), dim3(256), 0, (hipStream_t)stream, *S, *Nn, d_Px, d_Ax, (const double *)0, 0,
-                     (const int *)0, d_Px ? keepP : (double *)0, d_Ax ? keepA : (double *)0,
-                     d_status_reset && d_rho_updates_reset ? d_status_reset : (int *)0, d_rho_updates_reset);
+                     (const int *)0, d_Px ? keepP : (double *)0, d_Ax ? keepA : (double *)0, sr, d_rho_updates_reset);
   return launch_status();
 }
 // start of osqp_solve for the whole batch in one launch: status = OSQP_UNSOLVED, rho_updates = 0 (reset_info, auxil.c:628-645),
