@@ -2584,22 +2584,6 @@ __device__ __forceinline__ void arrow_factor_body(const rldl_dev_sym &S, const r
   double dcur = readlane_f64(w[0], 0), lcur = w[0] * recip_nr(dcur);
   pc[lane] = lane < g ? w[0] : 0.0;                              // (unscaled column, see elim_step)
   elim_steps<SM, LCH>(std::make_integer_sequence<int, SM>(), w, pc, g, lane, dcur, lcur, zero, npos);
-  } else {
-#pragma unroll
-  for (int j = 0; j < SM; j++) {
-    if (j < g) {                                                 // uniform
-      const double d = readlane_f64(w[j], j);
-      if (d == 0.0) zero = 1;
-      if (lane == 0 && d > 0.0) npos++;
-      const double dinv = recip_nr(d);
-      const double a = w[j];
-      const double l = a * dinv;
-      const double lv = lane < g ? l : 0.0;                      // pivot column, one entry per lane: broadcast by v_readlane
-      if (lane > j) w[j] = l;                                    // (no LDS round trip per column; the VALUs have room at 2 waves per SIMD)
-#pragma unroll
-      for (int k = j + 1; k < SM; k++) w[k] = fma(-a, readlane_f64(lv, k), w[k]);
-    }
-  }
   }
   if (tr) tr[4] = wall_clock64();
   // back to the CSC workspace, then the common coalesced write-out in plan slot order (the positions are fetched again: 56 registers
@@ -4309,9 +4293,7 @@ static int launch_factor(const rldl_dev_sym *S, const rldl_dev_num *Nn, const in
       const size_t il = sizeof(double) * (size_t)((g * (g - 1)) / 2 + 2 + 2 * LCH + 64 + 256 * ((g + 15) / 16));
       if (S->tile_ok && Nn->Ti && S->arrow_tb == 0 && !split) {               // (the conditions of launch_tile_invert)
         const size_t fl = al > il ? al : il;
-        static const int rl = getenv("RLDL_READLANE_PIVOT") ? 1 : 0;          // (A/B: pivot column by v_readlane, as in round 2)
-#define AF(SMV) do { if (rl) hipLaunchKernelGGL((k_arrow_factor<SMV, true, false>), grid, blk, fl, (hipStream_t)stream, *S, *Nn, d_mask, d_trace); \
-                     else hipLaunchKernelGGL((k_arrow_factor<SMV, true, true>), grid, blk, fl, (hipStream_t)stream, *S, *Nn, d_mask, d_trace); } while (0)
+#define AF(SMV) hipLaunchKernelGGL((k_arrow_factor<SMV, true, true>), grid, blk, fl, (hipStream_t)stream, *S, *Nn, d_mask, d_trace)
         if (g <= 16) AF(16); else if (g <= 32) AF(32); else if (g <= 48) AF(48); else if (g <= 56) AF(56); else AF(64);
 #undef AF
         return launch_status();
