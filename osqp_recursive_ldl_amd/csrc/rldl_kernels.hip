@@ -49,15 +49,34 @@
 
 namespace {
 
+// Wave-wide reductions without LDS: four DPP steps reduce every row of 16 lanes (quad swaps, then the half-row and row mirrors: all
+// lanes of a row end with the row's value), v_readlane fetches the four row values and the rest is scalar-operand arithmetic.
+// (__shfl_xor on a double is two ds_bpermute_b32 + address arithmetic per step, six dependent LDS round trips per reduction; the
+// residual kernel does sixteen of them.)
+template <int CTRL>
+__device__ __forceinline__ double dpp_perm_f64(double v) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  return __hiloint2double(__builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false), __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ double wave_rows_f64(double v, int row) {   // value of lane 16 * row (row uniform)
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 16 * row), __builtin_amdgcn_readlane(__double2loint(v), 16 * row));
+}
 __device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { double t = __shfl_xor(v, o); v = t > v ? t : v; }
-  return v;
+  double t;
+  t = dpp_perm_f64<0xB1>(v); v = t > v ? t : v;                  // quad_perm [1, 0, 3, 2]
+  t = dpp_perm_f64<0x4E>(v); v = t > v ? t : v;                  // quad_perm [2, 3, 0, 1]
+  t = dpp_perm_f64<0x141>(v); v = t > v ? t : v;                 // row_half_mirror
+  t = dpp_perm_f64<0x140>(v); v = t > v ? t : v;                 // row_mirror
+  const double a = wave_rows_f64(v, 0), b = wave_rows_f64(v, 1), c = wave_rows_f64(v, 2), d = wave_rows_f64(v, 3);
+  const double ab = b > a ? b : a, cd = d > c ? d : c;
+  return cd > ab ? cd : ab;
 }
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
+  v += dpp_perm_f64<0xB1>(v);
+  v += dpp_perm_f64<0x4E>(v);
+  v += dpp_perm_f64<0x141>(v);
+  v += dpp_perm_f64<0x140>(v);
+  return (wave_rows_f64(v, 0) + wave_rows_f64(v, 1)) + (wave_rows_f64(v, 2) + wave_rows_f64(v, 3));
 }
 __device__ __forceinline__ int wave_any(int p) { return __any(p); }
 
