@@ -22,13 +22,17 @@ t2 = time.perf_counter()
 assert g.n_patterns == G
 r = g.solve()
 torch.cuda.synchronize()
-def timed(fn, reps=5):
+def timed(fn, reps=21):
+    """median of `reps` calls, each waited for (thousands of ctypes objects are alive here: an automatic full garbage collection
+    in the middle of a short loop costs 70 ms once and used to land in a 5-call average)"""
+    import gc
     fn(); torch.cuda.synchronize()
-    t = time.perf_counter()
+    gc.collect(); gc.disable()
+    ts = []
     for _ in range(reps):
-        fn()
-    torch.cuda.synchronize()
-    return 1e3 * (time.perf_counter() - t) / reps
+        t = time.perf_counter(); fn(); torch.cuda.synchronize(); ts.append(1e3 * (time.perf_counter() - t))
+    gc.enable()
+    return float(np.median(ts))
 solve_ms = timed(g.solve)
 vals = []
 for idx, w in g.groups:
