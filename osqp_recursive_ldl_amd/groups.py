@@ -172,12 +172,17 @@ class OSQPBatchGroups:
         if self._multi is not None:
             self._mstream.wait_event(ready)
             mv = [values[k] for k in self._members]
-            for v in mv:
-                v[0].record_stream(self._mstream); v[1].record_stream(self._mstream)
             G = len(mv)
-            px = (C.c_void_p * G)(*[C.c_void_p(v[0].data_ptr()) for v in mv])
-            ax = (C.c_void_p * G)(*[C.c_void_p(v[1].data_ptr()) for v in mv])
+            px = (C.c_void_p * G)(*[v[0].data_ptr() for v in mv])
+            ax = (C.c_void_p * G)(*[v[1].data_ptr() for v in mv])
             rc = _lib.lib().osqp_multi_update_P_A(self._multi, px, ax)
+            # the chain reads the caller's arrays on another stream: instead of telling the caching allocator about every one of
+            # them (record_stream: a millisecond of Python for a thousand groups), the producer stream waits for the chain's
+            # reads -- whatever the caller does next with these arrays, or with memory the allocator hands out again on that
+            # stream, runs behind them
+            done = torch.cuda.Event()
+            done.record(self._mstream)
+            torch.cuda.current_stream(self._dev).wait_event(done)
             if rc == 2:
                 rest = list(range(len(self.groups)))
             elif rc:
