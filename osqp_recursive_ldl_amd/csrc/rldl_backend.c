@@ -154,7 +154,7 @@ static int upload_symbolic(rldl_batch *h) {
   D->arrow_vsteps = s->arrow_vsteps; D->arrow_vrows = s->arrow_vrows;
   D->tile_ok = D->arrow_ok ? s->tile_ok : 0; D->tile_ta = s->tile_ta; D->tile_tq = s->tile_tq; D->tile_lanes = s->tile_lanes;
   D->nTi = s->nTi; D->ldTi = (s->nTi + 1) & ~1;
-  D->po_tlane = s->po_tlane; D->po_tmap = s->po_tmap; D->po_tislot = s->po_tislot; D->po_tmask = s->po_tmask; D->po_pinv = s->po_pinv; D->po_trc = s->po_trc;
+  D->po_tlane = s->po_tlane; D->po_tmap = s->po_tmap; D->po_tislot = s->po_tislot; D->po_tmask = s->po_tmask; D->po_pinv = s->po_pinv; D->po_trc = s->po_trc; D->po_spack = s->po_spack;
   D->tile_admm_ok = D->tile_ok ? s->tile_admm_ok : 0; D->tile_scatter_ok = D->tile_ok ? s->tile_scatter_ok : 0; D->tile_vslots = s->tile_vslots; D->tile_slots = s->tile_slots; D->po_tpos = s->po_tpos;
   D->tile_ck[0] = s->tile_ck[0]; D->tile_ck[1] = s->tile_ck[1]; D->tile_ck[2] = s->tile_ck[2]; D->tile_tk = s->tile_tk; D->tile_sp = s->tile_sp;
   D->po_cmap = s->po_cmap; D->po_crow = s->po_crow;

@@ -85,7 +85,7 @@ typedef struct {
   int arrow_ok, arrow_group, arrow_steps; /* arrowhead specialisation (see rldl_plan.c) */
   int arrow_vsteps, arrow_vrows;          /* virtual rows: coupling rows cut into pieces of <= vsteps entries, one piece per lane */
   int tile_ok, tile_ta, tile_tq, tile_lanes, nTi, ldTi;   /* tail inverse by register tiles (rldl_symbolic.h); ldTi = nTi rounded up to even */
-  int po_tlane, po_tmap, po_tislot, po_tmask, po_pinv, po_trc;
+  int po_tlane, po_tmap, po_tislot, po_tmask, po_pinv, po_trc, po_spack;
   int tile_admm_ok, tile_scatter_ok, tile_vslots, tile_slots, po_tpos;   /* ADMM slots of the tile kernels (rldl_symbolic.h) */
   int tile_ck[3], tile_tk, tile_sp, po_cmap, po_crow;            /* backward coupling product gathered by the owner lane */
   int arrow_g0, arrow_g;       /* index range of the tail group */

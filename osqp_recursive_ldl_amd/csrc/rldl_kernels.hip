@@ -3460,21 +3460,25 @@ __global__ __launch_bounds__(256, (TA <= 5 && TG <= 18) ? 3 : 2) void k_tile_sol
   const __amdgpu_buffer_rsrc_t rD = __builtin_amdgcn_make_buffer_rsrc((void *)(Fg + S.nS), 0, 8 * S.N, 0x00020000);
   const __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc((void *)(Nn.rho_inv + (size_t)inst * S.m), 0, S.polish ? 0 : 8 * S.m, 0x00020000);
   const __amdgpu_buffer_rsrc_t rTi = __builtin_amdgcn_make_buffer_rsrc((void *)(Nn.Ti + (size_t)inst * S.ldTi), 0, 8 * S.nTi, 0x00020000);
-  const unsigned l4 = 4u * (unsigned)lane, l8 = 8u * (unsigned)lane;
+  const unsigned l8 = 8u * (unsigned)lane;
   // ---- phase A: issue every load of the wave.  Tables first (L2-resident, needed first; vmcnt retires in order), then the rows
   // of this instance: b, Dinv, the coupling values (LDS-DMA), the lane's tile of Linv. ----
-  unsigned pw[TMAX], cw[(TG + 1) / 2], mw[(TG + 1) / 2], rcw[TA];
+  // (the table words of a lane sit side by side in 16-byte records, [chunk][lane][4]: one load per chunk, rldl_plan.c po_spack)
+  unsigned pw[TMAX], cw[(TG + 1) / 2], mw[(TG + 1) / 2], rcw[TA], tlw, jrw;
+  {
+    constexpr int H = (TG + 1) / 2, NWP = TMAX + 2 * H + TA + 2, NCH = (NWP + 3) / 4;
+    pv_v4u rk[NCH];
 #pragma unroll
-  for (int t = 0; t < TMAX; t++) pw[t] = __builtin_amdgcn_raw_buffer_load_b32(rP, l4 + 4u * (unsigned)(S.po_pinv + 64 * t), 0, 0);
+    for (int c = 0; c < NCH; c++) rk[c] = __builtin_amdgcn_raw_buffer_load_b128(rP, 16u * (unsigned)lane + 4u * (unsigned)(S.po_spack + 256 * c), 0, 0);
 #pragma unroll
-  for (int t2 = 0; t2 < (TG + 1) / 2; t2++) {
-    cw[t2] = __builtin_amdgcn_raw_buffer_load_b32(rP, l4 + 4u * (unsigned)(S.po_avcol + 64 * t2), 0, 0);
-    mw[t2] = __builtin_amdgcn_raw_buffer_load_b32(rP, l4 + 4u * (unsigned)(S.po_avmap + 64 * t2), 0, 0);
+    for (int t = 0; t < TMAX; t++) pw[t] = rk[t / 4][t % 4];
+#pragma unroll
+    for (int t2 = 0; t2 < H; t2++) { cw[t2] = rk[(TMAX + t2) / 4][(TMAX + t2) % 4]; mw[t2] = rk[(TMAX + H + t2) / 4][(TMAX + H + t2) % 4]; }
+#pragma unroll
+    for (int sx = 0; sx < TA; sx++) rcw[sx] = rk[(TMAX + 2 * H + sx) / 4][(TMAX + 2 * H + sx) % 4];
+    tlw = rk[(TMAX + 2 * H + TA) / 4][(TMAX + 2 * H + TA) % 4];
+    jrw = rk[(TMAX + 2 * H + TA + 1) / 4][(TMAX + 2 * H + TA + 1) % 4];
   }
-#pragma unroll
-  for (int sx = 0; sx < TA; sx++) rcw[sx] = __builtin_amdgcn_raw_buffer_load_b32(rP, l4 + 4u * (unsigned)(S.po_trc + 64 * sx), 0, 0);
-  const unsigned tlw = __builtin_amdgcn_raw_buffer_load_b32(rP, l4 + 4u * (unsigned)S.po_tlane, 0, 0);
-  const unsigned jrw = __builtin_amdgcn_raw_buffer_load_b32(rP, l4 + 4u * (unsigned)S.po_avrow, 0, 0);
   pv_v2u blr[TMAX], dlr[TMAX], rrr[TMAX];
 #pragma unroll
   for (int t = 0; t < TMAX; t++) {
@@ -4157,7 +4161,7 @@ static bool tile_admm_usable(const rldl_dev_sym *S, const rldl_dev_num *Nn, cons
 static int tile_solve3_cwp(const rldl_dev_sym *S) { return ((S->nOp + 127) / 128) * 128; }
 static bool tile_solve3_usable(const rldl_dev_sym *S) {
   static const int off = getenv("RLDL_SOLVE_V2") ? 1 : 0;
-  return !off && S->po_tmask > 0 && sizeof(double) * (size_t)(tile_solve3_cwp(S) + tile_per_wave(S) + WAVE) * TILE_WPB < 65536;
+  return !off && S->po_tmask > 0 && S->po_spack > 0 && sizeof(double) * (size_t)(tile_solve3_cwp(S) + tile_per_wave(S) + WAVE) * TILE_WPB < 65536;
 }
 static int launch_tile_solve3(const rldl_dev_sym *S, const rldl_dev_num *Nn, double *d_b, long long *d_trace, void *stream) {
   const int pw = tile_per_wave(S), cwp = tile_solve3_cwp(S), grid = (Nn->batch + TILE_WPB - 1) / TILE_WPB;

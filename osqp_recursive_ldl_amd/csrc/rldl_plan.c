@@ -187,7 +187,7 @@ int rldl_plan_build(rldl_symbolic *s) {
   s->po_avrow = words; words += s->arrow_ok ? 64 : 0;                                 /* row (permuted index) of the lane's piece */
   /* tail inverse by register tiles (see rldl_symbolic.h): tile size from the set the kernels are compiled for */
   s->tile_ok = 0; s->tile_ta = 0; s->tile_tq = 0; s->tile_lanes = 0; s->nTi = 0;
-  s->po_tlane = s->po_tmap = s->po_tislot = s->po_tmask = s->po_pinv = s->po_trc = 0;
+  s->po_tlane = s->po_tmap = s->po_tislot = s->po_tmask = s->po_pinv = s->po_trc = s->po_spack = 0;
   if (s->arrow_ok && coloff[gstart[arrow_k]] == nOp) {
     static const int tas[4] = {2, 3, 5, 7};
     const int g = gstart[arrow_k + 1] - gstart[arrow_k];
@@ -248,6 +248,13 @@ int rldl_plan_build(rldl_symbolic *s) {
       }
       s->po_cmap = words; words += (s->tile_tk / 2) * 64;
       s->po_crow = words; words += (s->tile_tk / 2) * 64;
+      /* the solve kernel's per-lane table words (k_tile_solve3: pinv 3, avcol H, avmap H, trc a, tlane, avrow; H = vpad / 2) once more as
+       * 16-byte records, [chunk][64 lanes][4 words]: one wide load per chunk instead of one 4-byte load per word (28 -> 7 on the metric shape) */
+      s->po_spack = 0;
+      if (vpad <= 24) {
+        words = (words + 3) & ~3;
+        s->po_spack = words; words += 4 * 64 * ((3 + 2 * ((vpad + 1) / 2) + a + 2 + 3) / 4);
+      }
     }
   }
   blob = (int *)calloc((size_t)words + 4, sizeof(int));
@@ -538,6 +545,15 @@ int rldl_plan_build(rldl_symbolic *s) {
     for (k = 0; k < nbs; k++) { blob[s->po_bsb + k] = bsteps_base[k]; blob[s->po_bsc + k] = bsteps_cnt[k]; }
   }
 
+  if (s->tile_ok && s->po_spack > 0) {                       /* every source table is filled: pack (order = the kernel's word index) */
+    const int H = (vpad + 1) / 2, a = s->tile_ta, nw = 3 + 2 * H + a + 2;
+    int q, l;
+    for (q = 0; q < nw; q++) {
+      const int src = q < 3 ? s->po_pinv + 64 * q : q < 3 + H ? s->po_avcol + 64 * (q - 3) : q < 3 + 2 * H ? s->po_avmap + 64 * (q - 3 - H)
+                    : q < 3 + 2 * H + a ? s->po_trc + 64 * (q - 3 - 2 * H) : q == 3 + 2 * H + a ? s->po_tlane : s->po_avrow;
+      for (l = 0; l < 64; l++) blob[s->po_spack + 256 * (q / 4) + 4 * l + (q % 4)] = blob[src + l];
+    }
+  }
   s->plan = blob; blob = 0;
   s->plan_words = words;
   s->plan_ok = 1;

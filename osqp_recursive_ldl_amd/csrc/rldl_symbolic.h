@@ -74,6 +74,7 @@ typedef struct {
    *   po_trc    [ta][64]             word s of the lane = rotated row s | rotated column s << 16 of its tile, local to the tail group */
   int tile_ok, tile_ta, tile_tq, tile_lanes, nTi;
   int po_tlane, po_tmap, po_tislot, po_tmask, po_pinv, po_trc;
+  int po_spack;                /* k_tile_solve3's per-lane table words as 16-byte records [chunk][64][4] (0: none) */
   /* ADMM slots of the tile kernels: the permuted positions are dealt to (slot, lane) so that a slot holds variables only or
    * constraints only (uniform code per slot, no per-lane role test): po_tpos [3][64] = permuted position or -1;
    * tile_vslots = number of leading variable slots, tile_slots = slots in use (<= 3; more -> tile_admm_ok = 0) */
